@@ -1,0 +1,197 @@
+/*
+ * whisper_hip.h — C ABI of libwhisper_hip.so, the MI355X (gfx950) native Whisper inference path.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers + sizes + a hipStream_t (passed as
+ * void*), and returns an int status (WH_OK == 0).  No torch types cross this boundary.  Memory is
+ * owned by the caller: the library computes how many bytes it needs (…_bytes functions), the caller
+ * hands it one workspace pointer, and the library only carves it.
+ *
+ * Each function names the reference interface (openai/whisper @ v20250625, file:line under
+ * /root/reference/) it stands in for.  The reference has no C FFI — its "operator API" for the hot
+ * path is the Python seam `Inference.logits / rearrange_kv_cache / cleanup_caching`
+ * (whisper/decoding.py:130-141), `model.encoder(mel)` (whisper/model.py:188), `log_mel_spectrogram`
+ * (whisper/audio.py:110) and `median_filter` / `dtw` (whisper/timing.py:19,141).  INTEGRATION.md shows
+ * the ctypes stub a reference maintainer would add at each of those seams.
+ */
+#ifndef WHISPER_HIP_H
+#define WHISPER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WH_ABI_VERSION 1
+#define WH_MEL_SCRATCH_BYTES 2048
+
+/* status codes */
+enum {
+  WH_OK = 0,
+  WH_ERR_ARG = 1,        /* invalid argument (shape / null pointer / unsupported size) */
+  WH_ERR_WORKSPACE = 2,  /* workspace too small */
+  WH_ERR_HIP = 3,        /* a HIP runtime call failed; see wh_last_hip_error() */
+  WH_ERR_STATE = 4,      /* call sequence violation (e.g. step before prefill) */
+  WH_ERR_LIMIT = 5       /* exceeds a compiled-in limit (rows, LDS) */
+};
+
+/* element type of weights / activations / KV caches. Accumulation is always fp32. */
+enum { WH_F32 = 0, WH_F16 = 1 };
+
+/* ModelDimensions — whisper/model.py:25-36 (same ten integers, same order). */
+typedef struct wh_dims {
+  int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+  int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+} wh_dims;
+
+/*
+ * Packed weights of one ResidualAttentionBlock — whisper/model.py:142-171.
+ * Matrices are row-major [out][in] in the model element type (WH_F32 / WH_F16);
+ * LayerNorm parameters and biases are always fp32.
+ *   qkv_w  = rows [query; key; value] of block.attn      (3D x D); qkv_b has zeros for `key` (model.py:88)
+ *   ckv_w  = rows [key; value] of block.cross_attn       (2D x D); ckv_b has zeros for `key`
+ * Encoder blocks leave the cross-attention pointers NULL.
+ */
+typedef struct wh_layer_weights {
+  const float *attn_ln_w, *attn_ln_b;
+  const void *qkv_w;  const float *qkv_b;
+  const void *out_w;  const float *out_b;
+  const float *cross_ln_w, *cross_ln_b;
+  const void *cq_w;   const float *cq_b;
+  const void *ckv_w;  const float *ckv_b;
+  const void *cout_w; const float *cout_b;
+  const float *mlp_ln_w, *mlp_ln_b;
+  const void *fc1_w;  const float *fc1_b;
+  const void *fc2_w;  const float *fc2_b;
+} wh_layer_weights;
+
+/*
+ * Whole-model weight table.
+ *   conv1_w : [D][Kc1] with Kc1 = round_up(3*n_mels, 64), element (d, kk*n_mels + c) = conv1.weight[d][c][kk]
+ *   conv2_w : [D][3*D], element (d, kk*D + c) = conv2.weight[d][c][kk]      (model.py:182-183)
+ *   enc_pos : encoder.positional_embedding, fp32 [n_audio_ctx][D]           (model.py:184)
+ *   tok_emb : decoder.token_embedding.weight [n_vocab][D] (element type; also the tied logits matrix, model.py:245)
+ *   dec_pos : decoder.positional_embedding fp32 [n_text_ctx][D]             (model.py:214)
+ */
+typedef struct wh_model_weights {
+  const void *conv1_w; const float *conv1_b;
+  const void *conv2_w; const float *conv2_b;
+  const float *enc_pos;
+  const wh_layer_weights *enc_layers;   /* n_audio_layer entries (host array) */
+  const float *enc_ln_post_w, *enc_ln_post_b;
+  const void *tok_emb;
+  const float *dec_pos;
+  const wh_layer_weights *dec_layers;   /* n_text_layer entries (host array) */
+  const float *dec_ln_w, *dec_ln_b;
+} wh_model_weights;
+
+typedef struct wh_model wh_model;   /* opaque: dims + copies of the pointer tables */
+typedef struct wh_task wh_task;     /* opaque: per-DecodingTask KV caches + workspace carve-up */
+
+/* ---- library ------------------------------------------------------------------------------ */
+int wh_abi_version(void);
+const char *wh_status_string(int status);
+int wh_last_hip_error(void);            /* hipError_t of the last failing runtime call on this thread */
+const char *wh_last_hip_error_string(void);
+
+/* ---- audio front end: log_mel_spectrogram — whisper/audio.py:110-157 ----------------------- */
+/* audio: fp32 [batch][n_samples] (already zero-padded by `padding`, audio.py:145-146);
+ * filters: fp32 [n_mels][201] (mel_filters(), audio.py:91-107); out: fp32 [batch][n_mels][n_samples/160].
+ * The global max of audio.py:155 is taken over the whole [batch] tensor, as the reference does.
+ * scratch: >= WH_MEL_SCRATCH_BYTES bytes of device memory. n_samples > 200 (reflect padding). */
+int wh_log_mel(const float *audio, int64_t n_samples, int batch, int n_mels, const float *filters,
+               float *out, void *scratch, void *stream);
+
+/* ---- model handle -------------------------------------------------------------------------- */
+/* Stands in for Whisper.__init__ + load_state_dict (whisper/__init__.py:154-156): the caller has
+ * already packed the checkpoint into device memory; this only records dims and pointers. */
+int wh_model_create(const wh_dims *dims, int dtype, const wh_model_weights *weights, wh_model **out);
+void wh_model_destroy(wh_model *m);
+
+/* ---- AudioEncoder.forward — whisper/model.py:188-204 --------------------------------------- */
+size_t wh_encoder_workspace_bytes(const wh_model *m, int batch);
+/* mel: [batch][n_mels][2*n_audio_ctx] in fp32 (mel_is_f16 == 0) or fp16 (1);
+ * out: [batch][n_audio_ctx][D] in the model element type. */
+int wh_encode(const wh_model *m, const void *mel, int mel_is_f16, int batch, void *out,
+              void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- decoding task: PyTorchInference + kv_cache — whisper/decoding.py:144-176, model.py:310-341 */
+/* flags for wh_task_create */
+enum { WH_TASK_CAPTURE_Q = 1 };   /* keep cross-attention queries of every layer (word timestamps) */
+size_t wh_task_workspace_bytes(const wh_model *m, int n_audio, int n_group, int max_prefill_tokens,
+                               int flags);
+int wh_task_create(const wh_model *m, int n_audio, int n_group, int max_prefill_tokens, int flags,
+                   void *workspace, size_t workspace_bytes, wh_task **out);
+void wh_task_destroy(wh_task *t);
+/* Cross-attention K/V of every decoder layer from the encoder output (the `key`/`value` Linear of
+ * block.cross_attn applied to xa, model.py:101-105; cached by the hook at model.py:327-330).
+ * features: [n_audio][n_audio_ctx][D] element type. */
+int wh_task_set_audio(wh_task *t, const void *features, void *stream);
+/* First Inference.logits call (decoding.py:155-163 with an empty kv_cache): feeds T0 tokens per row,
+ * fills the self-attention caches at positions [offset, offset+T0) and returns fp32 logits.
+ *   tokens: int64 [n_rows][token_stride] device; uses columns [0, T0)
+ *   sel_pos/n_sel: host int array of positions in [0,T0) whose logits are wanted (NULL -> all T0);
+ *   logits_out: fp32 [n_rows][n_sel][n_vocab].
+ * May be called repeatedly (T0 >= 1) to append teacher-forced tokens; n_rows = n_audio * n_group. */
+int wh_task_prefill(wh_task *t, const int64_t *tokens, int64_t token_stride, int T0,
+                    const int32_t *sel_pos, int n_sel, float *logits_out, void *stream);
+/* Later Inference.logits calls (decoding.py:159-163): one new token per row.
+ *   last_tokens: int64 device, row r at last_tokens[r*token_stride]; logits_out: fp32 [n_rows][n_vocab]. */
+int wh_task_step(wh_task *t, const int64_t *last_tokens, int64_t token_stride, float *logits_out,
+                 void *stream);
+/* Inference.rearrange_kv_cache (decoding.py:172-176): new row i takes the self-attention cache of
+ * old row source_indices[i] (host array of n_rows ints). */
+int wh_task_rearrange(wh_task *t, const int32_t *source_indices, void *stream);
+/* Inference.cleanup_caching (decoding.py:165-170): forget cached positions (keeps the audio). */
+int wh_task_reset(wh_task *t);
+/* number of cached self-attention positions (the `offset` of model.py:234) */
+int wh_task_position(const wh_task *t);
+
+/*
+ * Fused greedy sampling loop == DecodingTask._main_loop with GreedyDecoder(temperature=0) and the
+ * SuppressBlank / SuppressTokens / ApplyTimestampRules filters (decoding.py:272-298, 423-505, 680-710),
+ * run entirely on the device (no per-step host sync).
+ */
+typedef struct wh_greedy_params {
+  int32_t sample_begin;          /* len(initial_tokens), decoding.py:536 */
+  int32_t max_steps;             /* sample_len, decoding.py:529 (prefill step included) */
+  int32_t n_ctx;                 /* loop ends once token count > n_ctx, decoding.py:705 */
+  int32_t eot;                   /* tokenizer.eot */
+  int32_t timestamp_begin;       /* tokenizer.timestamp_begin; < 0 disables ApplyTimestampRules */
+  int32_t no_timestamps;         /* tokenizer.no_timestamps id or -1 */
+  int32_t max_initial_timestamp_index; /* decoding.py:561-565 or -1 */
+  int32_t suppress_blank;        /* 0/1, decoding.py:555-556 */
+  int32_t blank_token;           /* tokenizer.encode(" ")[0] */
+  const uint8_t *suppress_mask;  /* device [n_vocab] bytes: 1 = token in SuppressTokens list */
+} wh_greedy_params;
+/*
+ * tokens: int64 [n_rows][token_stride] device, columns [0,sample_begin) hold the initial tokens; the
+ * loop appends sampled tokens in place.  sum_logprobs: fp32 [n_rows] (zeroed by the call).
+ * no_speech_probs: fp32 [n_rows] out = softmax(logits at sot_index)[no_speech] (decoding.py:689-693),
+ * skipped when no_speech_token < 0.  n_tokens_out (host): final token count per row (same for all rows).
+ */
+int wh_task_greedy(wh_task *t, const wh_greedy_params *p, int64_t *tokens, int64_t token_stride,
+                   int sot_index, int no_speech_token, float *sum_logprobs, float *no_speech_probs,
+                   int32_t *n_tokens_out, void *stream);
+
+/* cross-attention QK of chosen heads for the cached positions — the `qk` captured by the hooks of
+ * find_alignment (whisper/timing.py:186-197; model.py:130-137 manual path): for every pair
+ * (layers[i], heads[i]) writes fp32 [n_tok][n_audio_ctx] = (q*scale)·(k*scale)ᵀ of row `row`.
+ * Requires a task created with WH_TASK_CAPTURE_Q; tokens [tok_begin, tok_begin+n_tok) must have been
+ * fed through wh_task_prefill. */
+int wh_task_cross_qk(wh_task *t, int row, const int32_t *layers, const int32_t *heads, int n_pairs,
+                     int tok_begin, int n_tok, float *out, void *stream);
+
+/* ---- word-timestamp kernels — whisper/timing.py:19-54 (median_filter), :82-151 (dtw) -------- */
+/* x: fp32 [rows][n] -> out: fp32 [rows][n], reflect-padded sliding median of odd `width` along n. */
+int wh_median_filter(const float *x, float *out, int64_t rows, int n, int width, void *stream);
+/* x: fp32 [N][M] cost matrix.  trace_out: int8 [N+1][M+1] with dtw_cpu's codes (0 diag, 1 up, 2 left)
+ * and dtw_cpu's tie rule (timing.py:95-100); row 0 / column 0 hold the codes backtrace() forces there
+ * (timing.py:61-62).  N <= 8192. */
+int wh_dtw_trace(const float *x, int N, int M, int8_t *trace_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WHISPER_HIP_H */

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+REFERENCE = "/root/reference"          # exists only in the build container, never on the GPU box
+SHIMS = os.path.join(ROOT, "tests", "shims")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    config.addinivalue_line("markers", "reference: needs the read-only reference checkout at /root/reference")
+
+
+def pytest_collection_modifyitems(config, items):
+    have_ref = os.path.isdir(os.path.join(REFERENCE, "whisper"))
+    skip_ref = pytest.mark.skip(reason="/root/reference not present (GPU box)")
+    for item in items:
+        if "reference" in item.keywords and not have_ref:
+            item.add_marker(skip_ref)
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("test marked gpu but no GPU is visible")
+    return torch.device("cuda:0")

@@ -1,0 +1,204 @@
+"""GPU parity tests of the individual HIP kernels / C-ABI entry points against the CPU oracle.
+All calls go through libwhisper_hip.so (whisper_amd.hip -> ctypes).  Tolerances are stated per test."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from whisper_amd import hip
+
+pytestmark = pytest.mark.gpu
+
+
+def _audio(seed, n=480000):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 16000.0
+    x = rng.standard_normal(n).astype(np.float32) * 0.05
+    x += (0.3 * np.sin(2 * np.pi * 440 * t) + 0.1 * np.sin(2 * np.pi * 1870 * t)).astype(np.float32)
+    return x
+
+
+@pytest.fixture(scope="module")
+def micro(gpu_device):
+    out = {}
+    for name in ("micro.en", "micro-v3"):
+        dims = oracle.dims_for(name)
+        sd = oracle.synthetic_state_dict(dims, seed=1)
+        om = oracle.OracleModel(dims, sd)
+        models = {}
+        for dt in (hip.WH_F32, hip.WH_F16):
+            blob = hip.pack_weights(sd, dims, dt, gpu_device)
+            models[dt] = hip.HipModel(dims, dt, blob)
+        out[name] = (dims, sd, om, models)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_mels", [80, 128])
+@pytest.mark.parametrize("shape", [(1, 480000), (2, 160000), (1, 16000 * 7 + 80)])
+def test_log_mel(gpu_device, n_mels, shape):
+    """fp32; atol 1e-4 (restatement-vs-torch.stft noise is 5.8e-5)."""
+    B, n = shape
+    a = np.stack([_audio(10 + b, n) for b in range(B)])
+    filt = oracle.mel_filterbank(n_mels)
+    want = oracle.log_mel_spectrogram(a, filt, dtype=torch.float64)
+    got = hip.log_mel(torch.from_numpy(a).to(gpu_device), torch.from_numpy(filt).to(gpu_device)).cpu()
+    assert got.shape == want.shape
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max().item()
+    assert err < 1e-4, err
+    assert got.max() - got.min() <= 2.0 + 1e-6          # tests/test_audio.py:19 invariant of the reference
+
+
+@pytest.mark.parametrize("name", ["micro.en", "micro-v3"])
+@pytest.mark.parametrize("dt,tol", [(hip.WH_F32, 2e-4), (hip.WH_F16, 3e-2)])
+def test_encoder(micro, gpu_device, name, dt, tol):
+    dims, sd, om, models = micro[name]
+    filt = oracle.mel_filterbank(dims.n_mels)
+    mel = torch.stack([oracle.log_mel_spectrogram(_audio(3 + b), filt) for b in range(2)])
+    want = om.encoder(mel)
+    got = models[dt].encode(mel.to(gpu_device)).float().cpu()
+    err = (got - want).abs().max().item()
+    assert torch.isfinite(got).all()
+    assert err < tol, err
+
+
+def _feats(om, dims, B, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, dims.n_audio_ctx, dims.n_audio_state, generator=g)
+
+
+@pytest.mark.parametrize("name", ["micro.en", "micro-v3"])
+@pytest.mark.parametrize("dt,tol", [(hip.WH_F32, 1e-3), (hip.WH_F16, 5e-2)])
+@pytest.mark.parametrize("B,G,T0", [(2, 1, 5), (1, 3, 17), (3, 1, 1)])
+def test_prefill_and_steps(micro, gpu_device, name, dt, tol, B, G, T0):
+    """Teacher-forced logits at every position: prefill (GEMM path) then 6 single-token steps (GEMV path,
+    the 2nd onwards replayed from the hipGraph) vs the oracle's KV-cache decoder.  fp32: |dlogit| < 1e-3."""
+    dims, sd, om, models = micro[name]
+    model = models[dt]
+    R = B * G
+    feats = _feats(om, dims, B, seed=B * 7 + G)
+    g = torch.Generator().manual_seed(5)
+    toks = torch.randint(0, dims.n_vocab, (R, T0 + 6), generator=g)
+    cache = om.new_cache()
+    want0 = om.decoder(toks[:, :T0], feats, cache)
+    task = hip.HipTask(model, B, G, max(T0, 8))
+    try:
+        task.set_audio(feats.to(gpu_device, model.torch_dtype).contiguous())
+        dtoks = toks.to(gpu_device)
+        got0 = task.prefill(dtoks[:, :T0].contiguous()).cpu()
+        assert (got0 - want0).abs().max().item() < tol
+        for i in range(6):
+            want = om.decoder(toks[:, T0 + i: T0 + i + 1], feats, cache)[:, -1]
+            got = task.step(dtoks[:, T0 + i]).cpu()
+            err = (got - want).abs().max().item()
+            assert err < tol, (i, err)
+        assert task.position == T0 + 6
+        # selected positions only
+        task.reset()
+        sel = [0, T0 - 1]
+        got_sel = task.prefill(dtoks[:, :T0].contiguous(), sel=sel).cpu()
+        assert (got_sel - want0[:, sel]).abs().max().item() < tol
+    finally:
+        task.close()
+
+
+def test_rearrange(micro, gpu_device):
+    """rearrange_kv_cache (decoding.py:172-176): permuting rows of the self-attention cache == permuting rows."""
+    dims, sd, om, models = micro["micro.en"]
+    model = models[hip.WH_F32]
+    B, G, T0 = 1, 4, 6
+    feats = _feats(om, dims, B)
+    g = torch.Generator().manual_seed(9)
+    toks = torch.randint(0, dims.n_vocab, (G, T0 + 1), generator=g)
+    src = [2, 0, 0, 3]
+    cache = om.new_cache()
+    om.decoder(toks[:, :T0], feats, cache)
+    om.rearrange(cache, src)
+    nxt = toks[:, T0:T0 + 1]
+    want = om.decoder(nxt, feats, cache)[:, -1]
+    task = hip.HipTask(model, B, G, 8)
+    try:
+        task.set_audio(feats.to(gpu_device).contiguous())
+        task.prefill(toks[:, :T0].contiguous().to(gpu_device), sel=[T0 - 1])
+        task.rearrange(src)
+        got = task.step(nxt[:, 0].to(gpu_device)).cpu()
+        assert (got - want).abs().max().item() < 1e-3
+    finally:
+        task.close()
+
+
+def _rules(dims, T0, with_ts=True):
+    multilingual = dims.n_vocab >= 51865
+    eot = 50257 if multilingual else 50256
+    nl = dims.n_vocab - 51765 - int(multilingual)
+    sot = eot + 1
+    transcribe = sot + 1 + nl + 1
+    no_speech = transcribe + 3
+    no_ts = no_speech + 1
+    rng = np.random.default_rng(0)
+    suppress = sorted(set(rng.integers(0, 50000, 80).tolist() + [sot, transcribe, transcribe - 1, no_speech]))
+    return oracle.SamplingRules(sample_begin=T0, sot_index=0, eot=eot, n_ctx=dims.n_text_ctx,
+                                timestamp_begin=(no_ts + 1) if with_ts else None, no_timestamps=no_ts,
+                                max_initial_timestamp_index=50, suppress_blank=True, blank_token=220,
+                                suppress_tokens=suppress, no_speech=no_speech)
+
+
+@pytest.mark.parametrize("name", ["micro.en", "micro-v3"])
+@pytest.mark.parametrize("with_ts", [True, False])
+def test_fused_greedy(micro, gpu_device, name, with_ts):
+    """wh_task_greedy (device-side filters + argmax) vs the oracle's row-wise loop: token ids exact,
+    sum_logprobs within 1e-3, fp32 strict mode; 40 steps, 3 rows."""
+    dims, sd, om, models = micro[name]
+    model = models[hip.WH_F32]
+    B, n_steps = 3, 40
+    init = [50258 if dims.n_vocab >= 51865 else 50257]
+    if dims.n_vocab >= 51865:
+        init = [50258, 50259, 50258 + 1 + (dims.n_vocab - 51765 - 1) + 1]
+    if not with_ts:
+        init = init + [_rules(dims, 1).no_timestamps]
+    T0 = len(init)
+    rules = _rules(dims, T0, with_ts)
+    feats = _feats(om, dims, B, seed=11)
+    want = oracle.greedy_decode(om, feats, init, n_steps, rules)
+    task = hip.HipTask(model, B, 1, 8)
+    try:
+        task.set_audio(feats.to(gpu_device).contiguous())
+        tokens = torch.zeros(B, T0 + n_steps + 1, dtype=torch.int64, device=gpu_device)
+        tokens[:, :T0] = torch.tensor(init)
+        mask = torch.zeros(dims.n_vocab, dtype=torch.uint8)
+        mask[rules.suppress_tokens] = 1
+        mask = mask.to(gpu_device)
+        p = hip.GreedyParams(sample_begin=T0, max_steps=n_steps, n_ctx=dims.n_text_ctx, eot=rules.eot,
+                             timestamp_begin=rules.timestamp_begin if with_ts else -1,
+                             no_timestamps=rules.no_timestamps, max_initial_timestamp_index=50,
+                             suppress_blank=1, blank_token=220, suppress_mask=mask.data_ptr())
+        n, sum_lp, nsp = task.greedy(tokens, p, 0, rules.no_speech)
+        torch.cuda.synchronize()
+        wt = want["tokens"]
+        assert n == wt.shape[1], (n, wt.shape)
+        assert torch.equal(tokens[:, :n].cpu(), wt)
+        assert np.allclose(sum_lp.cpu().numpy(), np.array(want["sum_logprobs"]), atol=2e-3)
+        assert np.allclose(nsp.cpu().numpy(), np.array(want["no_speech_probs"]), rtol=1e-3, atol=1e-7)
+    finally:
+        task.close()
+
+
+@pytest.mark.parametrize("shape", [(10,), (1, 15), (4, 5, 345), (6, 12, 240, 512)])
+def test_median_filter(gpu_device, shape):
+    """shapes and widths of the reference's tests/test_timing.py:14-19,67-84; exact (order statistics)."""
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(0))
+    for w in [3, 5, 7, 13]:
+        want = oracle.median_filter(x.numpy(), w)
+        got = hip.median_filter(x.to(gpu_device), w).cpu().numpy()
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("N,M", [(10, 20), (32, 16), (123, 1500), (234, 189)])
+def test_dtw(gpu_device, N, M):
+    """sizes of tests/test_timing.py:8-13; trace equal to dtw_cpu's on random input (integer codes: exact)."""
+    x = np.random.default_rng(N * M).standard_normal((N, M)).astype(np.float32)
+    want = oracle.dtw_trace(x)
+    got = hip.dtw_trace(torch.from_numpy(x).to(gpu_device)).cpu().numpy()
+    assert np.array_equal(got[1:, 1:], want[1:, 1:])
+    assert np.array_equal(oracle.backtrace(got), oracle.backtrace(want))

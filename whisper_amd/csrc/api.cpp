@@ -1,0 +1,714 @@
+// api.cpp — the C ABI of libwhisper_hip.so (see include/whisper_hip.h) and the host-side orchestration
+// of the encoder pass, the decoder prefill, the hipGraph-captured decode step and the fused greedy loop.
+// Host code only: all device work is in the .hip files behind kernels.h.
+#include "../../include/whisper_hip.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <new>
+#include <vector>
+
+using namespace whk;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local hipError_t g_last_hip = hipSuccess;
+
+#define HIPCHK(expr)                                   \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) { g_last_hip = _e; return WH_ERR_HIP; } \
+  } while (0)
+
+extern "C" int wh_abi_version(void) { return WH_ABI_VERSION; }
+extern "C" const char* wh_status_string(int s) {
+  switch (s) {
+    case WH_OK: return "ok";
+    case WH_ERR_ARG: return "invalid argument";
+    case WH_ERR_WORKSPACE: return "workspace too small";
+    case WH_ERR_HIP: return "HIP runtime error";
+    case WH_ERR_STATE: return "invalid call sequence";
+    case WH_ERR_LIMIT: return "compiled-in limit exceeded";
+    default: return "unknown status";
+  }
+}
+extern "C" int wh_last_hip_error(void) { return (int)g_last_hip; }
+extern "C" const char* wh_last_hip_error_string(void) { return hipGetErrorString(g_last_hip); }
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Carver {   // bump allocator over the caller's workspace; with base == nullptr it only sizes
+  char* base; size_t off;
+  explicit Carver(void* b) : base((char*)b), off(0) {}
+  void* take(size_t bytes) {
+    off = align_up(off, 256);
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+struct wh_model {
+  wh_dims d;
+  int dtype;         // WH_F32 / WH_F16
+  int esize;
+  int kc1;           // padded K of conv1 GEMM
+  wh_model_weights w;
+  std::vector<wh_layer_weights> enc, dec;
+};
+
+// ------------------------------------------------------------------------------------------------
+// log-mel
+// ------------------------------------------------------------------------------------------------
+static std::mutex g_tab_mutex;
+static float* g_mel_tables[64] = {nullptr};
+
+static int mel_tables(float** out) {
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return WH_ERR_ARG;
+  std::lock_guard<std::mutex> lock(g_tab_mutex);
+  if (!g_mel_tables[dev]) {
+    std::vector<float> h(1200);
+    const double PI = 3.14159265358979323846;
+    for (int i = 0; i < 400; ++i) {
+      h[i] = (float)cos(2.0 * PI * i / 400.0);
+      h[400 + i] = (float)sin(2.0 * PI * i / 400.0);
+      h[800 + i] = (float)(0.5 - 0.5 * cos(2.0 * PI * i / 400.0));   // torch.hann_window(400), periodic
+    }
+    float* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, 1200 * sizeof(float)));
+    HIPCHK(hipMemcpy(d, h.data(), 1200 * sizeof(float), hipMemcpyHostToDevice));
+    g_mel_tables[dev] = d;
+  }
+  *out = g_mel_tables[dev];
+  return WH_OK;
+}
+
+extern "C" int wh_log_mel(const float* audio, int64_t n_samples, int batch, int n_mels,
+                          const float* filters, float* out, void* scratch, void* stream) {
+  if (!audio || !filters || !out || !scratch) return WH_ERR_ARG;
+  if (n_samples <= 200 || batch <= 0 || n_mels <= 0 || n_mels > 128) return WH_ERR_ARG;
+  if (n_samples / 160 <= 0) return WH_ERR_ARG;
+  float* tables = nullptr;
+  int rc = mel_tables(&tables);
+  if (rc != WH_OK) return rc;
+  HIPCHK(launch_log_mel(audio, n_samples, batch, n_mels, filters, tables, out, scratch, (hipStream_t)stream));
+  return WH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------------------
+extern "C" int wh_model_create(const wh_dims* dims, int dtype, const wh_model_weights* weights, wh_model** out) {
+  if (!dims || !weights || !out) return WH_ERR_ARG;
+  if (dtype != WH_F32 && dtype != WH_F16) return WH_ERR_ARG;
+  const wh_dims& d = *dims;
+  if (d.n_audio_state != d.n_text_state) return WH_ERR_ARG;
+  if (d.n_audio_state % 64 != 0 || d.n_audio_state / 64 != d.n_audio_head || d.n_text_state / 64 != d.n_text_head)
+    return WH_ERR_ARG;   // d_head == 64 for every Whisper checkpoint
+  if (d.n_audio_state > 2048 || d.n_mels > 128 || d.n_audio_ctx > 1536 || d.n_text_ctx > 1536) return WH_ERR_LIMIT;
+  wh_model* m = new (std::nothrow) wh_model();
+  if (!m) return WH_ERR_ARG;
+  m->d = d;
+  m->dtype = dtype;
+  m->esize = dtype == WH_F16 ? 2 : 4;
+  m->kc1 = (int)align_up((size_t)3 * d.n_mels, 64);
+  m->w = *weights;
+  m->enc.assign(weights->enc_layers, weights->enc_layers + d.n_audio_layer);
+  m->dec.assign(weights->dec_layers, weights->dec_layers + d.n_text_layer);
+  m->w.enc_layers = m->enc.data();
+  m->w.dec_layers = m->dec.data();
+  *out = m;
+  return WH_OK;
+}
+extern "C" void wh_model_destroy(wh_model* m) { delete m; }
+
+// ------------------------------------------------------------------------------------------------
+// GEMM convenience
+// ------------------------------------------------------------------------------------------------
+static hipError_t gemm(const wh_model* m, const void* A, int64_t lda, const void* W, int K, void* C, int64_t ldc,
+                       int M, int N, const float* bias, int act, const float* res, int64_t ldr, bool out_f32,
+                       hipStream_t s) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.C = C; g.ldc = ldc;
+  g.bias = bias; g.act = act; g.res = res; g.ldr = ldr;
+  g.M = M; g.N = N; g.K = K;
+  return launch_gemm(g, m->dtype, out_f32 || m->dtype == WH_F32, 1, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder
+// ------------------------------------------------------------------------------------------------
+struct EncWs {
+  void *melT, *c1, *xn, *qkv, *vt, *att, *h;
+  float* x;
+  size_t total;
+};
+static const int VT_LD = 1536;
+
+static EncWs enc_carve(const wh_model* m, int B, void* base) {
+  const wh_dims& d = m->d;
+  const size_t es = m->esize, T = d.n_audio_ctx, F = 2 * T, D = d.n_audio_state;
+  Carver c(base);
+  EncWs w;
+  w.melT = c.take(((size_t)B * (F + 2) * d.n_mels + 256) * es);
+  w.c1 = c.take(((size_t)B * (F + 2) * D + 256) * es);
+  w.x = (float*)c.take((size_t)B * T * D * 4);
+  w.xn = c.take((size_t)B * T * D * es);
+  w.qkv = c.take((size_t)B * T * 3 * D * es);
+  w.vt = m->dtype == WH_F16 ? c.take((size_t)B * D * VT_LD * es) : nullptr;
+  w.att = c.take((size_t)B * T * D * es);
+  w.h = c.take((size_t)B * T * 4 * D * es);
+  w.total = align_up(c.off, 256);
+  return w;
+}
+
+extern "C" size_t wh_encoder_workspace_bytes(const wh_model* m, int batch) {
+  if (!m || batch <= 0) return 0;
+  return enc_carve(m, batch, nullptr).total;
+}
+
+extern "C" int wh_encode(const wh_model* m, const void* mel, int mel_is_f16, int B, void* out, void* workspace,
+                         size_t workspace_bytes, void* stream_) {
+  if (!m || !mel || !out || !workspace || B <= 0) return WH_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream_;
+  const wh_dims& d = m->d;
+  const int T = d.n_audio_ctx, F = 2 * T, D = d.n_audio_state, H = d.n_audio_head, NM = d.n_mels;
+  const size_t es = m->esize;
+  EncWs w = enc_carve(m, B, workspace);
+  if (w.total > workspace_bytes) return WH_ERR_WORKSPACE;
+  const bool f16 = m->dtype == WH_F16;
+
+  // ---- conv1 / conv2 as GEMMs over overlapping rows (whisper/model.py:193-194) -------------
+  HIPCHK(hipMemsetAsync((char*)w.melT + (size_t)B * (F + 2) * NM * es, 0, 256 * es, s));   // slack read by padded K
+  HIPCHK(launch_mel_transpose(mel, mel_is_f16, B, NM, F, w.melT, m->dtype, s));
+  for (int b = 0; b < B; ++b) {   // zero pad rows 0 and F+1 of the conv1 output
+    char* base = (char*)w.c1 + (size_t)b * (F + 2) * D * es;
+    HIPCHK(hipMemsetAsync(base, 0, (size_t)D * es, s));
+    HIPCHK(hipMemsetAsync(base + (size_t)(F + 1) * D * es, 0, (size_t)D * es, s));
+  }
+  {
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = w.melT; g.lda = NM; g.a_bs = (int64_t)(F + 2) * NM;
+    g.W = m->w.conv1_w; g.ldw = m->kc1;
+    g.C = (char*)w.c1 + (size_t)D * es; g.ldc = D; g.c_bs = (int64_t)(F + 2) * D;
+    g.bias = m->w.conv1_b; g.act = 1;
+    g.M = F; g.N = D; g.K = m->kc1;
+    HIPCHK(launch_gemm(g, m->dtype, !f16, B, s));
+  }
+  {
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = w.c1; g.lda = 2 * D; g.a_bs = (int64_t)(F + 2) * D;
+    g.W = m->w.conv2_w; g.ldw = 3 * D;
+    g.C = w.x; g.ldc = D; g.c_bs = (int64_t)T * D;
+    g.bias = m->w.conv2_b; g.act = 1;
+    g.res = m->w.enc_pos; g.ldr = D; g.r_bs = 0;      // + positional_embedding (model.py:198)
+    g.M = T; g.N = D; g.K = 3 * D;
+    HIPCHK(launch_gemm(g, m->dtype, 1, B, s));
+  }
+  if (f16) HIPCHK(hipMemsetAsync(w.vt, 0, (size_t)B * D * VT_LD * es, s));   // zero key padding of V^T
+
+  const int M = B * T;
+  for (int l = 0; l < d.n_audio_layer; ++l) {
+    const wh_layer_weights& L = m->enc[l];
+    HIPCHK(launch_layernorm(w.x, D, L.attn_ln_w, L.attn_ln_b, w.xn, D, M, D, m->dtype, s));
+    if (f16) {
+      // Q,K row-major; V produced transposed (V^T = Wv · X^T) for the PV MFMA operand
+      HIPCHK(gemm(m, w.xn, D, L.qkv_w, D, w.qkv, 2 * D, M, 2 * D, L.qkv_b, 0, nullptr, 0, false, s));
+      GemmArgs g; memset(&g, 0, sizeof(g));
+      g.A = (const char*)L.qkv_w + (size_t)2 * D * D * es; g.lda = D; g.a_bs = 0;
+      g.W = w.xn; g.ldw = D; g.w_bs = (int64_t)T * D;
+      g.C = w.vt; g.ldc = VT_LD; g.c_bs = (int64_t)D * VT_LD;
+      g.bias = L.qkv_b + 2 * D; g.bias_on_m = 1;
+      g.M = D; g.N = T; g.K = D;
+      HIPCHK(launch_gemm(g, m->dtype, 0, B, s));
+      HIPCHK(launch_attn_flash_f16(w.qkv, 2 * D, (int64_t)T * 2 * D, (const char*)w.qkv + (size_t)D * es, 2 * D,
+                                   (int64_t)T * 2 * D, w.vt, VT_LD, (int64_t)D * VT_LD, w.att, D,
+                                   (int64_t)T * D, B, H, T, s));
+    } else {
+      HIPCHK(gemm(m, w.xn, D, L.qkv_w, D, w.qkv, 3 * D, M, 3 * D, L.qkv_b, 0, nullptr, 0, false, s));
+      AttnArgs a; memset(&a, 0, sizeof(a));
+      a.q = w.qkv; a.q_ld = 3 * D; a.q_bs = (int64_t)T * 3 * D;
+      a.k = (const char*)w.qkv + (size_t)D * es; a.k_ld = 3 * D; a.k_bs = a.q_bs;
+      a.v = (const char*)w.qkv + (size_t)2 * D * es; a.v_ld = 3 * D; a.v_bs = a.q_bs;
+      a.out = w.att; a.o_ld = D; a.o_bs = (int64_t)T * D;
+      a.H = H; a.Tq = T; a.Tk = T; a.causal = 0; a.kv_group = 1;
+      HIPCHK(launch_attn_generic(a, B, m->dtype, s));
+    }
+    HIPCHK(gemm(m, w.att, D, L.out_w, D, w.x, D, M, D, L.out_b, 0, w.x, D, true, s));
+    HIPCHK(launch_layernorm(w.x, D, L.mlp_ln_w, L.mlp_ln_b, w.xn, D, M, D, m->dtype, s));
+    HIPCHK(gemm(m, w.xn, D, L.fc1_w, D, w.h, 4 * D, M, 4 * D, L.fc1_b, 1, nullptr, 0, false, s));
+    HIPCHK(gemm(m, w.h, 4 * D, L.fc2_w, 4 * D, w.x, D, M, D, L.fc2_b, 0, w.x, D, true, s));
+  }
+  HIPCHK(launch_layernorm(w.x, D, m->w.enc_ln_post_w, m->w.enc_ln_post_b, out, D, M, D, m->dtype, s));
+  return WH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoding task
+// ------------------------------------------------------------------------------------------------
+struct wh_task {
+  const wh_model* m;
+  int B, G, R, Tmax, flags;
+  int pos;                 // host mirror of *d_pos
+  bool audio_set;
+  int steps_eager;         // decode steps launched without a graph (first one warms up attributes)
+  hipGraph_t graph; hipGraphExec_t graph_exec;
+  // device buffers (carved from the caller's workspace)
+  void* cross_kv;          // [L][B*Ta][2D]
+  void* self_k; void* self_v;   // [L][R][n_ctx][D]
+  void* spare_k; void* spare_v; // beam reorder staging (G > 1)
+  float* x; void* xn; void* qkv; void* att; void* h; void* qbuf;
+  float* part_o; float* part_ml;
+  float* logits;           // [R][V] step logits / [R][2][V] greedy prefill logits
+  float* xsel; void* xseln;
+  int* d_pos; int* d_alive; int* d_sel; int* d_src;
+  int64_t* step_tokens;
+  void* qcap;              // [L][R*Tcap][D] captured cross-attention queries
+  int cross_splits;
+  size_t total;
+};
+
+static int pick_splits(int R, int H) {
+  int s = (640 + R * H - 1) / (R * H);
+  if (s < 1) s = 1;
+  if (s > 8) s = 8;
+  return s;
+}
+
+static void task_carve(wh_task* t, void* base) {
+  const wh_model* m = t->m;
+  const wh_dims& d = m->d;
+  const size_t es = m->esize, D = d.n_text_state, L = d.n_text_layer, Ta = d.n_audio_ctx, C = d.n_text_ctx;
+  const size_t R = t->R, Mx = (size_t)t->R * t->Tmax, V = d.n_vocab, H = d.n_text_head;
+  Carver c(base);
+  t->cross_kv = c.take(L * t->B * Ta * 2 * D * es);
+  t->self_k = c.take(L * R * C * D * es);
+  t->self_v = c.take(L * R * C * D * es);
+  t->spare_k = t->G > 1 ? c.take(R * C * D * es) : nullptr;
+  t->spare_v = nullptr;
+  t->x = (float*)c.take(Mx * D * 4);
+  t->xn = c.take(Mx * D * es);
+  t->qkv = c.take(Mx * 3 * D * es);
+  t->att = c.take(Mx * D * es);
+  t->h = c.take(Mx * 4 * D * es);
+  t->qbuf = c.take(R * D * es);
+  t->part_o = (float*)c.take(R * H * 8 * 64 * 4);
+  t->part_ml = (float*)c.take(R * H * 8 * 2 * 4);
+  t->logits = (float*)c.take(R * 2 * V * 4);
+  t->xsel = (float*)c.take(Mx * D * 4);
+  t->xseln = c.take(Mx * D * es);
+  t->d_pos = (int*)c.take(256);
+  t->d_alive = (int*)c.take(256);
+  t->d_sel = (int*)c.take(Mx * 4);
+  t->d_src = (int*)c.take(R * 4);
+  t->step_tokens = (int64_t*)c.take(R * 8);
+  t->qcap = (t->flags & WH_TASK_CAPTURE_Q) ? c.take(L * R * C * D * es) : nullptr;
+  t->total = align_up(c.off, 256);
+}
+
+extern "C" size_t wh_task_workspace_bytes(const wh_model* m, int n_audio, int n_group, int max_prefill_tokens,
+                                          int flags) {
+  if (!m || n_audio <= 0 || n_group <= 0 || max_prefill_tokens <= 0) return 0;
+  wh_task t; memset((void*)&t, 0, sizeof(t));
+  t.m = m; t.B = n_audio; t.G = n_group; t.R = n_audio * n_group; t.Tmax = max_prefill_tokens; t.flags = flags;
+  task_carve(&t, nullptr);
+  return t.total;
+}
+
+extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int max_prefill_tokens, int flags,
+                              void* workspace, size_t workspace_bytes, wh_task** out) {
+  if (!m || !workspace || !out || n_audio <= 0 || n_group <= 0 || max_prefill_tokens <= 0) return WH_ERR_ARG;
+  if (max_prefill_tokens > m->d.n_text_ctx) return WH_ERR_ARG;
+  wh_task* t = new (std::nothrow) wh_task();
+  if (!t) return WH_ERR_ARG;
+  memset((void*)t, 0, sizeof(*t));
+  t->m = m; t->B = n_audio; t->G = n_group; t->R = n_audio * n_group; t->Tmax = max_prefill_tokens; t->flags = flags;
+  task_carve(t, workspace);
+  if (t->total > workspace_bytes) { delete t; return WH_ERR_WORKSPACE; }
+  if (m->dtype == WH_F32 && t->R > 16 * 65535) { delete t; return WH_ERR_LIMIT; }
+  t->cross_splits = pick_splits(t->R, m->d.n_text_head);
+  hipError_t e = hipMemset(t->d_pos, 0, 4);
+  if (e != hipSuccess) { g_last_hip = e; delete t; return WH_ERR_HIP; }
+  *out = t;
+  return WH_OK;
+}
+
+extern "C" void wh_task_destroy(wh_task* t) {
+  if (!t) return;
+  if (t->graph_exec) (void)hipGraphExecDestroy(t->graph_exec);
+  if (t->graph) (void)hipGraphDestroy(t->graph);
+  delete t;
+}
+
+extern "C" int wh_task_position(const wh_task* t) { return t ? t->pos : -1; }
+
+extern "C" int wh_task_reset(wh_task* t) {
+  if (!t) return WH_ERR_ARG;
+  HIPCHK(hipMemset(t->d_pos, 0, 4));
+  t->pos = 0;
+  return WH_OK;
+}
+
+extern "C" int wh_task_set_audio(wh_task* t, const void* features, void* stream_) {
+  if (!t || !features) return WH_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream_;
+  const wh_model* m = t->m;
+  const wh_dims& d = m->d;
+  const int D = d.n_text_state, Ta = d.n_audio_ctx, M = t->B * Ta;
+  const size_t es = m->esize;
+  for (int l = 0; l < d.n_text_layer; ++l) {
+    const wh_layer_weights& L = m->dec[l];
+    void* C = (char*)t->cross_kv + (size_t)l * M * 2 * D * es;
+    HIPCHK(gemm(m, features, D, L.ckv_w, D, C, 2 * D, M, 2 * D, L.ckv_b, 0, nullptr, 0, false, s));
+  }
+  t->audio_set = true;
+  return WH_OK;
+}
+
+static inline void* self_k_layer(const wh_task* t, int l) {
+  const wh_dims& d = t->m->d;
+  return (char*)t->self_k + (size_t)l * t->R * d.n_text_ctx * d.n_text_state * t->m->esize;
+}
+static inline void* self_v_layer(const wh_task* t, int l) {
+  const wh_dims& d = t->m->d;
+  return (char*)t->self_v + (size_t)l * t->R * d.n_text_ctx * d.n_text_state * t->m->esize;
+}
+static inline void* cross_layer(const wh_task* t, int l) {
+  const wh_dims& d = t->m->d;
+  return (char*)t->cross_kv + (size_t)l * t->B * d.n_audio_ctx * 2 * d.n_text_state * t->m->esize;
+}
+
+// ---- prefill: T0 tokens per row through the GEMM path ------------------------------------------
+static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride, int T0, const int32_t* sel_pos,
+                        int n_sel, float* logits_out, int64_t logits_row_ld, hipStream_t s) {
+  const wh_model* m = t->m;
+  const wh_dims& d = m->d;
+  const int D = d.n_text_state, H = d.n_text_head, C = d.n_text_ctx, Ta = d.n_audio_ctx, V = d.n_vocab;
+  const int R = t->R, M = R * T0;
+  const size_t es = m->esize;
+  if (!t->audio_set) return WH_ERR_STATE;
+  if (T0 <= 0 || T0 > t->Tmax || t->pos + T0 > C) return WH_ERR_ARG;
+
+  HIPCHK(launch_embed(tokens, token_stride, R, T0, m->w.tok_emb, m->w.dec_pos, t->d_pos, D, V, t->x, m->dtype, s));
+  for (int l = 0; l < d.n_text_layer; ++l) {
+    const wh_layer_weights& L = m->dec[l];
+    // self attention (causal over cached + new positions)
+    HIPCHK(launch_layernorm(t->x, D, L.attn_ln_w, L.attn_ln_b, t->xn, D, M, D, m->dtype, s));
+    HIPCHK(gemm(m, t->xn, D, L.qkv_w, D, t->qkv, 3 * D, M, 3 * D, L.qkv_b, 0, nullptr, 0, false, s));
+    HIPCHK(launch_scatter_kv(t->qkv, R, T0, D, t->d_pos, C, self_k_layer(t, l), self_v_layer(t, l), m->dtype, s));
+    {
+      AttnArgs a; memset(&a, 0, sizeof(a));
+      a.q = t->qkv; a.q_ld = 3 * D; a.q_bs = (int64_t)T0 * 3 * D;
+      a.k = self_k_layer(t, l); a.k_ld = D; a.k_bs = (int64_t)C * D;
+      a.v = self_v_layer(t, l); a.v_ld = D; a.v_bs = (int64_t)C * D;
+      a.out = t->att; a.o_ld = D; a.o_bs = (int64_t)T0 * D;
+      a.H = H; a.Tq = T0; a.d_len = t->d_pos; a.causal = 1; a.kv_group = 1;
+      HIPCHK(launch_attn_generic(a, R, m->dtype, s));
+    }
+    HIPCHK(gemm(m, t->att, D, L.out_w, D, t->x, D, M, D, L.out_b, 0, t->x, D, true, s));
+    // cross attention over the cached audio K/V
+    HIPCHK(launch_layernorm(t->x, D, L.cross_ln_w, L.cross_ln_b, t->xn, D, M, D, m->dtype, s));
+    HIPCHK(gemm(m, t->xn, D, L.cq_w, D, t->qkv, D, M, D, L.cq_b, 0, nullptr, 0, false, s));
+    if (t->qcap) {   // keep q rows at their cache positions: [l][r][pos+t][D]
+      for (int r = 0; r < R; ++r) {
+        char* dst = (char*)t->qcap + (((size_t)l * R + r) * C + t->pos) * D * es;
+        HIPCHK(hipMemcpyAsync(dst, (char*)t->qkv + (size_t)r * T0 * D * es, (size_t)T0 * D * es,
+                              hipMemcpyDeviceToDevice, s));
+      }
+    }
+    {
+      AttnArgs a; memset(&a, 0, sizeof(a));
+      a.q = t->qkv; a.q_ld = D; a.q_bs = (int64_t)T0 * D;
+      a.k = cross_layer(t, l); a.k_ld = 2 * D; a.k_bs = (int64_t)Ta * 2 * D;
+      a.v = (char*)cross_layer(t, l) + (size_t)D * es; a.v_ld = 2 * D; a.v_bs = a.k_bs;
+      a.out = t->att; a.o_ld = D; a.o_bs = (int64_t)T0 * D;
+      a.H = H; a.Tq = T0; a.Tk = Ta; a.causal = 0; a.kv_group = t->G;
+      HIPCHK(launch_attn_generic(a, R, m->dtype, s));
+    }
+    HIPCHK(gemm(m, t->att, D, L.cout_w, D, t->x, D, M, D, L.cout_b, 0, t->x, D, true, s));
+    // MLP
+    HIPCHK(launch_layernorm(t->x, D, L.mlp_ln_w, L.mlp_ln_b, t->xn, D, M, D, m->dtype, s));
+    HIPCHK(gemm(m, t->xn, D, L.fc1_w, D, t->h, 4 * D, M, 4 * D, L.fc1_b, 1, nullptr, 0, false, s));
+    HIPCHK(gemm(m, t->h, 4 * D, L.fc2_w, 4 * D, t->x, D, M, D, L.fc2_b, 0, t->x, D, true, s));
+  }
+  // logits of the selected positions
+  if (logits_out && n_sel > 0) {
+    std::vector<int> sel((size_t)R * n_sel);
+    for (int r = 0; r < R; ++r)
+      for (int i = 0; i < n_sel; ++i) {
+        const int p = sel_pos ? sel_pos[i] : i;
+        if (p < 0 || p >= T0) return WH_ERR_ARG;
+        sel[(size_t)r * n_sel + i] = r * T0 + p;
+      }
+    const int Ms = R * n_sel;
+    HIPCHK(hipMemcpyAsync(t->d_sel, sel.data(), sel.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // `sel` is host stack memory
+    HIPCHK(launch_gather_rows(t->x, t->d_sel, Ms, D, t->xsel, s));
+    HIPCHK(launch_layernorm(t->xsel, D, m->w.dec_ln_w, m->w.dec_ln_b, t->xseln, D, Ms, D, m->dtype, s));
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = t->xseln; g.lda = D; g.W = m->w.tok_emb; g.ldw = D;
+    g.C = logits_out; g.ldc = logits_row_ld;
+    g.M = Ms; g.N = V; g.K = D;
+    HIPCHK(launch_gemm(g, m->dtype, 1, 1, s));
+  }
+  HIPCHK(launch_add_int(t->d_pos, T0, s));
+  t->pos += T0;
+  return WH_OK;
+}
+
+extern "C" int wh_task_prefill(wh_task* t, const int64_t* tokens, int64_t token_stride, int T0,
+                               const int32_t* sel_pos, int n_sel, float* logits_out, void* stream) {
+  if (!t || !tokens) return WH_ERR_ARG;
+  if (!sel_pos) n_sel = T0;
+  return prefill_impl(t, tokens, token_stride, T0, sel_pos, n_sel, logits_out, t->m->d.n_vocab, (hipStream_t)stream);
+}
+
+// ---- one decode step (all kernels read the position from *d_pos: graph-replayable) ---------------
+static int step_launch(wh_task* t, hipStream_t s) {
+  const wh_model* m = t->m;
+  const wh_dims& d = m->d;
+  const int D = d.n_text_state, H = d.n_text_head, C = d.n_text_ctx, Ta = d.n_audio_ctx, V = d.n_vocab;
+  const int R = t->R;
+  const size_t es = m->esize;
+  HIPCHK(launch_embed(t->step_tokens, 1, R, 1, m->w.tok_emb, m->w.dec_pos, t->d_pos, D, V, t->x, m->dtype, s));
+  for (int l = 0; l < d.n_text_layer; ++l) {
+    const wh_layer_weights& L = m->dec[l];
+    GemvArgs g;
+    // LN -> QKV, K/V appended in place at *d_pos
+    memset(&g, 0, sizeof(g));
+    g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.attn_ln_w; g.ln_b = L.attn_ln_b;
+    g.W = L.qkv_w; g.bias = L.qkv_b; g.N = 3 * D; g.K = D; g.R = R;
+    g.epi = EPI_QKV; g.y = t->qbuf; g.y_ld = D;
+    g.kcache = self_k_layer(t, l); g.vcache = self_v_layer(t, l); g.cache_bs = (int64_t)C * D; g.d_pos = t->d_pos; g.D = D;
+    HIPCHK(launch_gemv(g, m->dtype, s));
+    {
+      DecAttnArgs a; memset(&a, 0, sizeof(a));
+      a.q = t->qbuf; a.q_ld = D;
+      a.k = self_k_layer(t, l); a.k_ld = D; a.k_bs = (int64_t)C * D;
+      a.v = self_v_layer(t, l); a.v_ld = D; a.v_bs = (int64_t)C * D;
+      a.H = H; a.R = R; a.kv_group = 1; a.d_len = t->d_pos; a.len_plus = 1; a.splits = 1;
+      a.out = t->att; a.o_ld = D;
+      HIPCHK(launch_attn_decode(a, m->dtype, s));
+    }
+    memset(&g, 0, sizeof(g));
+    g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D;
+    g.W = L.out_w; g.bias = L.out_b; g.N = D; g.K = D; g.R = R;
+    g.epi = EPI_RESID; g.resid = t->x; g.resid_ld = D;
+    HIPCHK(launch_gemv(g, m->dtype, s));
+    // LN -> cross query
+    memset(&g, 0, sizeof(g));
+    g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.cross_ln_w; g.ln_b = L.cross_ln_b;
+    g.W = L.cq_w; g.bias = L.cq_b; g.N = D; g.K = D; g.R = R;
+    g.epi = EPI_STORE; g.y = t->qbuf; g.y_ld = D;
+    HIPCHK(launch_gemv(g, m->dtype, s));
+    {
+      DecAttnArgs a; memset(&a, 0, sizeof(a));
+      a.q = t->qbuf; a.q_ld = D;
+      a.k = cross_layer(t, l); a.k_ld = 2 * D; a.k_bs = (int64_t)Ta * 2 * D;
+      a.v = (char*)cross_layer(t, l) + (size_t)D * es; a.v_ld = 2 * D; a.v_bs = a.k_bs;
+      a.H = H; a.R = R; a.kv_group = t->G; a.Tk = Ta; a.splits = t->cross_splits;
+      a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
+      HIPCHK(launch_attn_decode(a, m->dtype, s));
+    }
+    memset(&g, 0, sizeof(g));
+    if (t->cross_splits > 1) {
+      g.pro = PRO_COMBINE; g.part_o = t->part_o; g.part_ml = t->part_ml; g.splits = t->cross_splits; g.H = H;
+    } else {
+      g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D;
+    }
+    g.W = L.cout_w; g.bias = L.cout_b; g.N = D; g.K = D; g.R = R;
+    g.epi = EPI_RESID; g.resid = t->x; g.resid_ld = D;
+    HIPCHK(launch_gemv(g, m->dtype, s));
+    // LN -> MLP
+    memset(&g, 0, sizeof(g));
+    g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.mlp_ln_w; g.ln_b = L.mlp_ln_b;
+    g.W = L.fc1_w; g.bias = L.fc1_b; g.N = 4 * D; g.K = D; g.R = R;
+    g.epi = EPI_GELU; g.y = t->h; g.y_ld = 4 * D;
+    HIPCHK(launch_gemv(g, m->dtype, s));
+    memset(&g, 0, sizeof(g));
+    g.pro = PRO_PLAIN; g.x = t->h; g.x_ld = 4 * D;
+    g.W = L.fc2_w; g.bias = L.fc2_b; g.N = D; g.K = 4 * D; g.R = R;
+    g.epi = EPI_RESID; g.resid = t->x; g.resid_ld = D;
+    HIPCHK(launch_gemv(g, m->dtype, s));
+  }
+  {
+    GemvArgs g; memset(&g, 0, sizeof(g));
+    g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = m->w.dec_ln_w; g.ln_b = m->w.dec_ln_b;
+    g.W = m->w.tok_emb; g.bias = nullptr; g.N = V; g.K = D; g.R = R;
+    g.epi = EPI_F32; g.y = t->logits; g.y_ld = V;
+    HIPCHK(launch_gemv(g, m->dtype, s));
+  }
+  HIPCHK(launch_add_int(t->d_pos, 1, s));
+  return WH_OK;
+}
+
+static bool graphs_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("WH_NO_GRAPH"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
+// runs one step from t->step_tokens into t->logits
+static int step_run(wh_task* t, hipStream_t s) {
+  if (t->pos <= 0) return WH_ERR_STATE;
+  if (t->pos + 1 > t->m->d.n_text_ctx) return WH_ERR_ARG;
+  int rc;
+  if (t->graph_exec) {
+    HIPCHK(hipGraphLaunch(t->graph_exec, s));
+  } else if (s == nullptr || !graphs_enabled() || t->steps_eager < 1) {
+    rc = step_launch(t, s);
+    if (rc != WH_OK) return rc;
+    t->steps_eager++;
+  } else {
+    HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    rc = step_launch(t, s);
+    hipError_t e = hipStreamEndCapture(s, &t->graph);
+    if (rc != WH_OK) return rc;
+    HIPCHK(e);
+    HIPCHK(hipGraphInstantiate(&t->graph_exec, t->graph, nullptr, nullptr, 0));
+    HIPCHK(hipGraphLaunch(t->graph_exec, s));
+  }
+  t->pos += 1;
+  return WH_OK;
+}
+
+extern "C" int wh_task_step(wh_task* t, const int64_t* last_tokens, int64_t token_stride, float* logits_out,
+                            void* stream_) {
+  if (!t || !last_tokens || !logits_out) return WH_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream_;
+  HIPCHK(launch_gather_tokens(last_tokens, token_stride, t->R, t->step_tokens, s));
+  int rc = step_run(t, s);
+  if (rc != WH_OK) return rc;
+  if (logits_out != t->logits)
+    HIPCHK(hipMemcpyAsync(logits_out, t->logits, (size_t)t->R * t->m->d.n_vocab * 4, hipMemcpyDeviceToDevice, s));
+  return WH_OK;
+}
+
+extern "C" int wh_task_rearrange(wh_task* t, const int32_t* source_indices, void* stream_) {
+  if (!t || !source_indices) return WH_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream_;
+  const wh_dims& d = t->m->d;
+  bool identity = true;
+  for (int i = 0; i < t->R; ++i) {
+    if (source_indices[i] < 0 || source_indices[i] >= t->R) return WH_ERR_ARG;
+    if (source_indices[i] != i) identity = false;
+  }
+  if (identity || t->pos == 0) return WH_OK;     // decoding.py:173
+  if (!t->spare_k) return WH_ERR_STATE;
+  HIPCHK(hipMemcpyAsync(t->d_src, source_indices, (size_t)t->R * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const size_t es = t->m->esize;
+  const int64_t row_bytes = (int64_t)d.n_text_ctx * d.n_text_state * es;
+  const int64_t used_bytes = (int64_t)t->pos * d.n_text_state * es;
+  for (int l = 0; l < d.n_text_layer; ++l) {
+    void* caches[2] = {self_k_layer(t, l), self_v_layer(t, l)};
+    for (int c = 0; c < 2; ++c) {
+      HIPCHK(launch_gather_cache(caches[c], t->spare_k, t->d_src, t->R, row_bytes, used_bytes, s));
+      HIPCHK(hipMemcpy2DAsync(caches[c], row_bytes, t->spare_k, row_bytes, used_bytes, t->R,
+                              hipMemcpyDeviceToDevice, s));
+    }
+  }
+  return WH_OK;
+}
+
+// ---- fused greedy loop -----------------------------------------------------------------------------
+extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* tokens, int64_t token_stride,
+                              int sot_index, int no_speech_token, float* sum_logprobs, float* no_speech_probs,
+                              int32_t* n_tokens_out, void* stream_) {
+  if (!t || !p || !tokens || !sum_logprobs || !n_tokens_out) return WH_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream_;
+  const wh_dims& d = t->m->d;
+  const int V = d.n_vocab, R = t->R, T0 = p->sample_begin;
+  if (t->pos != 0 || T0 <= 0 || T0 > t->Tmax || p->max_steps <= 0) return WH_ERR_ARG;
+  if (token_stride < (int64_t)T0 + p->max_steps) return WH_ERR_ARG;
+
+  int32_t sel[2]; int n_sel;
+  const bool want_ns = no_speech_token >= 0 && no_speech_probs != nullptr;
+  if (want_ns && sot_index != T0 - 1) { sel[0] = sot_index; sel[1] = T0 - 1; n_sel = 2; }
+  else { sel[0] = T0 - 1; n_sel = 1; }
+  int rc = prefill_impl(t, tokens, token_stride, T0, sel, n_sel, t->logits, V, s);
+  if (rc != WH_OK) return rc;
+  if (want_ns) HIPCHK(launch_no_speech(t->logits, (int64_t)n_sel * V, R, V, no_speech_token, no_speech_probs, s));
+  HIPCHK(hipMemsetAsync(sum_logprobs, 0, (size_t)R * 4, s));
+  int alive_init = T0 - 1;
+  HIPCHK(hipMemcpyAsync(t->d_alive, &alive_init, 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+
+  SampleArgs sa; memset(&sa, 0, sizeof(sa));
+  sa.R = R; sa.V = V; sa.tokens = tokens; sa.token_stride = token_stride; sa.d_ntok = t->d_pos;
+  sa.sample_begin = T0; sa.eot = p->eot; sa.timestamp_begin = p->timestamp_begin; sa.no_timestamps = p->no_timestamps;
+  sa.max_initial_ts = p->max_initial_timestamp_index; sa.suppress_blank = p->suppress_blank;
+  sa.blank_token = p->blank_token; sa.suppress_mask = p->suppress_mask; sa.sum_logprobs = sum_logprobs;
+  sa.step_tokens = t->step_tokens; sa.d_alive_step = t->d_alive;
+
+  sa.logits = t->logits + (size_t)(n_sel - 1) * V; sa.logits_ld = (int64_t)n_sel * V;
+  HIPCHK(launch_greedy_sample(sa, s));
+  int ntok = T0 + 1, steps = 1, alive = T0;
+  sa.logits = t->logits; sa.logits_ld = V;
+  bool done = false;
+  while (steps < p->max_steps && ntok <= p->n_ctx && ntok <= d.n_text_ctx) {
+    rc = step_run(t, s);
+    if (rc != WH_OK) return rc;
+    HIPCHK(launch_greedy_sample(sa, s));
+    ++ntok; ++steps;
+    if ((steps & 7) == 0) {
+      HIPCHK(hipMemcpyAsync(&alive, t->d_alive, 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      if (alive < ntok - 1) { done = true; break; }
+    }
+  }
+  if (!done) {
+    HIPCHK(hipMemcpyAsync(&alive, t->d_alive, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  // the sampler that appended token index c ran with ntok == c; "completed" first holds at c = alive + 1
+  int final_len = alive + 2;
+  if (final_len > ntok) final_len = ntok;
+  *n_tokens_out = final_len;
+  return WH_OK;
+}
+
+// ---- word timestamps ---------------------------------------------------------------------------------
+extern "C" int wh_task_cross_qk(wh_task* t, int row, const int32_t* layers, const int32_t* heads, int n_pairs,
+                                int tok_begin, int n_tok, float* out, void* stream_) {
+  if (!t || !layers || !heads || !out || n_pairs <= 0) return WH_ERR_ARG;
+  if (!t->qcap) return WH_ERR_STATE;
+  const wh_dims& d = t->m->d;
+  if (row < 0 || row >= t->R || tok_begin < 0 || n_tok <= 0 || tok_begin + n_tok > t->pos) return WH_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream_;
+  const int D = d.n_text_state, C = d.n_text_ctx, Ta = d.n_audio_ctx;
+  const size_t es = t->m->esize;
+  for (int i = 0; i < n_pairs; ++i) {
+    const int l = layers[i], h = heads[i];
+    if (l < 0 || l >= d.n_text_layer || h < 0 || h >= d.n_text_head) return WH_ERR_ARG;
+    const char* q = (const char*)t->qcap + ((((size_t)l * t->R + row) * C) + tok_begin) * D * es;
+    const char* k = (const char*)cross_layer(t, l) + (size_t)(row / t->G) * Ta * 2 * D * es;
+    HIPCHK(launch_cross_qk(q, D, k, 2 * D, h, n_tok, Ta, out + (size_t)i * n_tok * Ta, t->m->dtype, s));
+  }
+  return WH_OK;
+}
+
+extern "C" int wh_median_filter(const float* x, float* out, int64_t rows, int n, int width, void* stream) {
+  if (!x || !out || rows < 0 || n <= 0) return WH_ERR_ARG;
+  if (width <= 0 || (width & 1) == 0 || width > 63) return WH_ERR_ARG;
+  HIPCHK(launch_median_filter(x, out, rows, n, width, (hipStream_t)stream));
+  return WH_OK;
+}
+
+extern "C" int wh_dtw_trace(const float* x, int N, int M, int8_t* trace_out, void* stream) {
+  if (!x || !trace_out || N <= 0 || M <= 0) return WH_ERR_ARG;
+  if (N > 8192) return WH_ERR_LIMIT;
+  HIPCHK(launch_dtw(x, N, M, trace_out, (hipStream_t)stream));
+  return WH_OK;
+}

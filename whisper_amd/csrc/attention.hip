@@ -1,0 +1,452 @@
+// attention.hip — MultiHeadAttention.qkv_attention (whisper/model.py:114-139), d_head = 64 always.
+//
+//   attn_flash_f16   encoder self-attention (1500 x 1500, non-causal) on MFMA: flash-style online
+//                    softmax, S^T = K·Q^T and O^T = V^T·P^T with v_mfma_f32_32x32x16_f16 so that a
+//                    lane owns one query column end-to-end (row max / rescale are lane-local, P feeds
+//                    the second MFMA straight from registers).  K tile and V^T tile are staged through
+//                    LDS (register staging, double buffered, XOR-swizzled 128-byte rows).
+//   attn_generic     any Tq x Tk, optional causal mask (decoder prefill, fp32 strict-parity encoder)
+//   attn_decode      the single-query step: one workgroup per (key split, head, row), 16 B/lane coalesced
+//                    K/V streaming, wave-shuffle reductions; split-K partials are merged by the consumer
+//                    GEMV's prologue.  This is where the cross-attention KV bytes (245.8 MB/row/step
+//                    for large-v3) are read — HBM-bound.
+//   cross_qk         raw scaled QK^T of chosen heads for word timestamps (whisper/timing.py:186-208)
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr float SCALE = 0.125f;                       // (64 ** -0.25) ** 2, model.py:118
+constexpr float SCALE_LOG2E = 0.125f * 1.4426950408889634f;
+
+// =============================================================================================
+// generic attention (VALU)
+// =============================================================================================
+constexpr int GQ = 16;   // queries per workgroup (4 waves x 4)
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_generic_kernel(whk::AttnArgs a) {
+  __shared__ float Ks[64][65];
+  __shared__ float Vs[64][64];
+  __shared__ float Qs[GQ][64];
+  __shared__ float Ps[4][64];
+  typedef typename ET<T>::unit_t unit_t;
+  constexpr int UNIT = ET<T>::UNIT;
+  constexpr int UPR = 64 / UNIT;   // units per head row
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * GQ;
+  const int Tq = a.Tq;
+  const int Tk = a.d_len ? (*a.d_len + Tq) : a.Tk;
+  const int kvb = b / a.kv_group;
+
+  const T* qp = (const T*)a.q + (int64_t)b * a.q_bs + h * 64;
+  const T* kp = (const T*)a.k + (int64_t)kvb * a.k_bs + h * 64;
+  const T* vp = (const T*)a.v + (int64_t)kvb * a.v_bs + h * 64;
+
+  for (int i = tid; i < GQ * 64; i += 256) {
+    const int qi = i >> 6, d = i & 63;
+    float v = 0.f;
+    if (q0 + qi < Tq) v = to_f32(qp[(int64_t)(q0 + qi) * a.q_ld + d]);
+    Qs[qi][d] = v;
+  }
+
+  float m[4], l[4], o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { m[i] = WH_NEG_INF; l[i] = 0.f; o[i] = 0.f; }
+
+  // keys needed by this block: causal blocks stop early
+  int k_end = Tk;
+  if (a.causal) {
+    int last_q = q0 + GQ - 1; if (last_q > Tq - 1) last_q = Tq - 1;
+    k_end = (Tk - Tq) + last_q + 1;
+    if (k_end > Tk) k_end = Tk;
+  }
+  const int nkt = (k_end + 63) / 64;
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    for (int u = tid; u < 64 * UPR; u += 256) {
+      const int row = u / UPR, cu = u - row * UPR;
+      const int key = kt * 64 + row;
+      unit_t kv, vv;
+      if (key < Tk) {
+        kv = *(const unit_t*)(kp + (int64_t)key * a.k_ld + cu * UNIT);
+        vv = *(const unit_t*)(vp + (int64_t)key * a.v_ld + cu * UNIT);
+      } else {
+#pragma unroll
+        for (int e = 0; e < UNIT; ++e) { kv[e] = 0; vv[e] = 0; }
+      }
+#pragma unroll
+      for (int e = 0; e < UNIT; ++e) {
+        Ks[row][cu * UNIT + e] = to_f32(kv[e]);
+        Vs[row][cu * UNIT + e] = to_f32(vv[e]);
+      }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi) {
+      const int qq = wave * 4 + qi;       // query within block
+      const int qg = q0 + qq;
+      if (qg >= Tq) continue;             // wave-uniform
+      const int key = kt * 64 + lane;
+      float s = 0.f;
+#pragma unroll 16
+      for (int d = 0; d < 64; ++d) s = __builtin_fmaf(Qs[qq][d], Ks[lane][d], s);
+      s *= SCALE;
+      bool valid = key < Tk;
+      if (a.causal) valid = valid && (key <= (Tk - Tq) + qg);
+      if (!valid) s = WH_NEG_INF;
+      const float mx = wave_max(s);
+      const float mn = fmaxf(m[qi], mx);
+      float alpha, p;
+      if (mn == WH_NEG_INF) { alpha = 1.f; p = 0.f; }
+      else { alpha = __expf(m[qi] - mn); p = __expf(s - mn); }
+      const float ps = wave_sum(p);
+      l[qi] = l[qi] * alpha + ps;
+      m[qi] = mn;
+      Ps[wave][lane] = p;
+      // wave-local LDS hand-off: the same wave writes and reads Ps[wave]; DS ops of one wave execute in order
+      __builtin_amdgcn_wave_barrier();
+      float acc = o[qi] * alpha;
+#pragma unroll 16
+      for (int j = 0; j < 64; ++j) acc = __builtin_fmaf(Ps[wave][j], Vs[j][lane], acc);
+      o[qi] = acc;
+    }
+  }
+
+  T* op = (T*)a.out + (int64_t)b * a.o_bs + h * 64;
+#pragma unroll
+  for (int qi = 0; qi < 4; ++qi) {
+    const int qg = q0 + wave * 4 + qi;
+    if (qg < Tq) op[(int64_t)qg * a.o_ld + lane] = from_f32<T>(o[qi] / l[qi]);
+  }
+}
+
+// =============================================================================================
+// encoder flash attention, fp16 MFMA
+// =============================================================================================
+constexpr int FQ = 128;   // queries per workgroup (4 waves x 32)
+
+__global__ __launch_bounds__(256, 2) void attn_flash_f16_kernel(
+    const half_t* __restrict__ q, int64_t q_ld, int64_t q_bs, const half_t* __restrict__ k, int64_t k_ld,
+    int64_t k_bs, const half_t* __restrict__ vt, int64_t vt_ld, int64_t vt_bs, half_t* __restrict__ out,
+    int64_t o_ld, int64_t o_bs, int T) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];   // [buf][K | Vt][64 rows x 128 B]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qrow = blockIdx.x * FQ + wave * 32 + (lane & 31);
+  const int hi = lane >> 5;
+
+  const half_t* qp = q + (int64_t)b * q_bs + h * 64;
+  const half_t* kp = k + (int64_t)b * k_bs + h * 64;
+  const half_t* vp = vt + (int64_t)b * vt_bs + (int64_t)h * 64 * vt_ld;
+
+  // Q fragments (B operand of S^T = K Q^T): lane (q, hi) holds Q[q][16 s + 8 hi .. +7], s = 0..3
+  half8v qf[4];
+  {
+    const int qr = qrow < T ? qrow : T - 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const half8v*)(qp + (int64_t)qr * q_ld + 16 * s + 8 * hi);
+  }
+
+  float16v oacc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+  float m_run = WH_NEG_INF, l_run = 0.f;
+
+  const int nkt = (T + 63) / 64;
+  // staging: thread handles units u = tid and tid+256 of each 512-unit tile
+  uint4v kreg[2], vreg[2];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int u = tid + 256 * j;
+      const int row = u >> 3, cu = u & 7;
+      int key = kt * 64 + row; if (key > T - 1) key = T - 1;
+      kreg[j] = *(const uint4v*)(kp + (int64_t)key * k_ld + cu * 8);
+      vreg[j] = *(const uint4v*)(vp + (int64_t)row * vt_ld + kt * 64 + cu * 8);
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* sK = smem + buf * 16384;
+    char* sV = sK + 8192;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int u = tid + 256 * j;
+      const int row = u >> 3, cu = u & 7;
+      *(uint4v*)(sK + swz_byte(row, cu)) = kreg[j];
+      *(uint4v*)(sV + swz_byte(row, cu)) = vreg[j];
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) gload(kt + 1);
+    const char* sK = smem + cur * 16384;
+    const char* sV = sK + 8192;
+
+    // ---- S^T tiles: keys kb*32.. x 32 queries
+    float16v sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+      const int krow = kb * 32 + (lane & 31);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const half8v kf = *(const half8v*)(sK + swz_byte(krow, 2 * s + hi));
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
+      }
+    }
+    // ---- mask tail keys (only the last tile can be ragged)
+    if (kt == nkt - 1 && (T & 63) != 0) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= T) sacc[kb][r] = WH_NEG_INF;
+        }
+    }
+    // ---- online softmax (lane owns query lane&31; partner lane^32 holds the other 16 keys per block)
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);          // finite: key 0 of every tile is valid
+    const float alpha = exp2f((m_run - m_new) * SCALE_LOG2E);
+    const float mc = m_new * SCALE_LOG2E;
+    float psum = 0.f;
+    half8v pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = exp2f(__builtin_fmaf(sacc[kb][r], SCALE_LOG2E, -mc));
+        psum += p;
+        pf[kb][r >> 3][r & 7] = (half_t)p;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+
+    // ---- O^T += V^T · P^T
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int drow = dt * 32 + (lane & 31);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int unit = kb * 4 + 2 * s2;
+          const half4v v0 = *(const half4v*)(sV + swz_byte(drow, unit) + hi * 8);
+          const half4v v1 = *(const half4v*)(sV + swz_byte(drow, unit + 1) + hi * 8);
+          const half8v vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s2], oacc[dt], 0, 0, 0);
+        }
+    }
+
+    if (kt + 1 < nkt) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qrow < T) {
+    half_t* op = out + (int64_t)b * o_bs + (int64_t)qrow * o_ld + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4v o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = (half_t)(oacc[dt][g * 4 + e] * inv);
+        *(half4v*)(op + dt * 32 + 8 * g + 4 * hi) = o4;
+      }
+  }
+}
+
+// =============================================================================================
+// decode attention: one query per row
+// =============================================================================================
+constexpr int DEC_MAX_KEYS = 1536;
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_kernel(whk::DecAttnArgs a) {
+  typedef typename ET<T>::unit_t unit_t;
+  constexpr int UNIT = ET<T>::UNIT;
+  constexpr int LPK = 64 / UNIT;     // lanes per key (8 fp16 / 16 fp32)
+  constexpr int KPW = 64 / LPK;      // keys per wave instruction
+  __shared__ float sc[DEC_MAX_KEYS];
+  __shared__ float red[4][64];
+  __shared__ float redm[4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
+  const int S = a.splits;
+  const int Tk = a.d_len ? (*a.d_len + a.len_plus) : a.Tk;
+  int chunk = (Tk + S - 1) / S;
+  chunk = (chunk + 31) & ~31;
+  const int k0 = s * chunk;
+  int k1 = k0 + chunk; if (k1 > Tk) k1 = Tk;
+  const int nkeys = k1 > k0 ? k1 - k0 : 0;
+
+  const int kvb = r / a.kv_group;
+  const T* kp = (const T*)a.k + (int64_t)kvb * a.k_bs + h * 64;
+  const T* vp = (const T*)a.v + (int64_t)kvb * a.v_bs + h * 64;
+  const int cu = lane % LPK;          // unit within the head row
+  const int ks = lane / LPK;          // key slot within the wave instruction
+
+  float qv[UNIT];
+  {
+    const unit_t qu = *(const unit_t*)((const T*)a.q + (int64_t)r * a.q_ld + h * 64 + cu * UNIT);
+#pragma unroll
+    for (int e = 0; e < UNIT; ++e) qv[e] = to_f32(qu[e]) * SCALE;
+  }
+
+  // ---- phase 1: scores
+  const int per_iter = 4 * KPW;
+  const int niter = (nkeys + per_iter - 1) / per_iter;
+#pragma unroll 4
+  for (int it = 0; it < niter; ++it) {
+    const int kk = (it * 4 + wave) * KPW + ks;
+    float d = 0.f;
+    if (kk < nkeys) {
+      const unit_t ku = *(const unit_t*)(kp + (int64_t)(k0 + kk) * a.k_ld + cu * UNIT);
+#pragma unroll
+      for (int e = 0; e < UNIT; ++e) d = __builtin_fmaf(qv[e], to_f32(ku[e]), d);
+    }
+#pragma unroll
+    for (int o = LPK / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if (cu == 0 && kk < nkeys) sc[kk] = d;
+  }
+  __syncthreads();
+
+  // ---- softmax over this split
+  float mx = WH_NEG_INF;
+  for (int i = tid; i < nkeys; i += 256) mx = fmaxf(mx, sc[i]);
+  mx = wave_max(mx);
+  if (lane == 0) redm[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+  float sum = 0.f;
+  for (int i = tid; i < nkeys; i += 256) {
+    const float p = __expf(sc[i] - mx);
+    sc[i] = p;
+    sum += p;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();                 // p values visible; redm reads done
+  if (lane == 0) redm[wave] = sum;
+
+  // ---- phase 2: o = sum_k p[k] V[k]
+  float acc[UNIT];
+#pragma unroll
+  for (int e = 0; e < UNIT; ++e) acc[e] = 0.f;
+#pragma unroll 4
+  for (int it = 0; it < niter; ++it) {
+    const int kk = (it * 4 + wave) * KPW + ks;
+    if (kk < nkeys) {
+      const unit_t vu = *(const unit_t*)(vp + (int64_t)(k0 + kk) * a.v_ld + cu * UNIT);
+      const float p = sc[kk];
+#pragma unroll
+      for (int e = 0; e < UNIT; ++e) acc[e] = __builtin_fmaf(p, to_f32(vu[e]), acc[e]);
+    }
+  }
+  // reduce over key slots (lane bits above log2(LPK))
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < UNIT; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
+  if (ks == 0) {
+#pragma unroll
+    for (int e = 0; e < UNIT; ++e) red[wave][cu * UNIT + e] = acc[e];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const float o = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    const float l = redm[0] + redm[1] + redm[2] + redm[3];
+    if (S == 1) {
+      ((T*)a.out)[(int64_t)r * a.o_ld + h * 64 + tid] = from_f32<T>(o / l);
+    } else {
+      const int64_t pi = ((int64_t)r * a.H + h) * S + s;
+      a.part_o[pi * 64 + tid] = nkeys > 0 ? o : 0.f;
+      if (tid == 0) {
+        a.part_ml[pi * 2 + 0] = nkeys > 0 ? mx : WH_NEG_INF;
+        a.part_ml[pi * 2 + 1] = nkeys > 0 ? l : 0.f;
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// cross QK capture
+// =============================================================================================
+template <typename T>
+__global__ void cross_qk_kernel(const T* __restrict__ q, int64_t q_ld, const T* __restrict__ k,
+                                int64_t k_ld, int head, int Tk, float* __restrict__ out) {
+  __shared__ float qs[64];
+  const int t = blockIdx.y;
+  if (threadIdx.x < 64) qs[threadIdx.x] = to_f32(q[(int64_t)t * q_ld + head * 64 + threadIdx.x]);
+  __syncthreads();
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Tk) return;
+  const T* kr = k + (int64_t)j * k_ld + head * 64;
+  float s = 0.f;
+#pragma unroll 16
+  for (int d = 0; d < 64; ++d) s = __builtin_fmaf(qs[d], to_f32(kr[d]), s);
+  out[(int64_t)t * Tk + j] = s * SCALE;
+}
+
+}  // namespace
+
+namespace whk {
+
+hipError_t launch_attn_generic(const AttnArgs& a, int batch, int dtype, hipStream_t stream) {
+  dim3 grid((a.Tq + GQ - 1) / GQ, a.H, batch), block(256);
+  if (dtype == 1) hipLaunchKernelGGL((attn_generic_kernel<half_t>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((attn_generic_kernel<float>), grid, block, 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_attn_flash_f16(const void* q, int64_t q_ld, int64_t q_bs, const void* k, int64_t k_ld,
+                                 int64_t k_bs, const void* vt, int64_t vt_ld, int64_t vt_bs, void* out,
+                                 int64_t o_ld, int64_t o_bs, int B, int H, int T, hipStream_t stream) {
+  dim3 grid((T + FQ - 1) / FQ, H, B), block(256);
+  hipLaunchKernelGGL(attn_flash_f16_kernel, grid, block, 0, stream, (const half_t*)q, q_ld, q_bs,
+                     (const half_t*)k, k_ld, k_bs, (const half_t*)vt, vt_ld, vt_bs, (half_t*)out, o_ld, o_bs, T);
+  return hipGetLastError();
+}
+
+hipError_t launch_attn_decode(const DecAttnArgs& a, int dtype, hipStream_t stream) {
+  const int maxk = a.d_len ? 4096 : a.Tk;
+  (void)maxk;
+  dim3 grid(a.splits, a.H, a.R), block(256);
+  if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((attn_decode_kernel<float>), grid, block, 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_cross_qk(const void* q, int64_t q_ld, const void* k, int64_t k_ld, int head, int n_tok,
+                           int Tk, float* out, int dtype, hipStream_t stream) {
+  dim3 grid((Tk + 255) / 256, n_tok), block(256);
+  if (dtype == 1)
+    hipLaunchKernelGGL((cross_qk_kernel<half_t>), grid, block, 0, stream, (const half_t*)q, q_ld, (const half_t*)k, k_ld, head, Tk, out);
+  else
+    hipLaunchKernelGGL((cross_qk_kernel<float>), grid, block, 0, stream, (const float*)q, q_ld, (const float*)k, k_ld, head, Tk, out);
+  return hipGetLastError();
+}
+
+}  // namespace whk

@@ -1,0 +1,90 @@
+// common.h — shared device helpers for the gfx950 kernels (wave64, MFMA, LDS swizzle).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+
+#define WH_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// element traits: T in {float, half_t}; a "unit" is 16 bytes of T (4 floats / 8 halves)
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct ET;
+template <> struct ET<float> {
+  static constexpr int UNIT = 4;   // elements per 16-byte unit
+  typedef float4v unit_t;
+};
+template <> struct ET<half_t> {
+  static constexpr int UNIT = 8;
+  typedef half8v unit_t;
+};
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(half_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ half_t from_f32<half_t>(float x) { return (half_t)x; }
+
+// dot of one 16-byte unit of T with another, accumulated in fp32
+__device__ __forceinline__ float dot_unit(float4v a, float4v b, float acc) {
+  acc = __builtin_fmaf(a[0], b[0], acc);
+  acc = __builtin_fmaf(a[1], b[1], acc);
+  acc = __builtin_fmaf(a[2], b[2], acc);
+  acc = __builtin_fmaf(a[3], b[3], acc);
+  return acc;
+}
+__device__ __forceinline__ float dot_unit(half8v a, half8v b, float acc) {
+  // v_dot2_f32_f16: two fp16 products accumulated in fp32
+  acc = __builtin_amdgcn_fdot2(half2v{a[0], a[1]}, half2v{b[0], b[1]}, acc, false);
+  acc = __builtin_amdgcn_fdot2(half2v{a[2], a[3]}, half2v{b[2], b[3]}, acc, false);
+  acc = __builtin_amdgcn_fdot2(half2v{a[4], a[5]}, half2v{b[4], b[5]}, acc, false);
+  acc = __builtin_amdgcn_fdot2(half2v{a[6], a[7]}, half2v{b[6], b[7]}, acc, false);
+  return acc;
+}
+
+// exact-erf GELU (nn.GELU() default, whisper/model.py:156,193)
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave reductions (64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS tile swizzle for row-major tiles whose rows are 128 bytes = 8 units of 16 bytes:
+// unit u of row r lives at unit slot u ^ ((r >> 1) & 7).  Conflict-free for ds_read_b128 when a
+// wave reads one unit column of 16 or 32 consecutive rows (MFMA A/B fragments).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz_unit(int row, int unit) { return unit ^ ((row >> 1) & 7); }
+__device__ __forceinline__ int swz_byte(int row, int unit) { return row * 128 + (swz_unit(row, unit) << 4); }
+
+// ordered-int encoding of floats so that atomicMax on int32 orders like float
+__device__ __forceinline__ int float_to_ordered(float f) {
+  int i = __float_as_int(f);
+  return (i >= 0) ? i : (i ^ 0x7fffffff);
+}
+__device__ __forceinline__ float ordered_to_float(int i) {
+  return __int_as_float((i >= 0) ? i : (i ^ 0x7fffffff));
+}
+
+#define WH_NEG_INF (-__builtin_huge_valf())

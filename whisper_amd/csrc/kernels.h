@@ -1,0 +1,127 @@
+// kernels.h — internal launcher interface between api.cpp and the .hip kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace whk {
+
+// dtype: 0 = fp32, 1 = fp16 (matches WH_F32 / WH_F16)
+
+// ---- mel.hip -------------------------------------------------------------------------------
+hipError_t launch_log_mel(const float* audio, int64_t n_samples, int batch, int n_mels,
+                          const float* filters, const float* tables, float* out, void* scratch,
+                          hipStream_t stream);
+
+// ---- gemm.hip ------------------------------------------------------------------------------
+struct GemmArgs {
+  const void* A; int64_t lda; int64_t a_bs;     // [M][K], row stride lda (elements), batch stride
+  const void* W; int64_t ldw; int64_t w_bs;     // [N][K]
+  void* C; int64_t ldc; int64_t c_bs;           // [M][N]
+  const float* bias; int bias_on_m;             // per-n (default) or per-m bias
+  const float* res; int64_t ldr; int64_t r_bs; int res_mod;  // fp32 residual, row index m % res_mod if res_mod>0
+  int act;                                      // 0 none, 1 exact GELU
+  int M, N, K;
+  int tiles_m, tiles_n;                         // filled by the launcher
+};
+hipError_t launch_gemm(const GemmArgs& a, int dtype, int out_f32, int batch, hipStream_t stream);
+
+// ---- elementwise.hip -----------------------------------------------------------------------
+// mel [B][n_mels][F] (fp32 or fp16) -> [B][F+2][n_mels] element type with zero rows 0 and F+1
+hipError_t launch_mel_transpose(const void* mel, int mel_is_f16, int B, int n_mels, int F, void* out,
+                                int dtype, hipStream_t stream);
+// fp32 x [rows][D] (row stride ldx) -> element-type out [rows][D] (row stride ldo)
+hipError_t launch_layernorm(const float* x, int64_t ldx, const float* w, const float* b, void* out,
+                            int64_t ldo, int64_t rows, int D, int dtype, hipStream_t stream);
+// x[r*T0+t][:] = tok_emb[tokens[r*stride+t]][:] + pos[(offset+t)][:]   (fp32 out)
+hipError_t launch_embed(const int64_t* tokens, int64_t stride, int R, int T0, const void* tok_emb,
+                        const float* pos, const int* d_offset, int D, int n_vocab, float* x, int dtype,
+                        hipStream_t stream);
+// qkv [R*T0][3D] -> q [R*T0][D] is left in place (ld 3D); k,v rows scattered to caches [R][n_ctx][D]
+hipError_t launch_scatter_kv(const void* qkv, int R, int T0, int D, const int* d_offset, int n_ctx,
+                             void* kcache, void* vcache, int dtype, hipStream_t stream);
+// out[i][:] = x[sel[i]][:] (fp32 rows of width D); sel device int array
+hipError_t launch_gather_rows(const float* x, const int* sel, int n_sel, int D, float* out,
+                              hipStream_t stream);
+// dst rows <- src rows[src_idx[i]] : self-attention cache gather for beam search (rows of row_elems elements)
+hipError_t launch_gather_cache(const void* src, void* dst, const int* src_idx, int R, int64_t row_bytes,
+                               int64_t used_bytes, hipStream_t stream);
+hipError_t launch_add_int(int* p, int v, hipStream_t stream);
+
+// ---- attention.hip -------------------------------------------------------------------------
+struct AttnArgs {
+  const void* q; int64_t q_ld; int64_t q_bs;      // q rows [Tq] per batch row (element type), head h at cols h*64
+  const void* k; int64_t k_ld; int64_t k_bs;      // keys  [Tk] per kv-batch
+  const void* v; int64_t v_ld; int64_t v_bs;
+  void* out; int64_t o_ld; int64_t o_bs;          // [Tq][H*64] element type
+  int H; int Tq; int Tk;                          // Tk used when d_len == nullptr
+  const int* d_len;                               // device: cached length BEFORE this call (Tk = *d_len + Tq), or null
+  int causal;                                     // query t sees keys <= (Tk - Tq) + t
+  int kv_group;                                   // kv batch index = batch / kv_group
+  float* qk_out;                                  // unused (reserved)
+};
+// generic (any Tq/Tk, VALU) attention, used for fp32 parity mode and decoder prefill
+hipError_t launch_attn_generic(const AttnArgs& a, int batch, int dtype, hipStream_t stream);
+// MFMA flash attention for the encoder (fp16 only): q,k [B][T][..] rows, vt = V transposed [B][H*64][ldv]
+hipError_t launch_attn_flash_f16(const void* q, int64_t q_ld, int64_t q_bs, const void* k, int64_t k_ld,
+                                 int64_t k_bs, const void* vt, int64_t vt_ld, int64_t vt_bs, void* out,
+                                 int64_t o_ld, int64_t o_bs, int B, int H, int T, hipStream_t stream);
+// single-query decode attention with split-K partials
+struct DecAttnArgs {
+  const void* q; int64_t q_ld;                    // [R][H*64]
+  const void* k; int64_t k_ld; int64_t k_bs;      // [Bkv][Tk][H*64]
+  const void* v; int64_t v_ld; int64_t v_bs;
+  int H; int R; int kv_group;
+  int Tk; const int* d_len; int len_plus;         // Tk fixed, or *d_len + len_plus
+  int splits;                                     // key-range splits
+  void* out; int64_t o_ld;                        // splits==1: normalized output, element type
+  float* part_o; float* part_ml;                  // splits>1: [R][H][S][64], [R][H][S][2]
+};
+hipError_t launch_attn_decode(const DecAttnArgs& a, int dtype, hipStream_t stream);
+// scores of selected (layer, head) pairs: out[pair][t][j] = scale^2 * q[t]·k[j]
+hipError_t launch_cross_qk(const void* q, int64_t q_ld, const void* k, int64_t k_ld, int head, int n_tok,
+                           int Tk, float* out, int dtype, hipStream_t stream);
+
+// ---- gemv.hip ------------------------------------------------------------------------------
+enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_COMBINE = 2 };
+enum { EPI_STORE = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3, EPI_F32 = 4 };
+struct GemvArgs {
+  // prologue
+  int pro;
+  const void* x; int64_t x_ld;                    // PRO_PLAIN: element type [R][K]
+  const float* xf; int64_t xf_ld;                 // PRO_LN: fp32 residual rows [R][K]
+  const float* ln_w; const float* ln_b;
+  const float* part_o; const float* part_ml; int splits; int H;  // PRO_COMBINE
+  // weights
+  const void* W; const float* bias; int N; int K; int R;
+  // epilogue
+  int epi;
+  void* y; int64_t y_ld;                          // EPI_STORE / EPI_GELU (element type), EPI_F32 (float)
+  float* resid; int64_t resid_ld;                 // EPI_RESID: resid[r][n] += y
+  void* kcache; void* vcache; int64_t cache_bs; const int* d_pos; int D;  // EPI_QKV
+};
+hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream);
+
+// ---- sampling.hip --------------------------------------------------------------------------
+struct SampleArgs {
+  const float* logits; int64_t logits_ld;   // row r at logits + r*logits_ld, V entries
+  int R, V;
+  int64_t* tokens; int64_t token_stride;          // [R][stride], current length *d_ntok
+  const int* d_ntok;          // device: number of tokens currently in each row (== cached positions)
+  int sample_begin, eot, timestamp_begin, no_timestamps, max_initial_ts, suppress_blank, blank_token;
+  const uint8_t* suppress_mask;
+  float* sum_logprobs;        // [R]
+  int64_t* step_tokens;       // [R] next-step input tokens (may be null)
+  int* d_alive_step;          // device: set to ntok by every row whose sampled token is not EOT
+};
+hipError_t launch_greedy_sample(const SampleArgs& a, hipStream_t stream);
+hipError_t launch_no_speech(const float* logits_row0, int64_t row_stride, int R, int V, int no_speech,
+                            float* out, hipStream_t stream);
+// dst[r] = src[r*stride]
+hipError_t launch_gather_tokens(const int64_t* src, int64_t stride, int R, int64_t* dst, hipStream_t stream);
+
+// ---- timing.hip ----------------------------------------------------------------------------
+hipError_t launch_median_filter(const float* x, float* out, int64_t rows, int n, int width,
+                                hipStream_t stream);
+hipError_t launch_dtw(const float* x, int N, int M, int8_t* trace, hipStream_t stream);
+
+}  // namespace whk

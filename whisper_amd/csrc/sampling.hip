@@ -1,0 +1,193 @@
+// sampling.hip — the logits epilogue of DecodingTask._main_loop (whisper/decoding.py:696-703) for
+// greedy decoding, as ONE kernel per step with no host synchronisation:
+//   SuppressBlank (decoding.py:423-430) -> SuppressTokens (:433-438) -> ApplyTimestampRules (:441-505)
+//   -> GreedyDecoder.update at temperature 0 (:277-293): argmax, log_softmax of the *filtered* logits,
+//   sum_logprobs accumulation for rows not yet at EOT, EOT stickiness.
+// One workgroup per row; a single pass over the fp32 logits keeps separate online (max, sum-exp,
+// arg-max) statistics for the text range [0, timestamp_begin) and the timestamp range, from which the
+// "timestamp probability mass > best text token" rule (:498-505) and the final normaliser follow
+// without re-reading the row.  The row's token history (needed by the pairing / monotonicity rules)
+// is scanned in parallel.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+struct Stat {           // online softmax statistics + first-index argmax of a range
+  float m, s; int idx;
+};
+__device__ __forceinline__ void stat_add(Stat& a, float x, int i) {
+  if (x == WH_NEG_INF) return;
+  if (x > a.m) { a.s = a.s * expf(a.m - x) + 1.0f; a.m = x; a.idx = i; }
+  else { a.s += expf(x - a.m); }   // x == a.m keeps the earlier (smaller) index: thread scan is ascending
+}
+__device__ __forceinline__ void stat_merge(Stat& a, float m, float s, int idx) {
+  if (m == WH_NEG_INF) return;
+  if (a.m == WH_NEG_INF) { a.m = m; a.s = s; a.idx = idx; return; }
+  if (m > a.m || (m == a.m && idx < a.idx)) {
+    a.s = a.s * expf(a.m - m) + s;
+    a.m = m; a.idx = idx;
+  } else {
+    a.s += s * expf(m - a.m);
+  }
+}
+__device__ __forceinline__ void stat_wave_reduce(Stat& a) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m = __shfl_xor(a.m, o, 64);
+    const float s = __shfl_xor(a.s, o, 64);
+    const int idx = __shfl_xor(a.idx, o, 64);
+    stat_merge(a, m, s, idx);
+  }
+}
+
+__global__ __launch_bounds__(256) void greedy_sample_kernel(whk::SampleArgs a) {
+  __shared__ int sh_last_ts;
+  __shared__ float sh_m[2][4], sh_s[2][4];
+  __shared__ int sh_i[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.x;
+  const int ntok = *a.d_ntok;
+  int64_t* row = a.tokens + (int64_t)k * a.token_stride;
+  const float* x = a.logits + (int64_t)k * a.logits_ld;
+  const int L = ntok - a.sample_begin;
+  const int TB = a.timestamp_begin;       // < 0: timestamp rules disabled (without_timestamps)
+  const bool ts_rules = TB >= 0;
+
+  if (tid == 0) sh_last_ts = -1;
+  __syncthreads();
+  if (ts_rules) {
+    for (int t = tid; t < L; t += 256)
+      if (row[a.sample_begin + t] >= TB) atomicMax(&sh_last_ts, t);
+  }
+  __syncthreads();
+
+  const int64_t last_tok = row[ntok - 1];
+  bool last_ts = false, pen_ts = false;
+  int ts_lo = 0, ts_hi = 0;              // forbidden timestamp interval [ts_lo, ts_hi)
+  if (ts_rules) {
+    last_ts = (L >= 1) && (row[ntok - 1] >= TB);
+    pen_ts = (L < 2) || (row[ntok - 2] >= TB);
+    if (sh_last_ts >= 0) {
+      const int t = (int)row[a.sample_begin + sh_last_ts];
+      ts_lo = TB;
+      ts_hi = (last_ts && !pen_ts) ? t : t + 1;
+    }
+  }
+  const int split = ts_rules ? TB : a.V;   // text range [0, split), timestamp range [split, V)
+
+  Stat st[2];
+  st[0] = Stat{WH_NEG_INF, 0.f, 0x7fffffff};
+  st[1] = Stat{WH_NEG_INF, 0.f, 0x7fffffff};
+  for (int v = tid; v < a.V; v += 256) {
+    bool masked = a.suppress_mask && a.suppress_mask[v];
+    if (a.suppress_blank && L == 0 && (v == a.blank_token || v == a.eot)) masked = true;
+    if (ts_rules) {
+      if (v == a.no_timestamps) masked = true;
+      if (last_ts) {
+        if (pen_ts) { if (v >= TB) masked = true; }
+        else { if (v < a.eot) masked = true; }
+      }
+      if (v >= ts_lo && v < ts_hi) masked = true;
+      if (L == 0) {
+        if (v < TB) masked = true;
+        if (a.max_initial_ts >= 0 && v > TB + a.max_initial_ts) masked = true;
+      }
+    }
+    if (masked) continue;
+    const float xv = x[v];
+    if (v < split) stat_add(st[0], xv, v); else stat_add(st[1], xv, v);
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    stat_wave_reduce(st[g]);
+    if (lane == 0) { sh_m[g][wave] = st[g].m; sh_s[g][wave] = st[g].s; sh_i[g][wave] = st[g].idx; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    Stat tx = Stat{WH_NEG_INF, 0.f, 0x7fffffff}, ts = tx;
+    for (int w = 0; w < 4; ++w) {
+      stat_merge(tx, sh_m[0][w], sh_s[0][w], sh_i[0][w]);
+      stat_merge(ts, sh_m[1][w], sh_s[1][w], sh_i[1][w]);
+    }
+    bool text_masked = false;
+    if (ts_rules) {
+      // decoding.py:498-505 — logsumexp of timestamp logprobs vs max text logprob (same normaliser)
+      Stat all = tx;
+      stat_merge(all, ts.m, ts.s, ts.idx);
+      if (all.m != WH_NEG_INF) {
+        const float lse_all = logf(all.s);
+        const float ts_lp_max = (ts.m - all.m) - lse_all;
+        const float ts_lse = (ts.m == WH_NEG_INF) ? WH_NEG_INF : ts_lp_max + logf(ts.s);
+        const float text_lp_max = (tx.m == WH_NEG_INF) ? WH_NEG_INF : (tx.m - all.m) - lse_all;
+        if (ts_lse > text_lp_max) text_masked = true;
+      }
+    }
+    Stat fin = ts;
+    if (!text_masked) { fin = tx; stat_merge(fin, ts.m, ts.s, ts.idx); }
+    int next = fin.idx;
+    // log_softmax(filtered)[next] = x - max - log(sum exp(x - max)); x[next] == max
+    float lp = -logf(fin.s);
+    if (fin.m == WH_NEG_INF) { next = 0; lp = __builtin_nanf(""); }   // every logit filtered: argmax of all -inf
+    if (last_tok != a.eot) a.sum_logprobs[k] += lp;
+    else next = a.eot;
+    row[ntok] = next;
+    if (a.step_tokens) a.step_tokens[k] = next;
+    if (next != a.eot) *a.d_alive_step = ntok;       // benign race: every writer stores the same value
+  }
+}
+
+__global__ __launch_bounds__(256) void no_speech_kernel(const float* __restrict__ logits, int64_t row_stride,
+                                                        int V, int no_speech, float* __restrict__ out) {
+  __shared__ float sh_m[4], sh_s[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = logits + (int64_t)blockIdx.x * row_stride;
+  float m = WH_NEG_INF, s = 0.f;
+  for (int v = tid; v < V; v += 256) {
+    const float xv = x[v];
+    if (xv > m) { s = s * expf(m - xv) + 1.0f; m = xv; } else s += expf(xv - m);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    const float mn = fmaxf(m, m2);
+    s = (mn == WH_NEG_INF) ? 0.f : s * expf(m - mn) + s2 * expf(m2 - mn);
+    m = mn;
+  }
+  if (lane == 0) { sh_m[wave] = m; sh_s[wave] = s; }
+  __syncthreads();
+  if (tid == 0) {
+    float M = fmaxf(fmaxf(sh_m[0], sh_m[1]), fmaxf(sh_m[2], sh_m[3]));
+    float S = 0.f;
+    for (int w = 0; w < 4; ++w) S += sh_s[w] * expf(sh_m[w] - M);
+    out[blockIdx.x] = expf(x[no_speech] - M) / S;
+  }
+}
+
+__global__ void gather_tokens_kernel(const int64_t* __restrict__ src, int64_t stride, int R,
+                                     int64_t* __restrict__ dst) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < R) dst[r] = src[(int64_t)r * stride];
+}
+
+}  // namespace
+
+namespace whk {
+
+hipError_t launch_greedy_sample(const SampleArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(greedy_sample_kernel, dim3(a.R), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_no_speech(const float* logits, int64_t row_stride, int R, int V, int no_speech,
+                            float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(no_speech_kernel, dim3(R), dim3(256), 0, stream, logits, row_stride, V, no_speech, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_tokens(const int64_t* src, int64_t stride, int R, int64_t* dst, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_tokens_kernel, dim3((R + 63) / 64), dim3(64), 0, stream, src, stride, R, dst);
+  return hipGetLastError();
+}
+
+}  // namespace whk

@@ -1,0 +1,474 @@
+"""ctypes binding of libwhisper_hip.so (include/whisper_hip.h) — the only door to the HIP kernels.
+
+Nothing here computes: tensors are allocated by torch (device memory, streams), their raw pointers are
+handed to the C ABI.  If the shared library is missing or the device is not a ROCm GPU, every entry
+point raises — there is deliberately no CPU fallback on the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+_LIB = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwhisper_hip.so")
+
+WH_F32, WH_F16 = 0, 1
+WH_TASK_CAPTURE_Q = 1
+MEL_SCRATCH_BYTES = 2048
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
+        "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")]
+
+
+_LAYER_FIELDS = (
+    "attn_ln_w", "attn_ln_b", "qkv_w", "qkv_b", "out_w", "out_b",
+    "cross_ln_w", "cross_ln_b", "cq_w", "cq_b", "ckv_w", "ckv_b", "cout_w", "cout_b",
+    "mlp_ln_w", "mlp_ln_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _LAYER_FIELDS]
+
+
+class ModelWeights(C.Structure):
+    _fields_ = [
+        ("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p),
+        ("conv2_w", C.c_void_p), ("conv2_b", C.c_void_p),
+        ("enc_pos", C.c_void_p),
+        ("enc_layers", C.POINTER(LayerWeights)),
+        ("enc_ln_post_w", C.c_void_p), ("enc_ln_post_b", C.c_void_p),
+        ("tok_emb", C.c_void_p), ("dec_pos", C.c_void_p),
+        ("dec_layers", C.POINTER(LayerWeights)),
+        ("dec_ln_w", C.c_void_p), ("dec_ln_b", C.c_void_p),
+    ]
+
+
+class GreedyParams(C.Structure):
+    _fields_ = [
+        ("sample_begin", C.c_int32), ("max_steps", C.c_int32), ("n_ctx", C.c_int32), ("eot", C.c_int32),
+        ("timestamp_begin", C.c_int32), ("no_timestamps", C.c_int32),
+        ("max_initial_timestamp_index", C.c_int32), ("suppress_blank", C.c_int32),
+        ("blank_token", C.c_int32), ("suppress_mask", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); also the list the CPU-only symbol test walks
+SIGNATURES = {
+    "wh_abi_version": (C.c_int, []),
+    "wh_status_string": (C.c_char_p, [C.c_int]),
+    "wh_last_hip_error": (C.c_int, []),
+    "wh_last_hip_error_string": (C.c_char_p, []),
+    "wh_log_mel": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "wh_model_create": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(ModelWeights), C.POINTER(C.c_void_p)]),
+    "wh_model_destroy": (None, [C.c_void_p]),
+    "wh_encoder_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "wh_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wh_task_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "wh_task_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "wh_task_destroy": (None, [C.c_void_p]),
+    "wh_task_set_audio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "wh_task_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p]),
+    "wh_task_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "wh_task_rearrange": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "wh_task_reset": (C.c_int, [C.c_void_p]),
+    "wh_task_position": (C.c_int, [C.c_void_p]),
+    "wh_task_greedy": (C.c_int, [C.c_void_p, C.POINTER(GreedyParams), C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "wh_task_cross_qk": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "wh_median_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "wh_dtw_trace": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+}
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def lib():
+    """Load libwhisper_hip.so (built in-tree by `make -C whisper_amd/csrc` / __graft_entry__.build())."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.isfile(_LIB_PATH):
+            raise HipError(
+                f"{_LIB_PATH} is missing: build it with `make -C whisper_amd/csrc` "
+                "(or __graft_entry__.build()). There is no non-HIP fallback.")
+        handle = C.CDLL(_LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.wh_abi_version() != 1:
+            raise HipError("libwhisper_hip.so ABI version mismatch")
+        _LIB = handle
+    return _LIB
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        L = lib()
+        msg = L.wh_status_string(rc).decode()
+        if rc == 3:
+            msg += f" ({L.wh_last_hip_error_string().decode()})"
+        raise HipError(f"{what or 'libwhisper_hip'}: {msg}")
+
+
+def require_gpu(device: torch.device) -> None:
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise HipError("the HIP path needs a ROCm GPU device ('cuda'); no CPU fallback exists in whisper_amd")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(stream: torch.cuda.Stream) -> int:
+    return stream.cuda_stream
+
+
+# ---------------------------------------------------------------------------------------------------
+# weight packing: reference checkpoint names (whisper/model.py module tree) -> one device blob
+# ---------------------------------------------------------------------------------------------------
+def _align(x: int, a: int = 256) -> int:
+    return (x + a - 1) // a * a
+
+
+def _block_pieces(sd: Dict[str, torch.Tensor], prefix: str, cross: bool, D: int):
+    """yield (field, tensor, is_matrix) for one ResidualAttentionBlock (whisper/model.py:142-171)"""
+    z = torch.zeros(D, dtype=torch.float32)
+    g = lambda k: sd[prefix + k]
+    yield "attn_ln_w", g("attn_ln.weight"), False
+    yield "attn_ln_b", g("attn_ln.bias"), False
+    yield "qkv_w", torch.cat([g("attn.query.weight"), g("attn.key.weight"), g("attn.value.weight")], 0), True
+    yield "qkv_b", torch.cat([g("attn.query.bias").float().cpu(), z, g("attn.value.bias").float().cpu()], 0), False
+    yield "out_w", g("attn.out.weight"), True
+    yield "out_b", g("attn.out.bias"), False
+    if cross:
+        yield "cross_ln_w", g("cross_attn_ln.weight"), False
+        yield "cross_ln_b", g("cross_attn_ln.bias"), False
+        yield "cq_w", g("cross_attn.query.weight"), True
+        yield "cq_b", g("cross_attn.query.bias"), False
+        yield "ckv_w", torch.cat([g("cross_attn.key.weight"), g("cross_attn.value.weight")], 0), True
+        yield "ckv_b", torch.cat([z, g("cross_attn.value.bias").float().cpu()], 0), False
+        yield "cout_w", g("cross_attn.out.weight"), True
+        yield "cout_b", g("cross_attn.out.bias"), False
+    yield "mlp_ln_w", g("mlp_ln.weight"), False
+    yield "mlp_ln_b", g("mlp_ln.bias"), False
+    yield "fc1_w", g("mlp.0.weight"), True
+    yield "fc1_b", g("mlp.0.bias"), False
+    yield "fc2_w", g("mlp.2.weight"), True
+    yield "fc2_b", g("mlp.2.bias"), False
+
+
+def _conv_as_gemm(w: torch.Tensor, k_pad: int) -> torch.Tensor:
+    """conv weight [D][C][3] -> GEMM weight [D][k_pad] with column kk*C + c (zero padded)"""
+    D, Cin, _ = w.shape
+    out = torch.zeros(D, k_pad, dtype=w.dtype, device=w.device)
+    out[:, : 3 * Cin] = w.permute(0, 2, 1).reshape(D, 3 * Cin)
+    return out
+
+
+def model_pieces(sd: Dict[str, torch.Tensor], dims) -> List[Tuple[str, torch.Tensor, bool]]:
+    D = dims.n_audio_state
+    kc1 = _align(3 * dims.n_mels, 64)
+    out = [
+        ("conv1_w", _conv_as_gemm(sd["encoder.conv1.weight"], kc1), True),
+        ("conv1_b", sd["encoder.conv1.bias"], False),
+        ("conv2_w", _conv_as_gemm(sd["encoder.conv2.weight"], 3 * D), True),
+        ("conv2_b", sd["encoder.conv2.bias"], False),
+        ("enc_pos", sd["encoder.positional_embedding"], False),
+        ("enc_ln_post_w", sd["encoder.ln_post.weight"], False),
+        ("enc_ln_post_b", sd["encoder.ln_post.bias"], False),
+        ("tok_emb", sd["decoder.token_embedding.weight"], True),
+        ("dec_pos", sd["decoder.positional_embedding"], False),
+        ("dec_ln_w", sd["decoder.ln.weight"], False),
+        ("dec_ln_b", sd["decoder.ln.bias"], False),
+    ]
+    for i in range(dims.n_audio_layer):
+        for f, t, mat in _block_pieces(sd, f"encoder.blocks.{i}.", False, D):
+            out.append((f"enc.{i}.{f}", t, mat))
+    for i in range(dims.n_text_layer):
+        for f, t, mat in _block_pieces(sd, f"decoder.blocks.{i}.", True, dims.n_text_state):
+            out.append((f"dec.{i}.{f}", t, mat))
+    return out
+
+
+def blob_layout(dims, dtype: int) -> Tuple[Dict[str, Tuple[int, Tuple[int, ...], bool]], int]:
+    """offsets of every packed tensor, computed from dims alone (every rank derives the same layout)"""
+    D, Dt, M = dims.n_audio_state, dims.n_text_state, dims.n_mels
+    kc1 = _align(3 * M, 64)
+    shapes: List[Tuple[str, Tuple[int, ...], bool]] = [
+        ("conv1_w", (D, kc1), True), ("conv1_b", (D,), False),
+        ("conv2_w", (D, 3 * D), True), ("conv2_b", (D,), False),
+        ("enc_pos", (dims.n_audio_ctx, D), False),
+        ("enc_ln_post_w", (D,), False), ("enc_ln_post_b", (D,), False),
+        ("tok_emb", (dims.n_vocab, Dt), True), ("dec_pos", (dims.n_text_ctx, Dt), False),
+        ("dec_ln_w", (Dt,), False), ("dec_ln_b", (Dt,), False),
+    ]
+
+    def block(prefix, d, cross):
+        s = [("attn_ln_w", (d,), False), ("attn_ln_b", (d,), False), ("qkv_w", (3 * d, d), True),
+             ("qkv_b", (3 * d,), False), ("out_w", (d, d), True), ("out_b", (d,), False)]
+        if cross:
+            s += [("cross_ln_w", (d,), False), ("cross_ln_b", (d,), False), ("cq_w", (d, d), True),
+                  ("cq_b", (d,), False), ("ckv_w", (2 * d, d), True), ("ckv_b", (2 * d,), False),
+                  ("cout_w", (d, d), True), ("cout_b", (d,), False)]
+        s += [("mlp_ln_w", (d,), False), ("mlp_ln_b", (d,), False), ("fc1_w", (4 * d, d), True),
+              ("fc1_b", (4 * d,), False), ("fc2_w", (d, 4 * d), True), ("fc2_b", (d,), False)]
+        return [(prefix + n, sh, m) for n, sh, m in s]
+
+    for i in range(dims.n_audio_layer):
+        shapes += block(f"enc.{i}.", D, False)
+    for i in range(dims.n_text_layer):
+        shapes += block(f"dec.{i}.", Dt, True)
+    esize = 2 if dtype == WH_F16 else 4
+    layout, off = {}, 0
+    for name, shape, mat in shapes:
+        n = 1
+        for s in shape:
+            n *= s
+        layout[name] = (off, shape, mat)
+        off = _align(off + n * (esize if mat else 4))
+    return layout, off + 4096   # tail slack: padded-K GEMM reads never leave the blob
+
+
+def pack_weights(sd: Dict[str, torch.Tensor], dims, dtype: int, device: torch.device) -> torch.Tensor:
+    """Cast + copy every tensor of a reference-format state_dict into one device blob."""
+    layout, total = blob_layout(dims, dtype)
+    blob = torch.zeros(total, dtype=torch.uint8, device=device)
+    tdt = torch.float16 if dtype == WH_F16 else torch.float32
+    for name, t, mat in model_pieces(sd, dims):
+        off, shape, mat2 = layout[name]
+        assert mat == mat2 and tuple(t.shape) == tuple(shape), (name, t.shape, shape)
+        dt = tdt if mat else torch.float32
+        nbytes = t.numel() * (2 if dt == torch.float16 else 4)
+        blob[off: off + nbytes].view(dt).copy_(t.detach().to(device=device, dtype=dt).reshape(-1))
+    return blob
+
+
+class HipModel:
+    """wh_model handle + the weight blob it points into."""
+
+    def __init__(self, dims, dtype: int, blob: torch.Tensor):
+        require_gpu(blob.device)
+        self.dims, self.dtype, self.blob = dims, dtype, blob
+        self.device = blob.device
+        self.torch_dtype = torch.float16 if dtype == WH_F16 else torch.float32
+        layout, total = blob_layout(dims, dtype)
+        assert blob.numel() >= total
+        base = blob.data_ptr()
+        addr = lambda n: base + layout[n][0]
+        self._enc = (LayerWeights * dims.n_audio_layer)()
+        self._dec = (LayerWeights * dims.n_text_layer)()
+        for i in range(dims.n_audio_layer):
+            for f in _LAYER_FIELDS:
+                key = f"enc.{i}.{f}"
+                setattr(self._enc[i], f, addr(key) if key in layout else None)
+        for i in range(dims.n_text_layer):
+            for f in _LAYER_FIELDS:
+                setattr(self._dec[i], f, addr(f"dec.{i}.{f}"))
+        w = ModelWeights()
+        for f in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "enc_pos", "enc_ln_post_w", "enc_ln_post_b",
+                  "tok_emb", "dec_pos", "dec_ln_w", "dec_ln_b"):
+            setattr(w, f, addr(f))
+        w.enc_layers = C.cast(self._enc, C.POINTER(LayerWeights))
+        w.dec_layers = C.cast(self._dec, C.POINTER(LayerWeights))
+        d = Dims(*[getattr(dims, n) for n, _ in Dims._fields_])
+        h = C.c_void_p()
+        check(lib().wh_model_create(C.byref(d), dtype, C.byref(w), C.byref(h)), "wh_model_create")
+        self.handle = h
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._enc_ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                lib().wh_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # -- AudioEncoder.forward ----------------------------------------------------------------------
+    def encode(self, mel: torch.Tensor) -> torch.Tensor:
+        d = self.dims
+        assert mel.is_cuda and mel.dim() == 3
+        if mel.shape[1:] != (d.n_mels, 2 * d.n_audio_ctx):
+            raise AssertionError("incorrect audio shape")   # whisper/model.py:197
+        if mel.dtype not in (torch.float32, torch.float16):
+            mel = mel.float()
+        mel = mel.contiguous()
+        B = mel.shape[0]
+        need = lib().wh_encoder_workspace_bytes(self.handle, B)
+        if self._enc_ws is None or self._enc_ws.numel() < need:
+            self._enc_ws = None
+            self._enc_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = torch.empty(B, d.n_audio_ctx, d.n_audio_state, dtype=self.torch_dtype, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        check(lib().wh_encode(self.handle, mel.data_ptr(), int(mel.dtype == torch.float16), B, out.data_ptr(),
+                              self._enc_ws.data_ptr(), self._enc_ws.numel(), stream_ptr(self.stream)), "wh_encode")
+        cur.wait_stream(self.stream)
+        mel.record_stream(self.stream)
+        return out
+
+
+class HipTask:
+    """wh_task: KV caches + workspace of one DecodingTask (whisper/decoding.py:144-176 PyTorchInference)."""
+
+    def __init__(self, model: HipModel, n_audio: int, n_group: int, max_prefill: int, capture_q: bool = False):
+        self.model = model
+        self.n_audio, self.n_group, self.n_rows = n_audio, n_group, n_audio * n_group
+        self.max_prefill = max_prefill
+        flags = WH_TASK_CAPTURE_Q if capture_q else 0
+        need = lib().wh_task_workspace_bytes(model.handle, n_audio, n_group, max_prefill, flags)
+        if need == 0:
+            raise HipError("wh_task_workspace_bytes: invalid arguments")
+        self.ws = torch.empty(need, dtype=torch.uint8, device=model.device)
+        h = C.c_void_p()
+        torch.cuda.synchronize(model.device)
+        check(lib().wh_task_create(model.handle, n_audio, n_group, max_prefill, flags, self.ws.data_ptr(),
+                                   self.ws.numel(), C.byref(h)), "wh_task_create")
+        self.handle = h
+        self.stream = model.stream
+
+    def close(self):
+        if getattr(self, "handle", None):
+            torch.cuda.synchronize(self.model.device)
+            lib().wh_task_destroy(self.handle)
+            self.handle = None
+            self.ws = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _enter(self):
+        cur = torch.cuda.current_stream(self.model.device)
+        self.stream.wait_stream(cur)
+        return cur
+
+    def set_audio(self, features: torch.Tensor):
+        assert features.is_cuda and features.dtype == self.model.torch_dtype and features.is_contiguous()
+        assert features.shape[0] == self.n_audio
+        cur = self._enter()
+        check(lib().wh_task_set_audio(self.handle, features.data_ptr(), stream_ptr(self.stream)), "wh_task_set_audio")
+        cur.wait_stream(self.stream)
+        features.record_stream(self.stream)
+
+    def prefill(self, tokens: torch.Tensor, sel: Optional[Sequence[int]] = None) -> torch.Tensor:
+        assert tokens.is_cuda and tokens.dtype == torch.int64 and tokens.dim() == 2
+        assert tokens.shape[0] == self.n_rows and tokens.stride(1) == 1
+        T0 = tokens.shape[1]
+        n_sel = T0 if sel is None else len(sel)
+        logits = torch.empty(self.n_rows, n_sel, self.model.dims.n_vocab, dtype=torch.float32, device=tokens.device)
+        sel_arr = None if sel is None else (C.c_int32 * n_sel)(*sel)
+        cur = self._enter()
+        check(lib().wh_task_prefill(self.handle, tokens.data_ptr(), tokens.stride(0), T0, sel_arr, n_sel,
+                                    logits.data_ptr(), stream_ptr(self.stream)), "wh_task_prefill")
+        cur.wait_stream(self.stream)
+        tokens.record_stream(self.stream)
+        return logits
+
+    def step(self, last_tokens: torch.Tensor) -> torch.Tensor:
+        """last_tokens: int64 view [n_rows] (any stride)."""
+        assert last_tokens.is_cuda and last_tokens.dtype == torch.int64 and last_tokens.dim() == 1
+        logits = torch.empty(self.n_rows, self.model.dims.n_vocab, dtype=torch.float32, device=last_tokens.device)
+        cur = self._enter()
+        check(lib().wh_task_step(self.handle, last_tokens.data_ptr(), last_tokens.stride(0), logits.data_ptr(),
+                                 stream_ptr(self.stream)), "wh_task_step")
+        cur.wait_stream(self.stream)
+        last_tokens.record_stream(self.stream)
+        return logits
+
+    def rearrange(self, source_indices: Sequence[int]):
+        arr = (C.c_int32 * len(source_indices))(*[int(i) for i in source_indices])
+        assert len(source_indices) == self.n_rows
+        cur = self._enter()
+        check(lib().wh_task_rearrange(self.handle, arr, stream_ptr(self.stream)), "wh_task_rearrange")
+        cur.wait_stream(self.stream)
+
+    def reset(self):
+        torch.cuda.synchronize(self.model.device)
+        check(lib().wh_task_reset(self.handle), "wh_task_reset")
+
+    @property
+    def position(self) -> int:
+        return lib().wh_task_position(self.handle)
+
+    def greedy(self, tokens: torch.Tensor, params: GreedyParams, sot_index: int, no_speech_token: int):
+        """tokens: int64 [n_rows][>= sample_begin + max_steps], initial tokens in the first columns.
+        Returns (n_tokens, sum_logprobs[n_rows], no_speech_probs[n_rows] | None)."""
+        assert tokens.is_cuda and tokens.dtype == torch.int64 and tokens.stride(1) == 1
+        dev = tokens.device
+        sum_lp = torch.empty(self.n_rows, dtype=torch.float32, device=dev)
+        nsp = torch.empty(self.n_rows, dtype=torch.float32, device=dev) if no_speech_token >= 0 else None
+        n_out = C.c_int32(0)
+        cur = self._enter()
+        check(lib().wh_task_greedy(self.handle, C.byref(params), tokens.data_ptr(), tokens.stride(0), sot_index,
+                                   no_speech_token, sum_lp.data_ptr(), _ptr(nsp), C.byref(n_out),
+                                   stream_ptr(self.stream)), "wh_task_greedy")
+        cur.wait_stream(self.stream)
+        return n_out.value, sum_lp, nsp
+
+    def cross_qk(self, row: int, layers: Sequence[int], heads: Sequence[int], tok_begin: int, n_tok: int) -> torch.Tensor:
+        n = len(layers)
+        out = torch.empty(n, n_tok, self.model.dims.n_audio_ctx, dtype=torch.float32, device=self.model.device)
+        la = (C.c_int32 * n)(*[int(x) for x in layers])
+        ha = (C.c_int32 * n)(*[int(x) for x in heads])
+        cur = self._enter()
+        check(lib().wh_task_cross_qk(self.handle, row, la, ha, n, tok_begin, n_tok, out.data_ptr(),
+                                     stream_ptr(self.stream)), "wh_task_cross_qk")
+        cur.wait_stream(self.stream)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# stand-alone kernels
+# ---------------------------------------------------------------------------------------------------
+def log_mel(audio: torch.Tensor, filters: torch.Tensor) -> torch.Tensor:
+    """audio fp32 [n] or [B][n] on the GPU (already padded); filters fp32 [n_mels][201]."""
+    require_gpu(audio.device)
+    single = audio.dim() == 1
+    a = (audio[None] if single else audio).contiguous().float()
+    B, n = a.shape
+    n_mels = filters.shape[0]
+    out = torch.empty(B, n_mels, n // 160, dtype=torch.float32, device=a.device)
+    scratch = torch.empty(MEL_SCRATCH_BYTES, dtype=torch.uint8, device=a.device)
+    s = torch.cuda.current_stream(a.device)
+    check(lib().wh_log_mel(a.data_ptr(), n, B, n_mels, filters.data_ptr(), out.data_ptr(), scratch.data_ptr(),
+                           stream_ptr(s)), "wh_log_mel")
+    return out[0] if single else out
+
+
+def median_filter(x: torch.Tensor, width: int) -> torch.Tensor:
+    require_gpu(x.device)
+    xc = x.contiguous().float()
+    n = xc.shape[-1]
+    rows = xc.numel() // n if n > 0 else 0
+    out = torch.empty_like(xc)
+    s = torch.cuda.current_stream(x.device)
+    check(lib().wh_median_filter(xc.data_ptr(), out.data_ptr(), rows, n, width, stream_ptr(s)), "wh_median_filter")
+    return out
+
+
+def dtw_trace(x: torch.Tensor) -> torch.Tensor:
+    """x fp32 [N][M] cost matrix on the GPU -> int8 trace [N+1][M+1] (dtw_cpu codes)."""
+    require_gpu(x.device)
+    xc = x.contiguous().float()
+    N, M = xc.shape
+    trace = torch.empty(N + 1, M + 1, dtype=torch.int8, device=x.device)
+    s = torch.cuda.current_stream(x.device)
+    check(lib().wh_dtw_trace(xc.data_ptr(), N, M, trace.data_ptr(), stream_ptr(s)), "wh_dtw_trace")
+    return trace
