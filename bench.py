@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""bench.py — audio-seconds transcribed per wall-second on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the whole hot path over one batch of synthetic 30 s clips per GPU:
+log-mel (HIP) -> AudioEncoder (MFMA) -> cross-KV -> greedy decode with the device-side sampling loop.
+Workload at N=1 = BASELINE.json configs[2]: large-v3 dims, batch = 8 x 30 s, greedy, fp16.  The step
+count is fixed: `sample_len` forced tokens per clip with EOT suppressed, so the work is
+identical run to run.  Inputs are resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, each rank decodes its own 8 clips (weak scaling, no collective in the step);
+rank 0 builds the packed weight blob and RCCL-broadcasts it over xGMI at load.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s float4-copy achievable)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--model", default="large-v3")
+    p.add_argument("--batch", type=int, default=8, help="30 s clips per GPU")
+    p.add_argument("--sample-len", type=int, default=224, help="forced decode steps per clip (n_text_ctx // 2)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--cpu-steps", type=int, default=12, help="decode steps timed on the CPU baseline")
+    return p.parse_args()
+
+
+def synth_audio(batch: int, rank: int, device) -> torch.Tensor:
+    """seeded noise + three tones so the mel is not flat; clip index = global clip id."""
+    n = 480000
+    t = np.arange(n) / 16000.0
+    clips = []
+    for b in range(batch):
+        rng = np.random.default_rng(rank * batch + b)
+        x = rng.standard_normal(n).astype(np.float32) * 0.05
+        for f, a in ((220.0 + 20 * b, 0.2), (1300.0, 0.1), (3100.0, 0.05)):
+            x += (a * np.sin(2 * np.pi * f * t)).astype(np.float32)
+        clips.append(x)
+    return torch.from_numpy(np.stack(clips)).to(device)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    else:
+        dist = None
+
+    from whisper_amd import hip
+    from whisper_amd.audio import log_mel_spectrogram
+    from whisper_amd.launcher import broadcast_weights
+    from whisper_amd.synthetic import dims_for, synthetic_state_dict
+    from whisper_amd.tokenizer import get_tokenizer
+
+    dims = dims_for(args.model)
+    dtype = hip.WH_F16
+    # ---- weights: rank 0 packs, everyone else receives the blob over RCCL -----------------------
+    blob = None
+    if rank == 0:
+        sd = synthetic_state_dict(dims, seed=0, device=device)
+        blob = hip.pack_weights(sd, dims, dtype, device)
+        del sd
+        torch.cuda.empty_cache()
+    blob = broadcast_weights(blob, dims, dtype, device, dist)
+    model = hip.HipModel(dims, dtype, blob)
+
+    B, N = args.batch, args.sample_len
+    multilingual = dims.n_vocab >= 51865
+    tok = get_tokenizer(multilingual, num_languages=dims.n_vocab - 51765 - int(multilingual), language="en",
+                        task="transcribe")
+    init = list(tok.sot_sequence)
+    T0 = len(init)
+    suppress = sorted(set(list(tok.non_speech_tokens) + [tok.transcribe, tok.translate, tok.sot, tok.sot_prev,
+                                                         tok.sot_lm, tok.no_speech, tok.eot]))   # + EOT: fixed N
+    mask = torch.zeros(dims.n_vocab, dtype=torch.uint8)
+    mask[suppress] = 1
+    mask = mask.to(device)
+    params = hip.GreedyParams(sample_begin=T0, max_steps=N, n_ctx=dims.n_text_ctx, eot=tok.eot,
+                              timestamp_begin=tok.timestamp_begin, no_timestamps=tok.no_timestamps,
+                              max_initial_timestamp_index=50, suppress_blank=1,
+                              blank_token=tok.encode(" ")[0], suppress_mask=mask.data_ptr())
+
+    audio = synth_audio(B, rank, device)
+    task = hip.HipTask(model, B, 1, max(T0, 8))
+    tokens = torch.zeros(B, T0 + N + 1, dtype=torch.int64, device=device)
+
+    def one_pass():
+        mel = log_mel_spectrogram(audio, dims.n_mels)            # (B, n_mels, 3000) fp32 on device
+        feats = model.encode(mel)
+        task.reset()
+        task.set_audio(feats)
+        tokens.zero_()
+        tokens[:, :T0] = torch.tensor(init, device=device)
+        n, sum_lp, nsp = task.greedy(tokens, params, tok.sot_sequence.index(tok.sot), tok.no_speech)
+        return n
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        n_tok = one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_tok = one_pass()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert n_tok == T0 + N, (n_tok, T0, N)
+    ms_per_step = elapsed / args.steps * 1e3
+    audio_s = 30.0 * B * world * args.steps
+    value = audio_s / elapsed
+
+    out = {
+        "metric": "audio-seconds transcribed per wall-second (large-v3 greedy)",
+        "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"{args.model} dims (random-init weights), {B} x 30 s synthetic clips per GPU, "
+                               f"greedy, fp16 weights/KV + fp32 accumulate, {N} forced decode steps per clip "
+                               f"(EOT suppressed), log-mel + encoder + cross-KV + decode timed",
+                   "clips_per_gpu": B, "sample_len": N, "parallelism": f"dp{world} (clips sharded, no step collective)"},
+    }
+
+    # ---- roofline of the dominant kernels: HIP events on the launch stream, layer-rotated (HBM-cold) ----
+    if rank == 0 and not args.no_roofline:
+        kinds = {"decode_step": 0, "attn_decode_cross": 1, "gemv_qkv": 3, "gemv_fc1": 4, "gemv_fc2": 5,
+                 "gemv_logits": 6, "gemv_out": 7}
+        kern = {}
+        for name, kind in kinds.items():
+            ms, nbytes = task.bench_kernel(kind, 64 if kind else 16)
+            kern[name] = {"avg_us": round(ms * 1e3, 2), "bytes": nbytes, "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1)}
+        dom = kern["attn_decode_cross"]
+        out["roofline"] = {"bound": "hbm", "kernel": "attn_decode_kernel<half> (cross-attention KV stream)",
+                           "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                           "bytes_per_launch": dom["bytes"], "avg_us": dom["avg_us"], "all_kernels": kern}
+    task.close()
+
+    # ---- CPU baseline: the oracle (fp32 torch-CPU restatement of the reference) on this box's host cores ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, dims, init, suppress, tok, audio[:1].cpu().numpy())
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, dims, init, suppress, tok, audio_np):
+    """Oracle = "port": same algorithm as the reference's CPU fp32 path.  Bounded sample: 1 clip, log-mel +
+    encoder + `cpu_steps` decode steps; audio-s/s extrapolated linearly to `sample_len` steps."""
+    import oracle
+    from whisper_amd.synthetic import synthetic_state_dict
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synthetic_state_dict(dims, seed=0, device="cpu")
+    om = oracle.OracleModel(dims, sd)
+    filt = oracle.mel_filterbank(dims.n_mels)
+    t0 = time.perf_counter()
+    mel = oracle.log_mel_spectrogram(audio_np[0], filt)
+    t_mel = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        feats = om.encoder(mel[None])
+    t_enc = time.perf_counter() - t0
+    rules = oracle.SamplingRules(sample_begin=len(init), sot_index=0, eot=tok.eot, n_ctx=dims.n_text_ctx,
+                                 timestamp_begin=tok.timestamp_begin, no_timestamps=tok.no_timestamps,
+                                 suppress_tokens=suppress, blank_token=tok.encode(" ")[0], no_speech=tok.no_speech)
+    k = args.cpu_steps
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        oracle.greedy_decode(om, feats, init, k, rules)
+    t_dec = time.perf_counter() - t0
+    per_step = t_dec / k
+    total = t_mel + t_enc + per_step * args.sample_len
+    return {"value": round(30.0 / total, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"1 clip of the same workload: log-mel {t_mel:.2f}s + encoder {t_enc:.2f}s + {k} decode steps "
+                      f"at {per_step * 1e3:.0f} ms/step, extrapolated to {args.sample_len} steps (fp32, torch CPU, "
+                      f"{cores} threads)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -336,7 +336,6 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
   t->m = m; t->B = n_audio; t->G = n_group; t->R = n_audio * n_group; t->Tmax = max_prefill_tokens; t->flags = flags;
   task_carve(t, workspace);
   if (t->total > workspace_bytes) { delete t; return WH_ERR_WORKSPACE; }
-  if (m->dtype == WH_F32 && t->R > 16 * 65535) { delete t; return WH_ERR_LIMIT; }
   t->cross_splits = pick_splits(t->R, m->d.n_text_head);
   hipError_t e = hipMemset(t->d_pos, 0, 4);
   if (e != hipSuccess) { g_last_hip = e; delete t; return WH_ERR_HIP; }
@@ -676,6 +675,91 @@ extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* to
   int final_len = alive + 2;
   if (final_len > ntok) final_len = ntok;
   *n_tokens_out = final_len;
+  return WH_OK;
+}
+
+// ---- measurement hook ----------------------------------------------------------------------------------
+extern "C" int wh_task_bench_kernel(wh_task* t, int kind, int iters, double* bytes_per_launch, void* stream_) {
+  if (!t || iters <= 0) return WH_ERR_ARG;
+  if (!t->audio_set || t->pos <= 0) return WH_ERR_STATE;
+  hipStream_t s = (hipStream_t)stream_;
+  const wh_model* m = t->m;
+  const wh_dims& d = m->d;
+  const int D = d.n_text_state, H = d.n_text_head, C = d.n_text_ctx, Ta = d.n_audio_ctx, V = d.n_vocab;
+  const int R = t->R, Ln = d.n_text_layer;
+  const double es = m->esize;
+  double bytes = 0;
+  for (int i = 0; i < iters; ++i) {
+    const int l = i % Ln;
+    const wh_layer_weights& L = m->dec[l];
+    GemvArgs g; memset(&g, 0, sizeof(g));
+    switch (kind) {
+      case 0: {
+        int rc = step_launch(t, s);
+        if (rc != WH_OK) return rc;
+        HIPCHK(launch_add_int(t->d_pos, -1, s));   // stay at the same position
+        bytes = es * ((double)Ln * 14.0 * D * D + (double)V * D) + (double)t->B * Ln * 2.0 * Ta * D * es +
+                (double)R * (t->pos + 1) * Ln * 2.0 * D * es + (double)R * V * 4.0;
+      } break;
+      case 1: {
+        DecAttnArgs a; memset(&a, 0, sizeof(a));
+        a.q = t->qbuf; a.q_ld = D;
+        a.k = cross_layer(t, l); a.k_ld = 2 * D; a.k_bs = (int64_t)Ta * 2 * D;
+        a.v = (char*)cross_layer(t, l) + (size_t)D * m->esize; a.v_ld = 2 * D; a.v_bs = a.k_bs;
+        a.H = H; a.R = R; a.kv_group = t->G; a.Tk = Ta; a.splits = t->cross_splits;
+        a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
+        HIPCHK(launch_attn_decode(a, m->dtype, s));
+        bytes = (double)t->B * 2.0 * Ta * D * es;
+      } break;
+      case 2: {
+        DecAttnArgs a; memset(&a, 0, sizeof(a));
+        a.q = t->qbuf; a.q_ld = D;
+        a.k = self_k_layer(t, l); a.k_ld = D; a.k_bs = (int64_t)C * D;
+        a.v = self_v_layer(t, l); a.v_ld = D; a.v_bs = (int64_t)C * D;
+        a.H = H; a.R = R; a.kv_group = 1; a.d_len = t->d_pos; a.len_plus = 0; a.splits = 1;
+        a.out = t->att; a.o_ld = D;
+        HIPCHK(launch_attn_decode(a, m->dtype, s));
+        bytes = (double)R * t->pos * 2.0 * D * es;
+      } break;
+      case 3:
+        g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.attn_ln_w; g.ln_b = L.attn_ln_b;
+        g.W = L.qkv_w; g.bias = L.qkv_b; g.N = 3 * D; g.K = D; g.R = R;
+        g.epi = EPI_STORE; g.y = t->qkv; g.y_ld = 3 * D;
+        HIPCHK(launch_gemv(g, m->dtype, s));
+        bytes = 3.0 * D * D * es;
+        break;
+      case 4:
+        g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.mlp_ln_w; g.ln_b = L.mlp_ln_b;
+        g.W = L.fc1_w; g.bias = L.fc1_b; g.N = 4 * D; g.K = D; g.R = R;
+        g.epi = EPI_GELU; g.y = t->h; g.y_ld = 4 * D;
+        HIPCHK(launch_gemv(g, m->dtype, s));
+        bytes = 4.0 * D * D * es;
+        break;
+      case 5:
+        g.pro = PRO_PLAIN; g.x = t->h; g.x_ld = 4 * D;
+        g.W = L.fc2_w; g.bias = L.fc2_b; g.N = D; g.K = 4 * D; g.R = R;
+        g.epi = EPI_STORE; g.y = t->att; g.y_ld = D;
+        HIPCHK(launch_gemv(g, m->dtype, s));
+        bytes = 4.0 * D * D * es;
+        break;
+      case 6:
+        g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = m->w.dec_ln_w; g.ln_b = m->w.dec_ln_b;
+        g.W = m->w.tok_emb; g.N = V; g.K = D; g.R = R;
+        g.epi = EPI_F32; g.y = t->logits; g.y_ld = V;
+        HIPCHK(launch_gemv(g, m->dtype, s));
+        bytes = (double)V * D * es + (double)R * V * 4.0;
+        break;
+      case 7:
+        g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D;
+        g.W = L.out_w; g.bias = L.out_b; g.N = D; g.K = D; g.R = R;
+        g.epi = EPI_STORE; g.y = t->qbuf; g.y_ld = D;
+        HIPCHK(launch_gemv(g, m->dtype, s));
+        bytes = 1.0 * D * D * es;
+        break;
+      default: return WH_ERR_ARG;
+    }
+  }
+  if (bytes_per_launch) *bytes_per_launch = bytes;
   return WH_OK;
 }
 

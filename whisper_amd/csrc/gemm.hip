@@ -191,8 +191,8 @@ hipError_t launch_t(const whk::GemmArgs& a, int batch, hipStream_t stream) {
   p.tiles_n = (p.N + BN - 1) / BN;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              2 * STAGE_BYTES);
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);

@@ -86,6 +86,7 @@ SIGNATURES = {
                                  C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "wh_task_cross_qk": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "wh_task_bench_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
     "wh_median_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "wh_dtw_trace": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
@@ -421,6 +422,18 @@ class HipTask:
                                    stream_ptr(self.stream)), "wh_task_greedy")
         cur.wait_stream(self.stream)
         return n_out.value, sum_lp, nsp
+
+    def bench_kernel(self, kind: int, iters: int) -> Tuple[float, float]:
+        """(average ms per launch measured with HIP events on the launch stream, algorithmic bytes per launch)"""
+        nbytes = C.c_double(0.0)
+        st = self.stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        check(lib().wh_task_bench_kernel(self.handle, kind, 3, C.byref(nbytes), stream_ptr(st)), "bench warmup")
+        e0.record(st)
+        check(lib().wh_task_bench_kernel(self.handle, kind, iters, C.byref(nbytes), stream_ptr(st)), "bench")
+        e1.record(st)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / iters, nbytes.value
 
     def cross_qk(self, row: int, layers: Sequence[int], heads: Sequence[int], tok_begin: int, n_tok: int) -> torch.Tensor:
         n = len(layers)
