@@ -199,6 +199,13 @@ int wh_median_filter(const float *x, float *out, int64_t rows, int n, int width,
  * and dtw_cpu's tie rule (timing.py:95-100); row 0 / column 0 hold the codes backtrace() forces there
  * (timing.py:61-62).  N <= 8192. */
 int wh_dtw_trace(const float *x, int N, int M, int8_t *trace_out, void *stream);
+/* find_alignment's attention post-processing — whisper/timing.py:207-216: qk fp32 [n_heads][n_tok][n_audio_ctx]
+ * (from wh_task_cross_qk) -> crop to the first n_frames frames, softmax(qk * qk_scale) over frames, z-normalise
+ * over the token axis (biased std), median filter of odd `width` along frames, mean over heads, keep token rows
+ * [row_begin, row_end) and negate -> out fp32 [row_end-row_begin][n_frames], the cost matrix handed to dtw.
+ * scratch: >= 2*n_heads*n_tok*n_frames*4 bytes. */
+int wh_align_matrix(const float *qk, int n_heads, int n_tok, int n_audio_ctx, int n_frames, int width,
+                    int row_begin, int row_end, float qk_scale, float *out, void *scratch, void *stream);
 
 #ifdef __cplusplus
 }

@@ -86,3 +86,42 @@ def backtrace(trace: np.ndarray) -> np.ndarray:
 def dtw_path(x: np.ndarray) -> np.ndarray:
     """timing.py:141-151 (CPU branch): (2, path_len) int array of (text_index, time_index)."""
     return backtrace(dtw_trace(x))
+
+
+def alignment_matrix(model, tokens, feats, num_frames: int, heads, n_sot: int, medfilt_width: int = 7,
+                     qk_scale: float = 1.0):
+    """whisper/timing.py:186-216 on the oracle model: teacher-forced pass keeping cross-attention QK of every
+    layer, stack the alignment heads, crop to num_frames//2, softmax over frames, z-normalise over tokens
+    (biased std), median filter, mean over heads, drop the sot rows and the last row.
+    Returns (matrix [n_text+1, frames] float32, logits [T, V])."""
+    import torch
+    toks = torch.as_tensor(tokens, dtype=torch.int64)[None]
+    logits = model.decoder(toks, feats, None, keep_qk=True)[0]
+    qks = model.last_qk                                   # per layer (1, H, T, 1500)
+    w = torch.stack([qks[l][0, h] for l, h in heads])     # (n_heads, T, 1500)
+    w = w[:, :, : num_frames // 2]
+    w = (w * qk_scale).softmax(dim=-1)
+    std, mean = torch.std_mean(w, dim=-2, keepdim=True, unbiased=False)
+    w = (w - mean) / std
+    w = torch.from_numpy(median_filter(w.numpy(), medfilt_width))
+    matrix = w.mean(axis=0)[n_sot:-1]
+    return matrix.numpy().astype(np.float32), logits
+
+
+def word_times(model, tokenizer, text_tokens, feats, num_frames: int, heads, medfilt_width: int = 7):
+    """whisper/timing.py:163-242 end to end: returns (starts, ends, probabilities) per word."""
+    import torch
+    n_sot = len(tokenizer.sot_sequence)
+    tokens = [*tokenizer.sot_sequence, tokenizer.no_timestamps, *text_tokens, tokenizer.eot]
+    matrix, logits = alignment_matrix(model, tokens, feats, num_frames, heads, n_sot, medfilt_width)
+    probs = logits[n_sot:, : tokenizer.eot].softmax(dim=-1)
+    tprobs = probs[np.arange(len(text_tokens)), text_tokens].tolist()
+    text_idx, time_idx = dtw_path(-matrix)
+    words, word_tokens = tokenizer.split_to_word_tokens(list(text_tokens) + [tokenizer.eot])
+    if len(word_tokens) <= 1:
+        return np.array([]), np.array([]), np.array([])
+    bounds = np.pad(np.cumsum([len(t) for t in word_tokens[:-1]]), (1, 0))
+    jumps = np.pad(np.diff(text_idx), (1, 0), constant_values=1).astype(bool)
+    jump_times = time_idx[jumps] / 50.0                   # TOKENS_PER_SECOND (audio.py:22)
+    return (jump_times[bounds[:-1]], jump_times[bounds[1:]],
+            np.array([np.mean(tprobs[i:j]) for i, j in zip(bounds[:-1], bounds[1:])]))

@@ -1,0 +1,243 @@
+"""Host-side mirror (whisper_amd.decoding / tokenizer / audio / transcribe) against the LIVE reference, on CPU.
+The device kernels are not involved: the logit filters and token decoders are plain torch code that also runs
+on CPU tensors, `transcribe` is driven by a scripted fake model.  Needs /root/reference (marker `reference`)."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REFERENCE, SHIMS
+
+pytestmark = pytest.mark.reference
+
+
+@pytest.fixture(scope="module")
+def ref():
+    for p in (SHIMS, REFERENCE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import whisper
+    import whisper.decoding
+    import whisper.timing
+    import whisper.tokenizer
+    return whisper
+
+
+def test_tokenizer_equivalence(ref):
+    from whisper_amd.tokenizer import get_tokenizer
+    for ml, nl in ((False, 99), (True, 99), (True, 100)):
+        a = get_tokenizer(ml, num_languages=nl, language="en" if ml else None, task="transcribe" if ml else None)
+        b = ref.tokenizer.get_tokenizer(ml, num_languages=nl, language="en" if ml else None,
+                                        task="transcribe" if ml else None)
+        assert a.special_tokens == b.special_tokens
+        assert a.sot_sequence == b.sot_sequence and a.non_speech_tokens == b.non_speech_tokens
+        assert sorted(a.all_language_tokens) == sorted(b.all_language_tokens)
+        for text in ["Hello world, this is Whisper!", " ♪♪ [MUSIC] (laughs)", "다람쥐 헌 쳇바퀴에 타고파", "naïve café — 12,345.67"]:
+            assert a.encode(text) == b.encode(text)
+            assert a.decode(a.encode(text)) == text
+        toks = a.encode(" hello world this is a test") + [a.eot]
+        assert a.split_to_word_tokens(toks) == b.split_to_word_tokens(toks)
+
+
+def test_known_bpe_ids():
+    """known GPT-2 ids and the reference's golden split (tests/test_tokenizer.py:27-34): pins the BPE itself"""
+    from whisper_amd.tokenizer import get_tokenizer
+    g = get_tokenizer(False)
+    assert g.encode("hello world") == [31373, 995] and g.encode("Hello world") == [15496, 995]
+    m = get_tokenizer(True)
+    words, toks = m.split_tokens_on_unicode([8404, 871, 287, 6, 246, 526, 3210, 20378])
+    assert words == [" elle", " est", " l", "'", "�", "é", "rit", "oire"]
+    assert toks == [[8404], [871], [287], [6], [246], [526], [3210], [20378]]
+
+
+def test_pad_or_trim_and_filters(ref):
+    from whisper_amd import audio
+    x = np.random.default_rng(0).standard_normal((3, 1000)).astype(np.float32)
+    for n in (500, 1000, 1500):
+        assert np.array_equal(audio.pad_or_trim(x, n), ref.pad_or_trim(x, n))
+        assert torch.equal(audio.pad_or_trim(torch.from_numpy(x), n), ref.pad_or_trim(torch.from_numpy(x), n))
+        assert torch.equal(audio.pad_or_trim(torch.from_numpy(x), n, axis=0), ref.pad_or_trim(torch.from_numpy(x), n, axis=0))
+    for n in (80, 128):
+        assert (audio.mel_filters("cpu", n) - ref.audio.mel_filters("cpu", n)).abs().max() < 1e-8
+
+
+def _tok(ref_mod, multilingual=True):
+    from whisper_amd.tokenizer import get_tokenizer
+    return (get_tokenizer(multilingual, num_languages=100 if multilingual else 99, language="en" if multilingual else None,
+                          task="transcribe" if multilingual else None),
+            ref_mod.tokenizer.get_tokenizer(multilingual, num_languages=100 if multilingual else 99,
+                                            language="en" if multilingual else None,
+                                            task="transcribe" if multilingual else None))
+
+
+def test_logit_filters_match_reference(ref):
+    """vectorised filters == the reference's row loops (decoding.py:423-505), bit for bit, over crafted histories"""
+    from whisper_amd import decoding as mine
+    tk, rtk = _tok(ref)
+    TB, V = tk.timestamp_begin, 51866
+    g = torch.Generator().manual_seed(0)
+    sb = 3
+    histories = [
+        [], [TB + 5], [TB + 5, 400], [TB + 5, 400, TB + 30], [TB + 5, 400, TB + 30, TB + 30],
+        [TB + 5, 400, TB + 30, TB + 30, 900], [400, 401], [400, TB + 7], [TB + 1, TB + 1],
+    ]
+    for hist in histories:
+        R = 4
+        tokens = torch.tensor([[50258, 50259, 50360] + hist] * R)
+        # make rows differ in their last token where possible
+        if len(hist) >= 1:
+            tokens[1, -1] = 777
+            tokens[2, -1] = TB + 100
+        logits = torch.randn(R, V, generator=g) * 3
+        logits[3, TB:] += 8.0          # one row where timestamp mass dominates
+        a, b = logits.clone(), logits.clone()
+        for f in (mine.SuppressBlank(tk, sb), mine.SuppressTokens([1, 5, 9, tk.no_speech]),
+                  mine.ApplyTimestampRules(tk, sb, 50)):
+            f.apply(a, tokens)
+        for f in (ref.decoding.SuppressBlank(rtk, sb), ref.decoding.SuppressTokens([1, 5, 9, rtk.no_speech]),
+                  ref.decoding.ApplyTimestampRules(rtk, sb, 50)):
+            f.apply(b, tokens)
+        assert torch.equal(a, b), hist
+
+
+class _NullInference:
+    def __init__(self):
+        self.calls = []
+
+    def rearrange_kv_cache(self, idx):
+        self.calls.append(list(idx))
+
+
+def test_token_decoders_match_reference(ref):
+    from whisper_amd import decoding as mine
+    g = torch.Generator().manual_seed(1)
+    eot, V = 50257, 51866
+    # greedy
+    tokens = torch.randint(0, 50000, (5, 6), generator=g)
+    tokens[2, -1] = eot
+    logits = torch.randn(5, V, generator=g)
+    sa, sb_ = torch.zeros(5), torch.zeros(5)
+    ta, ca = mine.GreedyDecoder(0.0, eot).update(tokens.clone(), logits.clone(), sa)
+    tb, cb = ref.decoding.GreedyDecoder(0.0, eot).update(tokens.clone(), logits.clone(), sb_)
+    assert torch.equal(ta, tb) and bool(ca) == bool(cb) and torch.equal(sa, sb_)
+    # beam search: several steps with EOT made attractive at times, n_audio = 2
+    G_, n_audio = 3, 2
+    ia, ib = _NullInference(), _NullInference()
+    da = mine.BeamSearchDecoder(G_, eot, ia, patience=2.0)
+    db = ref.decoding.BeamSearchDecoder(G_, eot, ib, patience=2.0)
+    da.reset(); db.reset()
+    ta = tb = torch.randint(0, 50000, (n_audio * G_, 4), generator=g)
+    sa, sb_ = torch.zeros(n_audio * G_), torch.zeros(n_audio * G_)
+    for step in range(6):
+        logits = torch.randn(n_audio * G_, V, generator=g) * 2
+        if step in (2, 4):
+            logits[:, eot] += 9.0
+        if step == 3:
+            logits[1] = logits[0]          # duplicate candidates across beams
+            ta[1] = ta[0]; tb[1] = tb[0]
+        ta, ca = da.update(ta, logits.clone(), sa)
+        tb, cb = db.update(tb, logits.clone(), sb_)
+        assert torch.equal(ta, tb) and ca == cb and torch.equal(sa, sb_) and ia.calls == ib.calls
+    fa = da.finalize(ta.reshape(n_audio, G_, -1), sa.reshape(n_audio, G_))
+    fb = db.finalize(tb.reshape(n_audio, G_, -1), sb_.reshape(n_audio, G_))
+    assert [[t.tolist() for t in s] for s in fa[0]] == [[t.tolist() for t in s] for s in fb[0]]
+    assert fa[1] == fb[1]
+    ra = mine.MaximumLikelihoodRanker(None).rank(fa[0], fa[1])
+    rb = ref.decoding.MaximumLikelihoodRanker(None).rank(fb[0], fb[1])
+    assert [int(x) for x in ra] == [int(x) for x in rb]
+    ra = mine.MaximumLikelihoodRanker(0.6).rank(fa[0], fa[1])
+    rb = ref.decoding.MaximumLikelihoodRanker(0.6).rank(fb[0], fb[1])
+    assert [int(x) for x in ra] == [int(x) for x in rb]
+
+
+def _fake_model(multilingual=True):
+    dims = SimpleNamespace(n_mels=80, n_audio_ctx=1500, n_audio_state=384, n_audio_head=6, n_audio_layer=2,
+                           n_vocab=51865 if multilingual else 51864, n_text_ctx=448, n_text_state=384,
+                           n_text_head=6, n_text_layer=2)
+    return SimpleNamespace(dims=dims, is_multilingual=multilingual, device=torch.device("cpu"),
+                           num_languages=dims.n_vocab - 51765 - int(multilingual),
+                           decoder=SimpleNamespace(blocks=[]))      # the reference's PyTorchInference walks .blocks
+
+
+def test_task_setup_matches_reference(ref):
+    """initial tokens, sot_index, suppress list, option validation (decoding.py:514-642)"""
+    from whisper_amd import decoding as mine
+    for ml in (True, False):
+        model = _fake_model(ml)
+        for kw in (dict(), dict(without_timestamps=True), dict(prompt="some previous text", prefix=" and a prefix"),
+                   dict(prompt=list(range(1000, 1300)), sample_len=30), dict(suppress_tokens="-1,7,11"),
+                   dict(suppress_tokens=[3, 4]), dict(suppress_tokens=""), dict(max_initial_timestamp=None),
+                   dict(suppress_blank=False, beam_size=4, patience=1.5), dict(temperature=0.7, best_of=3)):
+            a = mine.DecodingTask(model, mine.DecodingOptions(language="en", **kw))
+            b = ref.decoding.DecodingTask(model, ref.DecodingOptions(language="en", **kw))
+            assert a.initial_tokens == b.initial_tokens and a.sot_index == b.sot_index
+            assert a.sample_begin == b.sample_begin and a.sample_len == b.sample_len and a.n_group == b.n_group
+            assert [type(f).__name__ for f in a.logit_filters] == [type(f).__name__ for f in b.logit_filters]
+            if kw.get("suppress_tokens", "-1"):
+                assert a._get_suppress_tokens() == b._get_suppress_tokens()
+        for bad in (dict(beam_size=2, best_of=2), dict(best_of=2), dict(patience=1.0), dict(length_penalty=1.5)):
+            with pytest.raises(ValueError):
+                mine.DecodingTask(model, mine.DecodingOptions(**bad))
+            with pytest.raises(ValueError):
+                ref.decoding.DecodingTask(model, ref.DecodingOptions(**bad))
+
+
+class _ScriptedModel:
+    """stands in for a Whisper model inside transcribe(): `decode` returns scripted DecodingResults"""
+
+    def __init__(self, result_cls, tokenizer, scripts, multilingual=True):
+        fm = _fake_model(multilingual)
+        self.dims, self.is_multilingual, self.num_languages, self.device = fm.dims, fm.is_multilingual, fm.num_languages, fm.device
+        self.result_cls, self.tk, self.scripts, self.calls = result_cls, tokenizer, scripts, []
+
+    def decode(self, segment, options):
+        i = min(len(self.calls), len(self.scripts) - 1)
+        self.calls.append((tuple(segment.shape), options.temperature, tuple(options.prompt or ())))
+        spec = self.scripts[i]
+        toks = spec["tokens"]
+        text = self.tk.decode(toks).strip()
+        return self.result_cls(audio_features=torch.zeros(1), language="en", tokens=toks, text=text,
+                               avg_logprob=spec.get("avg_logprob", -0.3), no_speech_prob=spec.get("no_speech_prob", 0.01),
+                               temperature=options.temperature, compression_ratio=spec.get("compression_ratio", 1.2))
+
+
+def test_transcribe_seek_logic_matches_reference(ref, monkeypatch):
+    """the 30 s window state machine (transcribe.py:272-508): same scripted decoder outputs -> same segments,
+    same seek sequence, same prompts, same fallback behaviour"""
+    import oracle
+    import whisper_amd  # noqa: F401
+    mine_tr = sys.modules["whisper_amd.transcribe"]   # the package attribute of that name is the function
+    from whisper_amd import decoding as mine
+    tk, rtk = _tok(ref)
+    TB = tk.timestamp_begin
+    hello = tk.encode(" hello there")
+    world = tk.encode(" general kenobi")
+    scripts = [
+        {"tokens": [TB, *hello, TB + 200, TB + 200, *world, TB + 450, TB + 450, *hello]},          # pairs, unfinished tail
+        {"tokens": [TB, *world, TB + 300], "compression_ratio": 3.0},                                 # triggers fallback
+        {"tokens": [TB, *world, TB + 300]},                                                           # single ts ending
+        {"tokens": [*hello, *world], "no_speech_prob": 0.9, "avg_logprob": -2.0},                     # skipped: silence
+        {"tokens": [TB + 10, *hello, TB + 100, TB + 100, *hello, TB + 700, TB + 700]},                # consecutive end
+        {"tokens": [*hello]},                                                                          # no timestamps
+    ]
+    rng = np.random.default_rng(0)
+    audio = (rng.standard_normal(16000 * 100) * 0.01).astype(np.float32)
+    filt = oracle.mel_filterbank(80)
+
+    def cpu_mel(a, n_mels=80, padding=0, device=None):
+        return oracle.log_mel_spectrogram(a, filt, padding=padding)
+    monkeypatch.setattr(mine_tr, "log_mel_spectrogram", cpu_mel)
+
+    for kw in (dict(temperature=(0.0, 0.4)), dict(temperature=0.0, condition_on_previous_text=False),
+               dict(temperature=(0.0, 0.4), initial_prompt="Star Wars", carry_initial_prompt=True),
+               dict(temperature=0.0, clip_timestamps="5,40,55"), dict(temperature=0.0, no_speech_threshold=None)):
+        ma = _ScriptedModel(mine.DecodingResult, tk, scripts)
+        mb = _ScriptedModel(ref.DecodingResult, rtk, scripts)
+        ra = mine_tr.transcribe(ma, audio, language="en", fp16=False, **kw)
+        rb = ref.transcribe(mb, audio, language="en", fp16=False, **kw)
+        assert ma.calls == mb.calls
+        assert ra["text"] == rb["text"] and ra["language"] == rb["language"]
+        assert ra["segments"] == rb["segments"]

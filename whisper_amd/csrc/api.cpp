@@ -796,3 +796,13 @@ extern "C" int wh_dtw_trace(const float* x, int N, int M, int8_t* trace_out, voi
   HIPCHK(launch_dtw(x, N, M, trace_out, (hipStream_t)stream));
   return WH_OK;
 }
+
+extern "C" int wh_align_matrix(const float* qk, int n_heads, int n_tok, int n_audio_ctx, int n_frames, int width,
+                               int row_begin, int row_end, float qk_scale, float* out, void* scratch, void* stream) {
+  if (!qk || !out || !scratch || n_heads <= 0 || n_tok <= 0 || n_frames <= 0 || n_frames > n_audio_ctx) return WH_ERR_ARG;
+  if (row_begin < 0 || row_end > n_tok || row_end <= row_begin) return WH_ERR_ARG;
+  if (width <= 0 || (width & 1) == 0 || width > 63) return WH_ERR_ARG;
+  HIPCHK(launch_align_matrix(qk, n_heads, n_tok, n_audio_ctx, n_frames, width, row_begin, row_end, qk_scale, out,
+                             (float*)scratch, (hipStream_t)stream));
+  return WH_OK;
+}

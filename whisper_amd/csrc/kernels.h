@@ -123,5 +123,9 @@ hipError_t launch_gather_tokens(const int64_t* src, int64_t stride, int R, int64
 hipError_t launch_median_filter(const float* x, float* out, int64_t rows, int n, int width,
                                 hipStream_t stream);
 hipError_t launch_dtw(const float* x, int N, int M, int8_t* trace, hipStream_t stream);
+// qk [H][T][Tk] -> softmax over first F frames, z-norm over tokens, median(width), -mean over heads of rows
+// [row_begin,row_end) -> out [rows][F]; scratch: 2*H*T*F floats
+hipError_t launch_align_matrix(const float* qk, int H, int T, int Tk, int F, int width, int row_begin,
+                               int row_end, float qk_scale, float* out, float* scratch, hipStream_t stream);
 
 }  // namespace whk

@@ -102,9 +102,77 @@ __global__ __launch_bounds__(1024) void dtw_kernel(const float* __restrict__ x, 
   }
 }
 
+// ---- find_alignment post-processing (whisper/timing.py:207-216) ---------------------------------
+// qk [H][T][Tk] -> w [H][T][F]: softmax over the first F frames of (qk * qk_scale)   (timing.py:208-209)
+__global__ __launch_bounds__(256) void align_softmax_kernel(const float* __restrict__ qk, int T, int Tk, int F,
+                                                            float qk_scale, float* __restrict__ w) {
+  __shared__ float red[4];
+  const int t = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* src = qk + ((int64_t)h * T + t) * Tk;
+  float* dst = w + ((int64_t)h * T + t) * F;
+  float m = WH_NEG_INF;
+  for (int j = tid; j < F; j += 256) m = fmaxf(m, src[j] * qk_scale);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int j = tid; j < F; j += 256) {
+    const float e = expf(src[j] * qk_scale - m);
+    dst[j] = e;
+    s += e;
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int j = tid; j < F; j += 256) dst[j] = dst[j] / s;
+}
+
+// z-normalise every (head, frame) column over the token axis: std_mean(dim=-2, unbiased=False), timing.py:210-211
+__global__ void align_znorm_kernel(float* __restrict__ w, int T, int F) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, h = blockIdx.y;
+  if (j >= F) return;
+  float* col = w + (int64_t)h * T * F + j;
+  float mean = 0.f;
+  for (int t = 0; t < T; ++t) mean += col[(int64_t)t * F];
+  mean /= (float)T;
+  float var = 0.f;
+  for (int t = 0; t < T; ++t) { const float d = col[(int64_t)t * F] - mean; var = __builtin_fmaf(d, d, var); }
+  const float sd = sqrtf(var / (float)T);
+  for (int t = 0; t < T; ++t) col[(int64_t)t * F] = (col[(int64_t)t * F] - mean) / sd;
+}
+
+// out[t - row_begin][j] = -mean_h w[h][t][j]   (timing.py:214-216: mean over heads, row slice, negation for dtw)
+__global__ void align_head_mean_kernel(const float* __restrict__ w, int H, int T, int F, int row_begin, int rows,
+                                       float* __restrict__ out) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)rows * F) return;
+  const int r = (int)(gid / F), j = (int)(gid - (int64_t)r * F);
+  float s = 0.f;
+  for (int h = 0; h < H; ++h) s += w[((int64_t)h * T + row_begin + r) * F + j];
+  out[gid] = -(s / (float)H);
+}
+
 }  // namespace
 
 namespace whk {
+
+hipError_t launch_align_matrix(const float* qk, int H, int T, int Tk, int F, int width, int row_begin,
+                               int row_end, float qk_scale, float* out, float* scratch, hipStream_t stream) {
+  float* w0 = scratch;
+  float* w1 = scratch + (size_t)H * T * F;
+  hipLaunchKernelGGL(align_softmax_kernel, dim3(T, H), dim3(256), 0, stream, qk, T, Tk, F, qk_scale, w0);
+  hipLaunchKernelGGL(align_znorm_kernel, dim3((F + 63) / 64, H), dim3(64), 0, stream, w0, T, F);
+  hipError_t e = launch_median_filter(w0, w1, (int64_t)H * T, F, width, stream);
+  if (e != hipSuccess) return e;
+  const int rows = row_end - row_begin;
+  const int64_t total = (int64_t)rows * F;
+  hipLaunchKernelGGL(align_head_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w1, H, T, F,
+                     row_begin, rows, out);
+  return hipGetLastError();
+}
 
 hipError_t launch_median_filter(const float* x, float* out, int64_t rows, int n, int width,
                                 hipStream_t stream) {

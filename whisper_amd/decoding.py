@@ -1,0 +1,618 @@
+"""Decoding of 30-second windows on the HIP path.
+
+Host-side mirror of the reference's `whisper/decoding.py`: the same public names (DecodingOptions,
+DecodingResult, Inference, TokenDecoder, LogitFilter, DecodingTask, decode, detect_language), the same option
+semantics and error behaviour, so code written against the reference runs unchanged.  What differs is where the
+work happens:
+
+* `HipInference` implements the `Inference` seam (reference decoding.py:130-141) on a `wh_task`: pre-allocated
+  self/cross KV caches, GEMM prefill, hipGraph-replayed single-token steps, in-place beam reordering.
+* the logit filters are vectorised over rows (no per-row `.tolist()` round trips, reference :458-505).
+* greedy decoding at temperature 0 with the stock filters runs as ONE C call (`wh_task_greedy`): the filters,
+  arg-max and log-prob accumulation are a device kernel (csrc/sampling.hip) and the host never syncs per token.
+* batched beam search works for n_audio > 1 (the reference raises there): cross-attention K/V
+  is indexed by row // beam_size inside the kernels.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, replace
+from typing import TYPE_CHECKING, Dict, Iterable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+from torch.distributions import Categorical
+
+from . import hip
+from .audio import CHUNK_LENGTH
+from .tokenizer import Tokenizer, get_tokenizer
+from .utils import compression_ratio
+
+if TYPE_CHECKING:
+    from .model import Whisper
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# language identification (reference decoding.py:18-77)
+# ---------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def detect_language(model: "Whisper", mel: Tensor, tokenizer: Tokenizer = None) -> Tuple[Tensor, List[dict]]:
+    """Most probable language token per audio and the probability of every language.  `mel` may be a
+    spectrogram (n_mels, 3000) / (B, n_mels, 3000) or already-encoded audio features."""
+    if tokenizer is None:
+        tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages)
+    if tokenizer.language is None or tokenizer.language_token not in tokenizer.sot_sequence:
+        raise ValueError("This model doesn't have language tokens so it can't perform lang id")
+
+    single = mel.ndim == 2
+    if single:
+        mel = mel.unsqueeze(0)
+    if mel.shape[-2:] != (model.dims.n_audio_ctx, model.dims.n_audio_state):
+        mel = model.encoder(mel)
+
+    n_audio = mel.shape[0]
+    x = torch.tensor([[tokenizer.sot]] * n_audio, device=mel.device)
+    logits = model.logits(x, mel)[:, 0]
+
+    keep = torch.zeros(logits.shape[-1], dtype=torch.bool, device=logits.device)
+    keep[list(tokenizer.all_language_tokens)] = True
+    logits = logits.masked_fill(~keep, -np.inf)
+    language_tokens = logits.argmax(dim=-1)
+    probs = logits.softmax(dim=-1).cpu()
+    language_probs = [
+        {c: probs[i, j].item() for j, c in zip(tokenizer.all_language_tokens, tokenizer.all_language_codes)}
+        for i in range(n_audio)
+    ]
+    if single:
+        language_tokens = language_tokens[0]
+        language_probs = language_probs[0]
+    return language_tokens, language_probs
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# options / results: field-for-field the reference's dataclasses (decoding.py:80-127)
+# ---------------------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class DecodingOptions:
+    task: str = "transcribe"                 # "transcribe" (X->X) or "translate" (X->English)
+    language: Optional[str] = None           # detected when None
+    temperature: float = 0.0
+    sample_len: Optional[int] = None         # max tokens to sample
+    best_of: Optional[int] = None            # independent samples when temperature > 0
+    beam_size: Optional[int] = None          # beams when temperature == 0
+    patience: Optional[float] = None         # beam-search patience (arxiv:2204.05424)
+    length_penalty: Optional[float] = None   # Google-NMT alpha, None = length normalisation
+    prompt: Optional[Union[str, List[int]]] = None   # previous context
+    prefix: Optional[Union[str, List[int]]] = None   # forced start of the current context
+    suppress_tokens: Optional[Union[str, Iterable[int]]] = "-1"   # "-1" = tokenizer.non_speech_tokens
+    suppress_blank: bool = True
+    without_timestamps: bool = False
+    max_initial_timestamp: Optional[float] = 1.0
+    fp16: bool = True
+
+
+@dataclass(frozen=True)
+class DecodingResult:
+    audio_features: Tensor
+    language: str
+    language_probs: Optional[Dict[str, float]] = None
+    tokens: List[int] = field(default_factory=list)
+    text: str = ""
+    avg_logprob: float = np.nan
+    no_speech_prob: float = np.nan
+    temperature: float = np.nan
+    compression_ratio: float = np.nan
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the Inference seam
+# ---------------------------------------------------------------------------------------------------------------
+class Inference:
+    def logits(self, tokens: Tensor, audio_features: Tensor) -> Tensor:
+        """Forward pass of the decoder: per-token logits"""
+        raise NotImplementedError
+
+    def rearrange_kv_cache(self, source_indices) -> None:
+        """Re-order the cached keys/values after the beams were re-ranked"""
+        raise NotImplementedError
+
+    def cleanup_caching(self) -> None:
+        """Release per-task state"""
+        pass
+
+
+class HipInference(Inference):
+    """`Inference` on a wh_task (C ABI).  Contract of reference decoding.py:155-176: the first `logits` call
+    sees all initial tokens and returns logits for them; later calls look at `tokens[:, -1]` only."""
+
+    def __init__(self, model: "Whisper", initial_token_length: int, n_group: int = 1, capture_q: bool = False):
+        self.model = model
+        self.initial_token_length = initial_token_length
+        self.n_group = n_group
+        self.capture_q = capture_q
+        self.task: Optional[hip.HipTask] = None
+        self.positions: Optional[List[int]] = None      # restrict first-call logits to these positions
+
+    def _ensure_task(self, tokens: Tensor, audio_features: Tensor) -> hip.HipTask:
+        if self.task is None:
+            engine = self.model.engine(audio_features.dtype)
+            n_rows = tokens.shape[0]
+            n_audio = audio_features.shape[0]
+            group = n_rows // n_audio if n_rows % n_audio == 0 and n_rows >= n_audio else None
+            if group is None:
+                raise ValueError(f"rows ({n_rows}) must be a multiple of audio segments ({n_audio})")
+            self.task = hip.HipTask(engine, n_audio, group, max(tokens.shape[1], 8), capture_q=self.capture_q)
+            self.task.set_audio(audio_features.contiguous())
+        return self.task
+
+    def logits(self, tokens: Tensor, audio_features: Tensor) -> Tensor:
+        task = self._ensure_task(tokens, audio_features)
+        if task.position == 0:
+            return task.prefill(tokens.contiguous(), sel=self.positions)
+        if tokens.shape[-1] > self.initial_token_length or task.position == tokens.shape[-1] - 1:
+            return task.step(tokens[:, -1])[:, None]
+        return task.prefill(tokens[:, task.position:].contiguous())
+
+    def rearrange_kv_cache(self, source_indices) -> None:
+        if self.task is not None:
+            self.task.rearrange([int(i) for i in source_indices])
+
+    def cleanup_caching(self) -> None:
+        if self.task is not None:
+            self.task.close()
+            self.task = None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ranking
+# ---------------------------------------------------------------------------------------------------------------
+class SequenceRanker:
+    def rank(self, tokens: List[List[Tensor]], sum_logprobs: List[List[float]]) -> List[int]:
+        """index of the chosen sample in every group"""
+        raise NotImplementedError
+
+
+class MaximumLikelihoodRanker(SequenceRanker):
+    """Highest log-probability after length normalisation (length_penalty None) or the Google-NMT penalty
+    ((5 + len) / 6) ** alpha (reference decoding.py:190-213)."""
+
+    def __init__(self, length_penalty: Optional[float]):
+        self.length_penalty = length_penalty
+
+    def rank(self, tokens: List[List[Tensor]], sum_logprobs: List[List[float]]):
+        picks = []
+        for group, logprobs in zip(tokens, sum_logprobs):
+            scores = []
+            for seq, lp in zip(group, logprobs):
+                n = len(seq)
+                penalty = n if self.length_penalty is None else ((5 + n) / 6) ** self.length_penalty
+                scores.append(lp / penalty)
+            picks.append(int(np.argmax(scores)))
+        return picks
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# token decoders
+# ---------------------------------------------------------------------------------------------------------------
+class TokenDecoder:
+    def reset(self):
+        """forget state from a previous sequence"""
+
+    def update(self, tokens: Tensor, logits: Tensor, sum_logprobs: Tensor) -> Tuple[Tensor, bool]:
+        """tokens (n_batch, len), logits (n_batch, vocab), sum_logprobs (n_batch) ->
+        (tokens with one more column, True when every sequence is finished)"""
+        raise NotImplementedError
+
+    def finalize(self, tokens: Tensor, sum_logprobs: Tensor) -> Tuple[Sequence[Sequence[Tensor]], List[List[float]]]:
+        """tokens (n_audio, n_group, len), sum_logprobs (n_audio, n_group) -> candidate sequences and their
+        cumulative log-probabilities per audio"""
+        raise NotImplementedError
+
+
+class GreedyDecoder(TokenDecoder):
+    """arg-max (temperature 0) or categorical sampling; rows that already produced EOT keep producing EOT and
+    stop accumulating log-probability (reference decoding.py:272-298)."""
+
+    def __init__(self, temperature: float, eot: int):
+        self.temperature = temperature
+        self.eot = eot
+
+    def update(self, tokens: Tensor, logits: Tensor, sum_logprobs: Tensor) -> Tuple[Tensor, bool]:
+        if self.temperature == 0:
+            picked = logits.argmax(dim=-1)
+        else:
+            picked = Categorical(logits=logits / self.temperature).sample()
+        logprobs = F.log_softmax(logits.float(), dim=-1)
+        chosen = logprobs.gather(1, picked[:, None])[:, 0]
+        ended = tokens[:, -1] == self.eot
+        sum_logprobs += chosen * (~ended)
+        picked = torch.where(ended, torch.full_like(picked, self.eot), picked)
+        tokens = torch.cat([tokens, picked[:, None]], dim=-1)
+        return tokens, bool((tokens[:, -1] == self.eot).all())
+
+    def finalize(self, tokens: Tensor, sum_logprobs: Tensor):
+        return F.pad(tokens, (0, 1), value=self.eot), sum_logprobs.tolist()   # at least one EOT per sequence
+
+
+class BeamSearchDecoder(TokenDecoder):
+    """Beam search with patience, same candidate bookkeeping as reference decoding.py:301-404 (candidate
+    sequences keyed by their token tuple, later duplicates overwrite, stable descending sort), but with one
+    device->host transfer per step instead of one per candidate."""
+
+    def __init__(self, beam_size: int, eot: int, inference: Inference, patience: Optional[float] = None):
+        self.beam_size = beam_size
+        self.eot = eot
+        self.inference = inference
+        self.patience = patience or 1.0
+        self.max_candidates: int = round(beam_size * self.patience)
+        self.finished_sequences = None
+        assert self.max_candidates > 0, f"Invalid beam size ({beam_size}) or patience ({patience})"
+
+    def reset(self):
+        self.finished_sequences = None
+
+    def update(self, tokens: Tensor, logits: Tensor, sum_logprobs: Tensor) -> Tuple[Tensor, bool]:
+        G = self.beam_size
+        if tokens.shape[0] % G != 0:
+            raise ValueError(f"{tokens.shape}[0] % {G} != 0")
+        n_audio = tokens.shape[0] // G
+        if self.finished_sequences is None:
+            self.finished_sequences = [{} for _ in range(n_audio)]
+
+        logprobs = F.log_softmax(logits.float(), dim=-1)
+        top_lp, top_tok = logprobs.topk(G + 1, dim=-1)
+        cand_scores = (sum_logprobs[:, None] + top_lp).cpu().tolist()     # fp32 sums, read back as Python floats
+        cand_tokens = top_tok.cpu().tolist()
+        prefixes = tokens.cpu().tolist()
+
+        next_tokens, source_indices, newly_finished, new_sums = [], [], [], []
+        for a in range(n_audio):
+            scores, sources = {}, {}
+            for j in range(G):
+                row = a * G + j
+                for s, t in zip(cand_scores[row], cand_tokens[row]):
+                    seq = tuple(prefixes[row] + [t])
+                    scores[seq] = s
+                    sources[seq] = row
+            finished, kept = {}, 0
+            for seq in sorted(scores, key=scores.get, reverse=True):
+                if seq[-1] == self.eot:
+                    finished[seq] = scores[seq]
+                else:
+                    new_sums.append(scores[seq])
+                    next_tokens.append(seq)
+                    source_indices.append(sources[seq])
+                    kept += 1
+                    if kept == G:
+                        break
+            newly_finished.append(finished)
+
+        sum_logprobs[: len(new_sums)] = torch.tensor(new_sums, dtype=sum_logprobs.dtype, device=sum_logprobs.device)
+        tokens = torch.tensor(next_tokens, device=tokens.device)
+        self.inference.rearrange_kv_cache(source_indices)
+
+        assert len(self.finished_sequences) == len(newly_finished)
+        for done, new in zip(self.finished_sequences, newly_finished):
+            for seq in sorted(new, key=new.get, reverse=True):
+                if len(done) >= self.max_candidates:
+                    break
+                done[seq] = new[seq]
+        completed = all(len(s) >= self.max_candidates for s in self.finished_sequences)
+        return tokens, completed
+
+    def finalize(self, preceding_tokens: Tensor, sum_logprobs: Tensor):
+        sum_logprobs = sum_logprobs.cpu()
+        for i, sequences in enumerate(self.finished_sequences):
+            if len(sequences) < self.beam_size:      # top up with the best unfinished beams
+                for j in list(np.argsort(sum_logprobs[i]))[::-1]:
+                    sequences[tuple(preceding_tokens[i, j].tolist() + [self.eot])] = sum_logprobs[i][j].item()
+                    if len(sequences) >= self.beam_size:
+                        break
+        tokens = [[torch.tensor(seq) for seq in s.keys()] for s in self.finished_sequences]
+        sums = [list(s.values()) for s in self.finished_sequences]
+        return tokens, sums
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# logit filters (vectorised over rows; semantics of reference decoding.py:407-505)
+# ---------------------------------------------------------------------------------------------------------------
+class LogitFilter:
+    def apply(self, logits: Tensor, tokens: Tensor) -> None:
+        """mask `logits` (n_batch, vocab) in place given the context `tokens` (n_batch, len)"""
+        raise NotImplementedError
+
+
+class SuppressBlank(LogitFilter):
+    def __init__(self, tokenizer: Tokenizer, sample_begin: int):
+        self.tokenizer = tokenizer
+        self.sample_begin = sample_begin
+
+    def apply(self, logits: Tensor, tokens: Tensor):
+        if tokens.shape[1] == self.sample_begin:
+            logits[:, self.tokenizer.encode(" ") + [self.tokenizer.eot]] = -np.inf
+
+
+class SuppressTokens(LogitFilter):
+    def __init__(self, suppress_tokens: Sequence[int]):
+        self.suppress_tokens = list(suppress_tokens)
+
+    def apply(self, logits: Tensor, tokens: Tensor):
+        logits[:, self.suppress_tokens] = -np.inf
+
+
+class ApplyTimestampRules(LogitFilter):
+    def __init__(self, tokenizer: Tokenizer, sample_begin: int, max_initial_timestamp_index: Optional[int]):
+        self.tokenizer = tokenizer
+        self.sample_begin = sample_begin
+        self.max_initial_timestamp_index = max_initial_timestamp_index
+
+    def apply(self, logits: Tensor, tokens: Tensor):
+        tk = self.tokenizer
+        TB, eot = tk.timestamp_begin, tk.eot
+        V = logits.shape[1]
+        if tk.no_timestamps is not None:
+            logits[:, tk.no_timestamps] = -np.inf
+
+        sampled = tokens[:, self.sample_begin:]
+        L = sampled.shape[1]
+        vocab = torch.arange(V, device=logits.device)[None, :]
+        if L >= 1:
+            is_ts = sampled >= TB
+            last_ts = is_ts[:, -1]
+            pen_ts = is_ts[:, -2] if L >= 2 else torch.ones_like(last_ts)
+            # timestamps come in pairs (except right before EOT)
+            banned = (last_ts & pen_ts)[:, None] & (vocab >= TB)
+            banned |= (last_ts & ~pen_ts)[:, None] & (vocab < eot)
+            # timestamps never decrease; a closed segment must have non-zero length
+            has_ts = is_ts.any(dim=1)
+            pos = (is_ts * torch.arange(1, L + 1, device=tokens.device)[None, :]).amax(dim=1) - 1
+            newest = sampled.gather(1, pos.clamp(min=0)[:, None])[:, 0]
+            floor = torch.where(last_ts & ~pen_ts, newest, newest + 1)
+            banned |= has_ts[:, None] & (vocab >= TB) & (vocab < floor[:, None])
+            logits.masked_fill_(banned, -np.inf)
+        else:
+            # first sampled token: must be a timestamp, and not later than max_initial_timestamp
+            logits[:, :TB] = -np.inf
+            if self.max_initial_timestamp_index is not None:
+                logits[:, TB + self.max_initial_timestamp_index + 1:] = -np.inf
+
+        # if the timestamps together are more probable than any single text token, force a timestamp
+        logprobs = F.log_softmax(logits.float(), dim=-1)
+        ts_mass = logprobs[:, TB:].logsumexp(dim=-1)
+        best_text = logprobs[:, :TB].max(dim=-1).values
+        logits[:, :TB] = logits[:, :TB].masked_fill((ts_mass > best_text)[:, None], -np.inf)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the task
+# ---------------------------------------------------------------------------------------------------------------
+class DecodingTask:
+    inference: Inference
+    sequence_ranker: SequenceRanker
+    decoder: TokenDecoder
+    logit_filters: List[LogitFilter]
+
+    def __init__(self, model: "Whisper", options: DecodingOptions):
+        self.model = model
+        tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages,
+                                  language=options.language or "en", task=options.task)
+        self.tokenizer: Tokenizer = tokenizer
+        self.options: DecodingOptions = self._verify_options(options)
+
+        self.n_group: int = options.beam_size or options.best_of or 1
+        self.n_ctx: int = model.dims.n_text_ctx
+        self.sample_len: int = options.sample_len or model.dims.n_text_ctx // 2
+
+        self.sot_sequence: Tuple[int] = tokenizer.sot_sequence
+        if self.options.without_timestamps:
+            self.sot_sequence = tokenizer.sot_sequence_including_notimestamps
+
+        self.initial_tokens: Tuple[int] = self._get_initial_tokens()
+        self.sample_begin: int = len(self.initial_tokens)
+        self.sot_index: int = self.initial_tokens.index(tokenizer.sot)
+
+        self.inference = HipInference(model, len(self.initial_tokens), self.n_group)
+        self.sequence_ranker = MaximumLikelihoodRanker(options.length_penalty)
+        if options.beam_size is not None:
+            self.decoder = BeamSearchDecoder(options.beam_size, tokenizer.eot, self.inference, options.patience)
+        else:
+            self.decoder = GreedyDecoder(options.temperature, tokenizer.eot)
+
+        self.logit_filters = []
+        self._suppress: Tuple[int, ...] = ()
+        self._max_initial_ts: Optional[int] = None
+        if self.options.suppress_blank:
+            self.logit_filters.append(SuppressBlank(self.tokenizer, self.sample_begin))
+        if self.options.suppress_tokens:
+            self._suppress = self._get_suppress_tokens()
+            self.logit_filters.append(SuppressTokens(self._suppress))
+        if not options.without_timestamps:
+            precision = CHUNK_LENGTH / model.dims.n_audio_ctx      # 0.02 s per timestamp token
+            if options.max_initial_timestamp:
+                self._max_initial_ts = round(self.options.max_initial_timestamp / precision)
+            self.logit_filters.append(ApplyTimestampRules(tokenizer, self.sample_begin, self._max_initial_ts))
+        self._stock_filters = list(self.logit_filters)
+
+    def _verify_options(self, options: DecodingOptions) -> DecodingOptions:
+        if options.beam_size is not None and options.best_of is not None:
+            raise ValueError("beam_size and best_of can't be given together")
+        if options.temperature == 0 and options.best_of is not None:
+            raise ValueError("best_of with greedy sampling (T=0) is not compatible")
+        if options.patience is not None and options.beam_size is None:
+            raise ValueError("patience requires beam_size to be given")
+        if options.length_penalty is not None and not (0 <= options.length_penalty <= 1):
+            raise ValueError("length_penalty (alpha) should be a value between 0 and 1")
+        return options
+
+    def _get_initial_tokens(self) -> Tuple[int]:
+        tokens = list(self.sot_sequence)
+        prefix = self.options.prefix
+        if prefix:
+            prefix_tokens = self.tokenizer.encode(" " + prefix.strip()) if isinstance(prefix, str) else prefix
+            if self.sample_len is not None:
+                prefix_tokens = prefix_tokens[-(self.n_ctx // 2 - self.sample_len):]
+            tokens = tokens + prefix_tokens
+        prompt = self.options.prompt
+        if prompt:
+            prompt_tokens = self.tokenizer.encode(" " + prompt.strip()) if isinstance(prompt, str) else prompt
+            tokens = [self.tokenizer.sot_prev] + prompt_tokens[-(self.n_ctx // 2 - 1):] + tokens
+        return tuple(tokens)
+
+    def _get_suppress_tokens(self) -> Tuple[int]:
+        suppress = self.options.suppress_tokens
+        if isinstance(suppress, str):
+            suppress = [int(t) for t in suppress.split(",")]
+        if -1 in suppress:
+            suppress = [t for t in suppress if t >= 0]
+            suppress.extend(self.tokenizer.non_speech_tokens)
+        elif suppress is None or len(suppress) == 0:
+            suppress = []
+        else:
+            assert isinstance(suppress, list), "suppress_tokens must be a list"
+        tk = self.tokenizer
+        suppress.extend([tk.transcribe, tk.translate, tk.sot, tk.sot_prev, tk.sot_lm])
+        if tk.no_speech is not None:
+            suppress.append(tk.no_speech)      # its probability is read separately
+        return tuple(sorted(set(suppress)))
+
+    def _get_audio_features(self, mel: Tensor):
+        if self.options.fp16:
+            mel = mel.half()
+        if mel.shape[-2:] == (self.model.dims.n_audio_ctx, self.model.dims.n_audio_state):
+            audio_features = mel               # already encoded
+        else:
+            audio_features = self.model.encoder(mel)
+        want = torch.float16 if self.options.fp16 else torch.float32
+        if audio_features.dtype != want:
+            raise TypeError(f"audio_features has an incorrect dtype: {audio_features.dtype}")
+        return audio_features
+
+    def _detect_language(self, audio_features: Tensor, tokens: Tensor):
+        languages = [self.options.language] * audio_features.shape[0]
+        lang_probs = None
+        if self.options.language is None or self.options.task == "lang_id":
+            lang_tokens, lang_probs = self.model.detect_language(audio_features, self.tokenizer)
+            languages = [max(probs, key=probs.get) for probs in lang_probs]
+            if self.options.language is None:
+                tokens[:, self.sot_index + 1] = lang_tokens.to(tokens.device)
+        return languages, lang_probs
+
+    # -- sampling loops -------------------------------------------------------------------------------------
+    def _fused_greedy_ok(self, tokens: Tensor) -> bool:
+        """device-side loop is exact for: temperature 0, no beams / best_of, stock filters and components"""
+        return (type(self.decoder) is GreedyDecoder and self.options.temperature == 0 and self.n_group == 1
+                and type(self.inference) is HipInference and self.logit_filters == self._stock_filters
+                and all(type(f) in (SuppressBlank, SuppressTokens, ApplyTimestampRules) for f in self.logit_filters)
+                and self.sample_begin + self.sample_len <= 2 * self.n_ctx)
+
+    def _main_loop_fused(self, audio_features: Tensor, tokens: Tensor):
+        tk = self.tokenizer
+        dev = audio_features.device
+        n_rows, T0 = tokens.shape
+        try:
+            task = self.inference._ensure_task(tokens, audio_features)
+            buf = torch.zeros(n_rows, T0 + self.sample_len + 1, dtype=torch.int64, device=dev)
+            buf[:, :T0] = tokens
+            mask = torch.zeros(self.model.dims.n_vocab, dtype=torch.uint8)
+            if self._suppress:
+                mask[list(self._suppress)] = 1
+            mask = mask.to(dev)
+            with_ts = not self.options.without_timestamps
+            params = hip.GreedyParams(
+                sample_begin=T0, max_steps=self.sample_len, n_ctx=self.n_ctx, eot=tk.eot,
+                timestamp_begin=tk.timestamp_begin if with_ts else -1,
+                no_timestamps=tk.no_timestamps if tk.no_timestamps is not None else -1,
+                max_initial_timestamp_index=self._max_initial_ts if self._max_initial_ts is not None else -1,
+                suppress_blank=int(bool(self.options.suppress_blank)), blank_token=tk.encode(" ")[0],
+                suppress_mask=mask.data_ptr())
+            no_speech = tk.no_speech if tk.no_speech is not None else -1
+            n, sum_logprobs, nsp = task.greedy(buf, params, self.sot_index, no_speech)
+            no_speech_probs = nsp.tolist() if nsp is not None else [np.nan] * n_rows
+            return buf[:, :n], sum_logprobs, no_speech_probs
+        finally:
+            self.inference.cleanup_caching()
+
+    def _main_loop(self, audio_features: Tensor, tokens: Tensor):
+        if self._fused_greedy_ok(tokens):
+            return self._main_loop_fused(audio_features, tokens)
+        n_batch = tokens.shape[0]
+        sum_logprobs: Tensor = torch.zeros(n_batch, device=audio_features.device)
+        no_speech_probs = [np.nan] * n_batch
+        if type(self.inference) is HipInference:   # only two positions of the first pass are ever read
+            self.inference.positions = sorted({self.sot_index, tokens.shape[1] - 1})
+        try:
+            for i in range(self.sample_len):
+                logits = self.inference.logits(tokens, audio_features)
+                if i == 0 and self.tokenizer.no_speech is not None:
+                    at_sot = 0 if getattr(self.inference, "positions", None) else self.sot_index
+                    probs_at_sot = logits[:, at_sot].float().softmax(dim=-1)
+                    no_speech_probs = probs_at_sot[:, self.tokenizer.no_speech].tolist()
+                logits = logits[:, -1]
+                for logit_filter in self.logit_filters:
+                    logit_filter.apply(logits, tokens)
+                tokens, completed = self.decoder.update(tokens, logits, sum_logprobs)
+                if completed or tokens.shape[-1] > self.n_ctx:
+                    break
+        finally:
+            self.inference.cleanup_caching()
+        return tokens, sum_logprobs, no_speech_probs
+
+    @torch.no_grad()
+    def run(self, mel: Tensor) -> List[DecodingResult]:
+        self.decoder.reset()
+        tokenizer: Tokenizer = self.tokenizer
+        n_audio: int = mel.shape[0]
+
+        audio_features: Tensor = self._get_audio_features(mel)
+        tokens: Tensor = torch.tensor([self.initial_tokens]).repeat(n_audio, 1)
+
+        languages, language_probs = self._detect_language(audio_features, tokens)
+        if self.options.task == "lang_id":
+            return [DecodingResult(audio_features=f, language=lang, language_probs=probs)
+                    for f, lang, probs in zip(audio_features, languages, language_probs)]
+
+        # one row per (audio, beam / sample); the kernels map row -> audio as row // n_group
+        tokens = tokens.repeat_interleave(self.n_group, dim=0).to(audio_features.device)
+        tokens, sum_logprobs, no_speech_probs = self._main_loop(audio_features, tokens)
+
+        no_speech_probs = no_speech_probs[:: self.n_group]
+        assert audio_features.shape[0] == len(no_speech_probs) == n_audio
+
+        tokens = tokens.reshape(n_audio, self.n_group, -1)
+        sum_logprobs = sum_logprobs.reshape(n_audio, self.n_group)
+        tokens, sum_logprobs = self.decoder.finalize(tokens, sum_logprobs)
+        if torch.is_tensor(tokens):
+            tokens = tokens.cpu()
+        tokens: List[List[Tensor]] = [
+            [t[self.sample_begin: (t == tokenizer.eot).nonzero()[0, 0]] for t in s] for s in tokens
+        ]
+
+        selected = self.sequence_ranker.rank(tokens, sum_logprobs)
+        tokens: List[List[int]] = [t[i].tolist() for i, t in zip(selected, tokens)]
+        texts: List[str] = [tokenizer.decode(t).strip() for t in tokens]
+        sum_logprobs: List[float] = [lp[i] for i, lp in zip(selected, sum_logprobs)]
+        avg_logprobs: List[float] = [lp / (len(t) + 1) for t, lp in zip(tokens, sum_logprobs)]
+
+        fields = (texts, languages, tokens, audio_features, avg_logprobs, no_speech_probs)
+        if len(set(map(len, fields))) != 1:
+            raise RuntimeError(f"inconsistent result lengths: {list(map(len, fields))}")
+        return [
+            DecodingResult(audio_features=features, language=language, tokens=tokens, text=text,
+                           avg_logprob=avg_logprob, no_speech_prob=no_speech_prob,
+                           temperature=self.options.temperature, compression_ratio=compression_ratio(text))
+            for text, language, tokens, features, avg_logprob, no_speech_prob in zip(*fields)
+        ]
+
+
+@torch.no_grad()
+def decode(model: "Whisper", mel: Tensor, options: DecodingOptions = DecodingOptions(),
+           **kwargs) -> Union[DecodingResult, List[DecodingResult]]:
+    """Decode 30-second segment(s) given as (n_mels, 3000) or (*, n_mels, 3000) log-mel spectrograms."""
+    single = mel.ndim == 2
+    if single:
+        mel = mel.unsqueeze(0)
+    if kwargs:
+        options = replace(options, **kwargs)
+    result = DecodingTask(model, options).run(mel)
+    return result[0] if single else result

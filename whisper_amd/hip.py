@@ -89,6 +89,8 @@ SIGNATURES = {
     "wh_task_bench_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
     "wh_median_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "wh_dtw_trace": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "wh_align_matrix": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 
@@ -485,3 +487,18 @@ def dtw_trace(x: torch.Tensor) -> torch.Tensor:
     s = torch.cuda.current_stream(x.device)
     check(lib().wh_dtw_trace(xc.data_ptr(), N, M, trace.data_ptr(), stream_ptr(s)), "wh_dtw_trace")
     return trace
+
+
+def align_matrix(qk: torch.Tensor, n_frames: int, width: int, row_begin: int, row_end: int,
+                 qk_scale: float = 1.0) -> torch.Tensor:
+    """qk fp32 [heads][tokens][n_audio_ctx] -> DTW cost matrix fp32 [row_end-row_begin][n_frames]
+    (softmax over frames, z-norm over tokens, median filter, -mean over heads; whisper/timing.py:207-216)."""
+    require_gpu(qk.device)
+    q = qk.contiguous().float()
+    H, T, Tk = q.shape
+    out = torch.empty(row_end - row_begin, n_frames, dtype=torch.float32, device=q.device)
+    scratch = torch.empty(2 * H * T * n_frames, dtype=torch.float32, device=q.device)
+    s = torch.cuda.current_stream(q.device)
+    check(lib().wh_align_matrix(q.data_ptr(), H, T, Tk, n_frames, width, row_begin, row_end, float(qk_scale),
+                                out.data_ptr(), scratch.data_ptr(), stream_ptr(s)), "wh_align_matrix")
+    return out

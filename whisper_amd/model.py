@@ -1,0 +1,175 @@
+"""`Whisper` model object of whisper_amd.
+
+Same attributes and bound methods as the reference's `whisper.model.Whisper` (model.py:252-345): `.dims`,
+`.device`, `.is_multilingual`, `.num_languages`, `.encoder(mel)`, `.decoder(tokens, xa)`, `.logits`,
+`.embed_audio`, `.forward`, `.alignment_heads`, `.set_alignment_heads`, `.detect_language`, `.transcribe`,
+`.decode`.  It is not an nn.Module: the parameters live in one packed device blob consumed by the HIP kernels
+(whisper_amd/hip.py -> libwhisper_hip.so).  The reference keeps fp32 master weights and lets the activation
+dtype follow the input (model.py:44-50, decoding.py:645-646); here each precision is its own packed engine,
+chosen by the dtype of the tensor you pass (fp16 mel -> fp16 engine, fp32 mel -> fp32 strict-parity engine) and
+built lazily from the retained checkpoint tensors.
+"""
+from __future__ import annotations
+
+import base64
+import gzip
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import hip
+from .decoding import decode as decode_function
+from .decoding import detect_language as detect_language_function
+from .transcribe import transcribe as transcribe_function
+
+
+@dataclass
+class ModelDimensions:
+    n_mels: int
+    n_audio_ctx: int
+    n_audio_state: int
+    n_audio_head: int
+    n_audio_layer: int
+    n_vocab: int
+    n_text_ctx: int
+    n_text_state: int
+    n_text_head: int
+    n_text_layer: int
+
+
+class _EncoderHandle:
+    """callable `model.encoder` (AudioEncoder.forward, reference model.py:188-204)"""
+
+    def __init__(self, owner: "Whisper"):
+        self._owner = owner
+
+    def __call__(self, x: Tensor) -> Tensor:
+        owner = self._owner
+        if x.dim() == 2:
+            x = x[None]
+        x = x.to(owner.device)
+        if x.dtype not in (torch.float16, torch.float32):
+            x = x.float()
+        return owner.engine(x.dtype).encode(x)
+
+    forward = __call__
+
+
+class _DecoderHandle:
+    """callable `model.decoder` (TextDecoder.forward, reference model.py:227-249) for teacher-forced passes.
+    Incremental decoding goes through decoding.HipInference (the KV cache lives in a wh_task, not in a dict of
+    module outputs), so a non-empty `kv_cache` is rejected."""
+
+    def __init__(self, owner: "Whisper"):
+        self._owner = owner
+
+    def __call__(self, x: Tensor, xa: Tensor, kv_cache: Optional[dict] = None) -> Tensor:
+        if kv_cache:
+            raise NotImplementedError("whisper_amd keeps KV caches inside HipInference / wh_task; "
+                                      "hook-based kv_cache dicts are not supported")
+        owner = self._owner
+        x = x.to(owner.device)
+        xa = xa.to(owner.device)
+        if x.dim() == 1:
+            x = x[None]
+        if xa.dim() == 2:
+            xa = xa[None]
+        engine = owner.engine(xa.dtype)
+        n_rows, n_audio = x.shape[0], xa.shape[0]
+        if n_audio == 1 and n_rows > 1:
+            group = n_rows
+        elif n_rows % n_audio == 0:
+            group = n_rows // n_audio
+        else:
+            raise ValueError("token rows must be a multiple of the audio batch")
+        task = hip.HipTask(engine, n_audio, group, max(int(x.shape[1]), 8))
+        try:
+            task.set_audio(xa.contiguous())
+            return task.prefill(x.contiguous().long())
+        finally:
+            task.close()
+
+    forward = __call__
+
+
+class Whisper:
+    def __init__(self, dims: ModelDimensions, state_dict: Dict[str, Tensor], device=None):
+        self.dims = dims
+        self._state_dict = state_dict            # reference-format tensors (any device), kept to build engines
+        self._device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        self._engines: Dict[torch.dtype, hip.HipModel] = {}
+        self.encoder = _EncoderHandle(self)
+        self.decoder = _DecoderHandle(self)
+        # default: every head of the upper half of the decoder (reference model.py:270-276)
+        heads = torch.zeros(dims.n_text_layer, dims.n_text_head, dtype=torch.bool)
+        heads[dims.n_text_layer // 2:] = True
+        self.alignment_heads = heads.to_sparse()
+
+    # ---- engines ---------------------------------------------------------------------------------------
+    def engine(self, dtype: torch.dtype) -> hip.HipModel:
+        if dtype not in (torch.float16, torch.float32):
+            raise TypeError(f"unsupported activation dtype {dtype}")
+        eng = self._engines.get(dtype)
+        if eng is None:
+            hip.require_gpu(self._device)
+            code = hip.WH_F16 if dtype == torch.float16 else hip.WH_F32
+            blob = hip.pack_weights(self._state_dict, self.dims, code, self._device)
+            eng = hip.HipModel(self.dims, code, blob)
+            self._engines[dtype] = eng
+        return eng
+
+    def adopt_engine(self, dtype: torch.dtype, engine: hip.HipModel) -> None:
+        """install an already-packed engine (multi-GPU load: the blob arrived by RCCL broadcast)"""
+        self._engines[dtype] = engine
+
+    # ---- reference surface -----------------------------------------------------------------------------
+    def set_alignment_heads(self, dump: bytes):
+        array = np.frombuffer(gzip.decompress(base64.b85decode(dump)), dtype=bool).copy()
+        mask = torch.from_numpy(array).reshape(self.dims.n_text_layer, self.dims.n_text_head)
+        self.alignment_heads = mask.to_sparse()
+
+    def embed_audio(self, mel: Tensor) -> Tensor:
+        return self.encoder(mel)
+
+    def logits(self, tokens: Tensor, audio_features: Tensor) -> Tensor:
+        return self.decoder(tokens, audio_features)
+
+    def forward(self, mel: Tensor, tokens: Tensor) -> Tensor:
+        return self.decoder(tokens, self.encoder(mel))
+
+    __call__ = forward
+
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    def to(self, device) -> "Whisper":
+        device = torch.device(device)
+        if device != self._device:
+            self._device = device
+            self._engines.clear()
+        return self
+
+    def eval(self) -> "Whisper":
+        return self
+
+    def state_dict(self) -> Dict[str, Tensor]:
+        return dict(self._state_dict)
+
+    @property
+    def is_multilingual(self) -> bool:
+        return self.dims.n_vocab >= 51865
+
+    @property
+    def num_languages(self) -> int:
+        return self.dims.n_vocab - 51765 - int(self.is_multilingual)
+
+    def install_kv_cache_hooks(self, cache: Optional[dict] = None):
+        raise NotImplementedError("no nn.Module hooks here: KV caching is done by decoding.HipInference (wh_task)")
+
+    detect_language = detect_language_function
+    transcribe = transcribe_function
+    decode = decode_function

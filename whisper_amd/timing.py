@@ -1,0 +1,193 @@
+"""Word-level timestamps: cross-attention alignment + dynamic time warping, on the HIP path.
+
+Mirror of the reference's `whisper/timing.py`: `median_filter` (:19), `dtw` (:141), `WordTiming` (:154),
+`find_alignment` (:163), `merge_punctuations` (:245), `add_word_timestamps` (:279) keep their signatures.
+Differences in *how*: the reference re-runs encoder + decoder with SDPA disabled and hooks every
+cross-attention module to grab QK^T (timing.py:186-197); here one teacher-forced prefill keeps the per-layer
+queries (wh_task created with WH_TASK_CAPTURE_Q) and `wh_task_cross_qk` evaluates QK^T only for the alignment
+heads.  softmax / z-norm / median / head-mean are one C call (`wh_align_matrix`), DTW runs as an anti-diagonal
+wavefront kernel with dtw_cpu's tie rule (timing.py:95-100) and only the back-trace walk is host code.
+"""
+from __future__ import annotations
+
+import itertools
+from dataclasses import dataclass
+from typing import TYPE_CHECKING, List
+
+import numpy as np
+import torch
+
+from . import hip
+from .audio import HOP_LENGTH, SAMPLE_RATE, TOKENS_PER_SECOND
+from .tokenizer import Tokenizer
+
+if TYPE_CHECKING:
+    from .model import Whisper
+
+
+def median_filter(x: torch.Tensor, filter_width: int) -> torch.Tensor:
+    """Sliding median of odd width along the last axis with reflect padding; input returned unchanged when it
+    is not longer than the padding (reference timing.py:19-54)."""
+    if x.shape[-1] <= filter_width // 2:
+        return x
+    assert filter_width > 0 and filter_width % 2 == 1, "`filter_width` should be an odd number"
+    return hip.median_filter(x, filter_width).to(x.dtype)
+
+
+def backtrace(trace: np.ndarray) -> np.ndarray:
+    """walk the trace matrix from (N, M) to the origin: code 0 = diagonal, 1 = up, 2 = left
+    (reference timing.py:57-79; row 0 / column 0 are forced to 2 / 1)"""
+    i, j = trace.shape[0] - 1, trace.shape[1] - 1
+    path = []
+    while i > 0 or j > 0:
+        path.append((i - 1, j - 1))
+        step = 2 if i == 0 else 1 if j == 0 else trace[i, j]
+        if step == 0:
+            i, j = i - 1, j - 1
+        elif step == 1:
+            i -= 1
+        elif step == 2:
+            j -= 1
+        else:
+            raise ValueError("Unexpected trace[i, j]")
+    return np.array(path)[::-1, :].T
+
+
+def dtw(x: torch.Tensor) -> np.ndarray:
+    """(2, path_len) array of (row, column) indices of the cheapest monotone path through cost matrix x"""
+    trace = hip.dtw_trace(x.to(torch.float32)).cpu().numpy()
+    return backtrace(trace)
+
+
+@dataclass
+class WordTiming:
+    word: str
+    tokens: List[int]
+    start: float
+    end: float
+    probability: float
+
+
+def find_alignment(model: "Whisper", tokenizer: Tokenizer, text_tokens: List[int], mel: torch.Tensor,
+                   num_frames: int, *, medfilt_width: int = 7, qk_scale: float = 1.0) -> List[WordTiming]:
+    if len(text_tokens) == 0:
+        return []
+    n_sot = len(tokenizer.sot_sequence)
+    tokens = torch.tensor([*tokenizer.sot_sequence, tokenizer.no_timestamps, *text_tokens, tokenizer.eot],
+                          device=model.device)
+    with torch.no_grad():
+        features = model.encoder(mel.unsqueeze(0))
+        engine = model.engine(features.dtype)
+        task = hip.HipTask(engine, 1, 1, max(int(tokens.numel()), 8), capture_q=True)
+        try:
+            task.set_audio(features.contiguous())
+            text_positions = list(range(n_sot, n_sot + len(text_tokens)))
+            logits = task.prefill(tokens[None].contiguous(), sel=text_positions)[0]       # (n_text, vocab)
+            probs = logits[:, : tokenizer.eot].softmax(dim=-1)
+            text_token_probs = probs[torch.arange(len(text_tokens)), torch.tensor(text_tokens)].tolist()
+            heads = model.alignment_heads.indices().T.tolist()
+            qk = task.cross_qk(0, [h[0] for h in heads], [h[1] for h in heads], 0, int(tokens.numel()))
+        finally:
+            task.close()
+        # softmax over frames -> z-norm over tokens -> median filter -> -mean over heads, rows [n_sot, -1)
+        matrix = hip.align_matrix(qk, num_frames // 2, medfilt_width, n_sot, int(tokens.numel()) - 1, qk_scale)
+        text_indices, time_indices = dtw(matrix)
+
+    words, word_tokens = tokenizer.split_to_word_tokens(text_tokens + [tokenizer.eot])
+    if len(word_tokens) <= 1:
+        return []          # only EOT: nothing to align
+    word_boundaries = np.pad(np.cumsum([len(t) for t in word_tokens[:-1]]), (1, 0))
+    jumps = np.pad(np.diff(text_indices), (1, 0), constant_values=1).astype(bool)
+    jump_times = time_indices[jumps] / TOKENS_PER_SECOND
+    start_times = jump_times[word_boundaries[:-1]]
+    end_times = jump_times[word_boundaries[1:]]
+    word_probabilities = [np.mean(text_token_probs[i:j]) for i, j in zip(word_boundaries[:-1], word_boundaries[1:])]
+    return [WordTiming(w, t, s, e, p)
+            for w, t, s, e, p in zip(words, word_tokens, start_times, end_times, word_probabilities)]
+
+
+def merge_punctuations(alignment: List[WordTiming], prepended: str, appended: str):
+    """glue opening punctuation to the following word and closing punctuation to the preceding one, in place"""
+    i, j = len(alignment) - 2, len(alignment) - 1
+    while i >= 0:
+        prev, nxt = alignment[i], alignment[j]
+        if prev.word.startswith(" ") and prev.word.strip() in prepended:
+            nxt.word = prev.word + nxt.word
+            nxt.tokens = prev.tokens + nxt.tokens
+            prev.word, prev.tokens = "", []
+        else:
+            j = i
+        i -= 1
+    i, j = 0, 1
+    while j < len(alignment):
+        prev, nxt = alignment[i], alignment[j]
+        if not prev.word.endswith(" ") and nxt.word in appended:
+            prev.word = prev.word + nxt.word
+            prev.tokens = prev.tokens + nxt.tokens
+            nxt.word, nxt.tokens = "", []
+        else:
+            i = j
+        j += 1
+
+
+def add_word_timestamps(*, segments: List[dict], model: "Whisper", tokenizer: Tokenizer, mel: torch.Tensor,
+                        num_frames: int, prepend_punctuations: str = "\"'“¿([{-",
+                        append_punctuations: str = "\"'.。,，!！?？:：”)]}、", last_speech_timestamp: float,
+                        **kwargs):
+    """attach a "words" list to every segment (reference timing.py:279-388, same clipping heuristics)"""
+    if len(segments) == 0:
+        return
+    per_segment = [[t for t in seg["tokens"] if t < tokenizer.eot] for seg in segments]
+    text_tokens = list(itertools.chain.from_iterable(per_segment))
+    alignment = find_alignment(model, tokenizer, text_tokens, mel, num_frames, **kwargs)
+
+    durations = np.array([w.end - w.start for w in alignment])
+    durations = durations[durations.nonzero()]
+    median_duration = min(0.7, float(np.median(durations) if len(durations) > 0 else 0.0))
+    max_duration = median_duration * 2
+
+    if len(durations) > 0:
+        # words at sentence boundaries must not be longer than twice the median word
+        marks = ".。!！?？"
+        for i in range(1, len(alignment)):
+            if alignment[i].end - alignment[i].start > max_duration:
+                if alignment[i].word in marks:
+                    alignment[i].end = alignment[i].start + max_duration
+                elif alignment[i - 1].word in marks:
+                    alignment[i].start = alignment[i].end - max_duration
+
+    merge_punctuations(alignment, prepend_punctuations, append_punctuations)
+
+    time_offset = segments[0]["seek"] * HOP_LENGTH / SAMPLE_RATE
+    cursor = 0
+    for segment, seg_tokens in zip(segments, per_segment):
+        consumed, words = 0, []
+        while cursor < len(alignment) and consumed < len(seg_tokens):
+            timing = alignment[cursor]
+            if timing.word:
+                words.append(dict(word=timing.word, start=round(time_offset + timing.start, 2),
+                                  end=round(time_offset + timing.end, 2), probability=timing.probability))
+            consumed += len(timing.tokens)
+            cursor += 1
+
+        if len(words) > 0:
+            # first / second word after a pause must not be longer than twice the median word
+            if words[0]["end"] - last_speech_timestamp > median_duration * 4 and (
+                    words[0]["end"] - words[0]["start"] > max_duration
+                    or (len(words) > 1 and words[1]["end"] - words[0]["start"] > max_duration * 2)):
+                if len(words) > 1 and words[1]["end"] - words[1]["start"] > max_duration:
+                    boundary = max(words[1]["end"] / 2, words[1]["end"] - max_duration)
+                    words[0]["end"] = words[1]["start"] = boundary
+                words[0]["start"] = max(0, words[0]["end"] - max_duration)
+            # prefer the segment-level start when the first word is too long
+            if segment["start"] < words[0]["end"] and segment["start"] - 0.5 > words[0]["start"]:
+                words[0]["start"] = max(0, min(words[0]["end"] - median_duration, segment["start"]))
+            else:
+                segment["start"] = words[0]["start"]
+            # prefer the segment-level end when the last word is too long
+            if segment["end"] > words[-1]["start"] and segment["end"] + 0.5 < words[-1]["end"]:
+                words[-1]["end"] = max(words[-1]["start"] + median_duration, segment["end"])
+            else:
+                segment["end"] = words[-1]["end"]
+            last_speech_timestamp = segment["end"]
+        segment["words"] = words

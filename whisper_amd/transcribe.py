@@ -1,0 +1,350 @@
+"""Long-form transcription driver: 30-second sliding window over a file, temperature fallback, prompt
+carry-over, timestamp-based seeking, optional word timestamps and hallucination skipping.
+
+Behavioural mirror of the reference's `whisper/transcribe.py:38-514` — same keyword arguments, same result
+dictionary (`text`, `segments[...]`, `language`), same seek arithmetic — organised as a small state machine
+(`_Transcriber`) instead of one long function.  The heavy lifting of every window (`model.decode`,
+`add_word_timestamps`) runs on the HIP path; the spectrogram of the whole file is computed once on the GPU.
+The argparse CLI of the reference (transcribe.py:517-623) is out of the hot-path scope.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import TYPE_CHECKING, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+import tqdm
+
+from .audio import FRAMES_PER_SECOND, HOP_LENGTH, N_FRAMES, N_SAMPLES, SAMPLE_RATE, log_mel_spectrogram, pad_or_trim
+from .decoding import DecodingOptions, DecodingResult
+from .timing import add_word_timestamps
+from .tokenizer import LANGUAGES, get_tokenizer
+from .utils import exact_div, format_timestamp, get_end, make_safe
+
+if TYPE_CHECKING:
+    from .model import Whisper
+
+_PUNCTUATION = "\"'“¿([{-\"'.。,，!！?？:：”)]}、"
+
+
+def _word_anomaly_score(word: dict) -> float:
+    """very short / very long / improbable words look like hallucinations"""
+    duration = word["end"] - word["start"]
+    score = 1.0 if word.get("probability", 0.0) < 0.15 else 0.0
+    if duration < 0.133:
+        score += (0.133 - duration) * 15
+    if duration > 2.0:
+        score += duration - 2.0
+    return score
+
+
+def _is_segment_anomaly(segment: Optional[dict]) -> bool:
+    if segment is None or not segment["words"]:
+        return False
+    words = [w for w in segment["words"] if w["word"] not in _PUNCTUATION][:8]
+    score = sum(_word_anomaly_score(w) for w in words)
+    return score >= 3 or score + 0.01 >= len(words)
+
+
+def _first_segment_with_words(segments: List[dict]) -> Optional[dict]:
+    for s in segments:
+        if s["words"]:
+            return s
+    return None
+
+
+class _Transcriber:
+    def __init__(self, model: "Whisper", verbose, temperature, compression_ratio_threshold, logprob_threshold,
+                 no_speech_threshold, condition_on_previous_text, initial_prompt, carry_initial_prompt,
+                 word_timestamps, prepend_punctuations, append_punctuations, clip_timestamps,
+                 hallucination_silence_threshold, decode_options: dict):
+        self.model = model
+        self.verbose = verbose
+        self.temperatures = [temperature] if isinstance(temperature, (int, float)) else list(temperature)
+        self.compression_ratio_threshold = compression_ratio_threshold
+        self.logprob_threshold = logprob_threshold
+        self.no_speech_threshold = no_speech_threshold
+        self.condition_on_previous_text = condition_on_previous_text
+        self.carry_initial_prompt = carry_initial_prompt
+        self.word_timestamps = word_timestamps
+        self.prepend_punctuations = prepend_punctuations
+        self.append_punctuations = append_punctuations
+        self.hallucination_silence_threshold = hallucination_silence_threshold
+        self.decode_options = decode_options
+        self.initial_prompt = initial_prompt
+        self.clip_timestamps = clip_timestamps
+
+    # ---- one window ------------------------------------------------------------------------------------
+    def decode_with_fallback(self, segment: torch.Tensor) -> DecodingResult:
+        """retry at increasing temperature while the output is too repetitive or too improbable
+        (reference transcribe.py:184-224)"""
+        result = None
+        for t in self.temperatures:
+            kwargs = {**self.decode_options}
+            if t > 0:
+                kwargs.pop("beam_size", None)      # sampling: no beams
+                kwargs.pop("patience", None)
+            else:
+                kwargs.pop("best_of", None)        # greedy / beam: no best-of
+            result = self.model.decode(segment, DecodingOptions(**kwargs, temperature=t))
+            retry = False
+            if (self.compression_ratio_threshold is not None
+                    and result.compression_ratio > self.compression_ratio_threshold):
+                retry = True
+            if self.logprob_threshold is not None and result.avg_logprob < self.logprob_threshold:
+                retry = True
+            if (self.no_speech_threshold is not None and result.no_speech_prob > self.no_speech_threshold
+                    and self.logprob_threshold is not None and result.avg_logprob < self.logprob_threshold):
+                retry = False                      # it is silence, not a failure
+            if not retry:
+                break
+        return result
+
+    def run(self, audio) -> dict:
+        model, opts = self.model, self.decode_options
+        dtype = torch.float16 if opts.get("fp16", True) else torch.float32
+        if model.device == torch.device("cpu"):
+            if torch.cuda.is_available():
+                warnings.warn("Performing inference on CPU when CUDA is available")
+            if dtype == torch.float16:
+                warnings.warn("FP16 is not supported on CPU; using FP32 instead")
+                dtype = torch.float32
+        if dtype == torch.float32:
+            opts["fp16"] = False
+
+        # whole-file spectrogram with 30 s of trailing silence so every window can be sliced
+        mel = log_mel_spectrogram(audio, model.dims.n_mels, padding=N_SAMPLES, device=model.device)
+        content_frames = mel.shape[-1] - N_FRAMES
+        content_duration = float(content_frames * HOP_LENGTH / SAMPLE_RATE)
+
+        if opts.get("language", None) is None:
+            if not model.is_multilingual:
+                opts["language"] = "en"
+            else:
+                if self.verbose:
+                    print("Detecting language using up to the first 30 seconds. Use `--language` to specify the language")
+                head = pad_or_trim(mel, N_FRAMES).to(model.device).to(dtype)
+                _, probs = model.detect_language(head)
+                opts["language"] = max(probs, key=probs.get)
+                if self.verbose is not None:
+                    print(f"Detected language: {LANGUAGES[opts['language']].title()}")
+
+        language: str = opts["language"]
+        task: str = opts.get("task", "transcribe")
+        tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language=language, task=task)
+
+        clips = self.clip_timestamps
+        if isinstance(clips, str):
+            clips = [float(ts) for ts in (clips.split(",") if clips else [])]
+        seek_points: List[int] = [round(ts * FRAMES_PER_SECOND) for ts in clips]
+        if len(seek_points) == 0:
+            seek_points.append(0)
+        if len(seek_points) % 2 == 1:
+            seek_points.append(content_frames)
+        seek_clips: List[Tuple[int, int]] = list(zip(seek_points[::2], seek_points[1::2]))
+
+        if self.word_timestamps and task == "translate":
+            warnings.warn("Word-level timestamps on translations may not be reliable.")
+
+        input_stride = exact_div(N_FRAMES, model.dims.n_audio_ctx)           # mel frames per timestamp token (2)
+        time_precision = input_stride * HOP_LENGTH / SAMPLE_RATE             # 0.02 s
+        all_tokens: List[int] = []
+        all_segments: List[dict] = []
+        prompt_reset_since = 0
+        remaining_prompt_length = model.dims.n_text_ctx // 2 - 1
+        if self.initial_prompt is not None:
+            initial_prompt_tokens = tokenizer.encode(" " + self.initial_prompt.strip())
+            all_tokens.extend(initial_prompt_tokens)
+            remaining_prompt_length -= len(initial_prompt_tokens)
+        else:
+            initial_prompt_tokens = []
+
+        clip_idx = 0
+        seek = seek_clips[clip_idx][0]
+        last_speech_timestamp = 0.0
+        threshold = self.hallucination_silence_threshold
+
+        def make_segment(*, seek_at: int, start: float, end: float, tokens: torch.Tensor, result: DecodingResult) -> dict:
+            ids = tokens.tolist()
+            return {
+                "seek": seek_at, "start": start, "end": end,
+                "text": tokenizer.decode([t for t in ids if t < tokenizer.eot]),
+                "tokens": ids, "temperature": result.temperature, "avg_logprob": result.avg_logprob,
+                "compression_ratio": result.compression_ratio, "no_speech_prob": result.no_speech_prob,
+            }
+
+        with tqdm.tqdm(total=content_frames, unit="frames", disable=self.verbose is not False) as pbar:
+            while clip_idx < len(seek_clips):
+                clip_start, clip_end = seek_clips[clip_idx]
+                if seek < clip_start:
+                    seek = clip_start
+                if seek >= clip_end:
+                    clip_idx += 1
+                    if clip_idx < len(seek_clips):
+                        seek = seek_clips[clip_idx][0]
+                    continue
+                time_offset = float(seek * HOP_LENGTH / SAMPLE_RATE)
+                window_end_time = float((seek + N_FRAMES) * HOP_LENGTH / SAMPLE_RATE)
+                segment_size = min(N_FRAMES, content_frames - seek, clip_end - seek)
+                segment_duration = segment_size * HOP_LENGTH / SAMPLE_RATE
+                mel_segment = pad_or_trim(mel[:, seek: seek + segment_size], N_FRAMES).to(model.device).to(dtype)
+
+                if self.carry_initial_prompt:
+                    ignored = max(len(initial_prompt_tokens), prompt_reset_since)
+                    tail = all_tokens[ignored:][-remaining_prompt_length:]
+                    opts["prompt"] = initial_prompt_tokens + tail
+                else:
+                    opts["prompt"] = all_tokens[prompt_reset_since:]
+
+                result = self.decode_with_fallback(mel_segment)
+                tokens = torch.tensor(result.tokens)
+
+                if self.no_speech_threshold is not None:
+                    skip = result.no_speech_prob > self.no_speech_threshold
+                    if self.logprob_threshold is not None and result.avg_logprob > self.logprob_threshold:
+                        skip = False           # confident text wins over the no-speech probability
+                    if skip:
+                        seek += segment_size
+                        continue
+
+                previous_seek = seek
+                current_segments: List[dict] = []
+
+                is_ts = tokens.ge(tokenizer.timestamp_begin)
+                single_timestamp_ending = is_ts[-2:].tolist() == [False, True]
+                pair_ends = (torch.where(is_ts[:-1] & is_ts[1:])[0] + 1).tolist()
+                if len(pair_ends) > 0:
+                    # consecutive timestamp pairs delimit segments
+                    cuts = pair_ends + ([len(tokens)] if single_timestamp_ending else [])
+                    begin = 0
+                    for cut in cuts:
+                        piece = tokens[begin:cut]
+                        t_start = piece[0].item() - tokenizer.timestamp_begin
+                        t_end = piece[-1].item() - tokenizer.timestamp_begin
+                        current_segments.append(make_segment(
+                            seek_at=seek, start=time_offset + t_start * time_precision,
+                            end=time_offset + t_end * time_precision, tokens=piece, result=result))
+                        begin = cut
+                    if single_timestamp_ending:
+                        seek += segment_size      # nothing spoken after the last timestamp
+                    else:
+                        last_pos = tokens[begin - 1].item() - tokenizer.timestamp_begin
+                        seek += last_pos * input_stride      # drop the unfinished tail, resume at its start
+                else:
+                    duration = segment_duration
+                    stamps = tokens[is_ts.nonzero().flatten()]
+                    if len(stamps) > 0 and stamps[-1].item() != tokenizer.timestamp_begin:
+                        duration = (stamps[-1].item() - tokenizer.timestamp_begin) * time_precision
+                    current_segments.append(make_segment(seek_at=seek, start=time_offset, end=time_offset + duration,
+                                                         tokens=tokens, result=result))
+                    seek += segment_size
+
+                if self.word_timestamps:
+                    add_word_timestamps(
+                        segments=current_segments, model=model, tokenizer=tokenizer, mel=mel_segment,
+                        num_frames=segment_size, prepend_punctuations=self.prepend_punctuations,
+                        append_punctuations=self.append_punctuations, last_speech_timestamp=last_speech_timestamp)
+
+                    if not single_timestamp_ending:
+                        last_word_end = get_end(current_segments)
+                        if last_word_end is not None and last_word_end > time_offset:
+                            seek = round(last_word_end * FRAMES_PER_SECOND)
+
+                    if threshold is not None:
+                        # skip silence around probable hallucinations
+                        if not single_timestamp_ending:
+                            last_word_end = get_end(current_segments)
+                            if last_word_end is not None and last_word_end > time_offset:
+                                if window_end_time - last_word_end > threshold:
+                                    seek = round(last_word_end * FRAMES_PER_SECOND)
+                                else:
+                                    seek = previous_seek + segment_size
+
+                        first = _first_segment_with_words(current_segments)
+                        if first is not None and _is_segment_anomaly(first):
+                            gap = first["start"] - time_offset
+                            if gap > threshold:
+                                seek = previous_seek + round(gap * FRAMES_PER_SECOND)
+                                continue
+
+                        hal_last_end = last_speech_timestamp
+                        for si in range(len(current_segments)):
+                            segment = current_segments[si]
+                            if not segment["words"]:
+                                continue
+                            if _is_segment_anomaly(segment):
+                                nxt = _first_segment_with_words(current_segments[si + 1:])
+                                hal_next_start = nxt["words"][0]["start"] if nxt is not None else time_offset + segment_duration
+                                silence_before = (segment["start"] - hal_last_end > threshold
+                                                  or segment["start"] < threshold
+                                                  or segment["start"] - time_offset < 2.0)
+                                silence_after = (hal_next_start - segment["end"] > threshold
+                                                 or _is_segment_anomaly(nxt)
+                                                 or window_end_time - segment["end"] < 2.0)
+                                if silence_before and silence_after:
+                                    seek = round(max(time_offset + 1, segment["start"]) * FRAMES_PER_SECOND)
+                                    if content_duration - segment["end"] < threshold:
+                                        seek = content_frames
+                                    current_segments[si:] = []
+                                    break
+                            hal_last_end = segment["end"]
+
+                    last_word_end = get_end(current_segments)
+                    if last_word_end is not None:
+                        last_speech_timestamp = last_word_end
+
+                if self.verbose:
+                    for segment in current_segments:
+                        line = (f"[{format_timestamp(segment['start'])} --> {format_timestamp(segment['end'])}] "
+                                f"{segment['text']}")
+                        print(make_safe(line))
+
+                for segment in current_segments:      # instantaneous or empty segments carry no text
+                    if segment["start"] == segment["end"] or segment["text"].strip() == "":
+                        segment["text"] = ""
+                        segment["tokens"] = []
+                        segment["words"] = []
+
+                base = len(all_segments)
+                all_segments.extend({"id": base + i, **segment} for i, segment in enumerate(current_segments))
+                all_tokens.extend(token for segment in current_segments for token in segment["tokens"])
+
+                if not self.condition_on_previous_text or result.temperature > 0.5:
+                    prompt_reset_since = len(all_tokens)      # do not condition on a high-temperature output
+
+                pbar.update(min(content_frames, seek) - previous_seek)
+
+        return dict(text=tokenizer.decode(all_tokens[len(initial_prompt_tokens):]), segments=all_segments,
+                    language=language)
+
+
+def transcribe(
+    model: "Whisper",
+    audio: Union[str, np.ndarray, torch.Tensor],
+    *,
+    verbose: Optional[bool] = None,
+    temperature: Union[float, Tuple[float, ...]] = (0.0, 0.2, 0.4, 0.6, 0.8, 1.0),
+    compression_ratio_threshold: Optional[float] = 2.4,
+    logprob_threshold: Optional[float] = -1.0,
+    no_speech_threshold: Optional[float] = 0.6,
+    condition_on_previous_text: bool = True,
+    initial_prompt: Optional[str] = None,
+    carry_initial_prompt: bool = False,
+    word_timestamps: bool = False,
+    prepend_punctuations: str = "\"'“¿([{-",
+    append_punctuations: str = "\"'.。,，!！?？:：”)]}、",
+    clip_timestamps: Union[str, List[float]] = "0",
+    hallucination_silence_threshold: Optional[float] = None,
+    **decode_options,
+):
+    """Transcribe an audio file / waveform.  Arguments and return value as in the reference
+    (whisper/transcribe.py:38-125): returns {"text", "segments", "language"}; `decode_options` are forwarded to
+    `DecodingOptions`; `temperature` may be a tuple of fallback temperatures; `clip_timestamps` selects
+    start,end,start,end,... ranges in seconds; `word_timestamps` adds per-word timing from cross-attention + DTW.
+    """
+    return _Transcriber(
+        model, verbose, temperature, compression_ratio_threshold, logprob_threshold, no_speech_threshold,
+        condition_on_previous_text, initial_prompt, carry_initial_prompt, word_timestamps, prepend_punctuations,
+        append_punctuations, clip_timestamps, hallucination_silence_threshold, decode_options,
+    ).run(audio)
