@@ -1,0 +1,206 @@
+"""End-to-end parity of the public API on the GPU: whisper_amd.load_model / decode / detect_language /
+find_alignment / transcribe against (a) outputs of the LIVE reference stored in tests/golden (token ids exact in
+the fp32 strict-parity engine) and (b) the CPU oracle for cases the reference cannot run (batched beam)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import whisper_amd
+from whisper_amd.synthetic import dims_for, save_checkpoint, synthetic_state_dict
+from whisper_amd.tokenizer import get_tokenizer
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_outputs.npz"))
+
+
+def audio(seed, n=480000):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 16000.0
+    x = rng.standard_normal(n).astype(np.float32) * 0.05
+    x += (0.3 * np.sin(2 * np.pi * 440 * t) + 0.1 * np.sin(2 * np.pi * 1870 * t)).astype(np.float32)
+    return x
+
+
+@pytest.fixture(scope="module", params=["micro.en", "micro-v3"])
+def setup(request, gpu_device, tmp_path_factory):
+    name = request.param
+    key = name.replace(".", "_").replace("-", "_")
+    dims = dims_for(name)
+    sd = synthetic_state_dict(dims, seed=1)
+    path = str(tmp_path_factory.mktemp("ckpt") / f"{name}.pt")
+    save_checkpoint(path, dims, sd)
+    model = whisper_amd.load_model(path, device=gpu_device)
+    mel = whisper_amd.pad_or_trim(whisper_amd.log_mel_spectrogram(audio(3), dims.n_mels, device=gpu_device), 3000)
+    return key, dims, sd, model, mel
+
+
+def test_mel_golden(gpu_device):
+    """HIP log-mel vs the reference's torch.stft path (stored outputs): atol 1e-4"""
+    for n_mels in (80, 128):
+        a = audio(100 + n_mels, 16000 * 4 + 37)
+        got = whisper_amd.log_mel_spectrogram(a, n_mels, device=gpu_device).cpu().numpy()
+        assert np.abs(got - G[f"mel{n_mels}_4s"]).max() < 1e-4
+        got = whisper_amd.log_mel_spectrogram(a, n_mels, padding=1600, device=gpu_device).cpu().numpy()[:, -40:]
+        assert np.abs(got - G[f"mel{n_mels}_4s_pad"]).max() < 1e-4
+    ab = np.stack([audio(7, 32000), audio(8, 32000) * 3.0])
+    got = whisper_amd.log_mel_spectrogram(torch.from_numpy(ab), 80, device=gpu_device).cpu().numpy()
+    assert np.abs(got - G["mel80_batch"]).max() < 1e-4        # global max over the batch (audio.py:155)
+
+
+def test_encoder_and_logits_golden(setup):
+    key, dims, sd, model, mel = setup
+    feats = model.encoder(mel[None].float())
+    assert feats.dtype == torch.float32
+    assert np.abs(feats[0, ::50, :24].cpu().numpy() - G[f"{key}_enc_slice"]).max() < 3e-4
+    toks = torch.from_numpy(G[f"{key}_tf_tokens"]).to(mel.device)
+    logits = model.decoder(toks, feats.repeat(2, 1, 1))
+    assert logits.dtype == torch.float32 and logits.shape == (2, 9, dims.n_vocab)
+    assert np.abs(logits[:, :, ::997].cpu().numpy() - G[f"{key}_tf_logits_slice"]).max() < 1e-3   # north_star: 1e-3
+    assert np.array_equal(logits.argmax(-1).cpu().numpy(), G[f"{key}_tf_logits_argmax"])
+    # fp16 engine: same call with fp16 activations
+    feats16 = model.encoder(mel[None].half())
+    assert feats16.dtype == torch.float16
+    lg16 = model.decoder(toks, feats16.repeat(2, 1, 1))
+    assert np.abs(lg16[:, :, ::997].cpu().numpy() - G[f"{key}_tf_logits_slice"]).max() < 6e-2
+
+
+@pytest.mark.parametrize("tag,kw", [("ts", {}), ("nots", {"without_timestamps": True}),
+                                    ("prompt", {"prompt": [1000, 2000, 3000], "prefix": [400, 500]})])
+def test_greedy_decode_golden(setup, tag, kw):
+    """fused device-side greedy loop, fp32 engine: token ids exactly those of the reference's DecodingTask"""
+    key, dims, sd, model, mel = setup
+    res = whisper_amd.decode(model, mel, whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=20, **kw))
+    assert res.tokens == G[f"{key}_greedy_{tag}_tokens"].tolist()
+    avg, nsp, cr = G[f"{key}_greedy_{tag}_stats"]
+    assert abs(res.avg_logprob - avg) < 1e-3
+    assert abs(res.no_speech_prob - nsp) < max(1e-7, 2e-3 * nsp)
+    assert abs(res.compression_ratio - cr) < 1e-9
+    assert res.audio_features.shape == (dims.n_audio_ctx, dims.n_audio_state)
+
+
+def test_generic_loop_equals_fused(setup):
+    """a user-supplied (no-op) LogitFilter forces the host-driven loop (per-step wh_task_step + vectorised
+    filters): same tokens and logprobs as the fused loop"""
+    from whisper_amd.decoding import DecodingTask, LogitFilter
+
+    class Noop(LogitFilter):
+        def apply(self, logits, tokens):
+            return None
+
+    key, dims, sd, model, mel = setup
+    opts = whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=20)
+    fused = DecodingTask(model, opts).run(mel[None])[0]
+    task = DecodingTask(model, opts)
+    task.logit_filters.append(Noop())
+    generic = task.run(mel[None])[0]
+    assert generic.tokens == fused.tokens == G[f"{key}_greedy_ts_tokens"].tolist()
+    assert abs(generic.avg_logprob - fused.avg_logprob) < 1e-4
+    assert abs(generic.no_speech_prob - fused.no_speech_prob) < 1e-6
+
+
+def test_beam_decode_golden(setup):
+    key, dims, sd, model, mel = setup
+    res = whisper_amd.decode(model, mel, whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=12, beam_size=3))
+    assert res.tokens == G[f"{key}_beam3_tokens"].tolist()
+    assert abs(res.avg_logprob - G[f"{key}_beam3_stats"][0]) < 1e-3
+    res = whisper_amd.decode(model, mel, whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=10,
+                                                                     beam_size=2, patience=2.0))
+    assert res.tokens == G[f"{key}_beam2p_tokens"].tolist()
+
+
+def test_batched_beam_vs_oracle(setup, gpu_device):
+    """n_audio = 3 x beam 3 in ONE task (the reference raises here): must equal each audio
+    decoded alone by the CPU oracle"""
+    key, dims, sd, model, mel = setup
+    mels = torch.stack([whisper_amd.pad_or_trim(whisper_amd.log_mel_spectrogram(audio(40 + i), dims.n_mels,
+                                                                                device=gpu_device), 3000) for i in range(3)])
+    results = whisper_amd.decode(model, mels, whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=8, beam_size=3))
+    om = oracle.OracleModel(dims, sd)
+    multilingual = dims.n_vocab >= 51865
+    tok = get_tokenizer(multilingual, num_languages=dims.n_vocab - 51765 - int(multilingual), language="en", task="transcribe")
+    suppress = sorted(set(list(tok.non_speech_tokens) + [tok.transcribe, tok.translate, tok.sot, tok.sot_prev, tok.sot_lm, tok.no_speech]))
+    init = list(tok.sot_sequence)
+    rules = oracle.SamplingRules(sample_begin=len(init), sot_index=0, eot=tok.eot, timestamp_begin=tok.timestamp_begin,
+                                 no_timestamps=tok.no_timestamps, suppress_tokens=suppress, blank_token=tok.encode(" ")[0],
+                                 no_speech=tok.no_speech)
+    filt = oracle.mel_filterbank(dims.n_mels)
+    for i, res in enumerate(results):
+        omel = oracle.log_mel_spectrogram(audio(40 + i), filt)
+        with torch.no_grad():
+            out = oracle.beam_decode(om, om.encoder(omel[None]), init, 8, rules, 3)
+        body, lp = oracle.decoding.rank_candidates(out["candidates"][0], len(init), tok.eot)
+        assert res.tokens == body, i
+
+
+def test_batch_invariance_fp16(setup, gpu_device):
+    """size-independent property at the bench batch size: 8 clips decoded together == each decoded alone
+    (fp16 engine; rows are independent, so token ids must agree exactly)"""
+    key, dims, sd, model, mel = setup
+    mels = torch.stack([whisper_amd.pad_or_trim(whisper_amd.log_mel_spectrogram(audio(60 + i), dims.n_mels,
+                                                                                device=gpu_device), 3000) for i in range(8)])
+    opts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=24)
+    together = whisper_amd.decode(model, mels, opts)
+    for i in range(8):
+        alone = whisper_amd.decode(model, mels[i], opts)
+        assert alone.tokens == together[i].tokens, i
+
+
+def test_fp16_tracks_fp32(setup):
+    """fp16 engine vs the fp32 reference tokens: not guaranteed identical (activation rounding), but the first
+    tokens and the no-speech probability must agree"""
+    key, dims, sd, model, mel = setup
+    res = whisper_amd.decode(model, mel, whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=20))
+    want = G[f"{key}_greedy_ts_tokens"].tolist()
+    assert res.tokens[:4] == want[:4]
+    assert abs(res.no_speech_prob - G[f"{key}_greedy_ts_stats"][1]) < 0.05 * G[f"{key}_greedy_ts_stats"][1] + 1e-7
+
+
+def test_detect_language_golden(setup):
+    key, dims, sd, model, mel = setup
+    if not model.is_multilingual:
+        with pytest.raises(ValueError):
+            whisper_amd.detect_language(model, mel)
+        return
+    tok, probs = whisper_amd.detect_language(model, mel.float())
+    assert int(tok) == int(G[f"{key}_lang_token"][0])
+    top = sorted(probs.items(), key=lambda kv: -kv[1])[:5]
+    assert [c for c, _ in top] == G[f"{key}_lang_top5"].tolist()
+    assert np.allclose([p for _, p in top], G[f"{key}_lang_top5_p"], rtol=2e-3)
+
+
+def test_find_alignment_golden(setup):
+    """cross-attention QK capture + softmax/z-norm/median + DTW kernels vs the reference's find_alignment"""
+    from whisper_amd.timing import find_alignment
+    key, dims, sd, model, mel = setup
+    multilingual = model.is_multilingual
+    tok = get_tokenizer(multilingual, num_languages=model.num_languages, language="en", task="transcribe")
+    al = find_alignment(model, tok, G[f"{key}_align_tokens"].tolist(), mel.float(), 3000)
+    starts, ends = np.array([w.start for w in al]), np.array([w.end for w in al])
+    assert len(al) == len(G[f"{key}_align_start"])
+    assert np.abs(starts - G[f"{key}_align_start"]).max() <= 0.0201       # one 20 ms frame of slack on DTW ties
+    assert np.abs(ends - G[f"{key}_align_end"]).max() <= 0.0201
+    assert np.allclose([w.probability for w in al], G[f"{key}_align_prob"], rtol=5e-3, atol=1e-6)
+
+
+def test_transcribe_golden(setup):
+    """50 s, two windows + fallback-free greedy + word timestamps through model.transcribe(): segment token ids,
+    seeks and boundaries equal the reference's; word times within one 20 ms frame"""
+    key, dims, sd, model, mel = setup
+    a50 = np.concatenate([audio(21), audio(22, 320000)])
+    r = model.transcribe(a50, temperature=0.0, fp16=False, language="en", sample_len=16, word_timestamps=True,
+                         condition_on_previous_text=True)
+    assert set(r) == {"text", "segments", "language"} and r["language"] == "en"
+    assert len(r["segments"]) == int(G[f"{key}_tr_n_segments"][0])
+    assert [t for s in r["segments"] for t in s["tokens"]] == G[f"{key}_tr_tokens"].tolist()
+    bounds = np.array([[s["seek"], s["start"], s["end"]] for s in r["segments"]])
+    assert np.array_equal(bounds[:, 0], G[f"{key}_tr_seg_bounds"][:, 0])
+    assert np.abs(bounds[:, 1:] - G[f"{key}_tr_seg_bounds"][:, 1:]).max() <= 0.0201
+    words = np.array([[w["start"], w["end"]] for s in r["segments"] for w in s["words"]])
+    assert words.shape == G[f"{key}_tr_word_times"].shape
+    assert np.abs(words - G[f"{key}_tr_word_times"]).max() <= 0.0201
+    for s in r["segments"]:
+        assert {"id", "seek", "start", "end", "text", "tokens", "temperature", "avg_logprob", "compression_ratio",
+                "no_speech_prob", "words"} <= set(s)

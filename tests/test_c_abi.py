@@ -1,0 +1,74 @@
+"""CPU-only checks of the drop-in boundary: libwhisper_hip.so loads, exports every symbol that
+include/whisper_hip.h declares (and nothing in the binding is missing from the header), the pure-host entry
+points behave, and the product refuses to run without a GPU instead of falling back."""
+import os
+import re
+
+import pytest
+import torch
+
+from whisper_amd import hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "whisper_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wh_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_header():
+    lib = hip.lib()
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in whisper_hip.h but not exported"
+    assert sorted(hip.SIGNATURES) == syms, "ctypes binding and header disagree"
+
+
+def test_status_strings_and_version():
+    lib = hip.lib()
+    assert lib.wh_abi_version() == 1
+    assert lib.wh_status_string(0) == b"ok"
+    assert b"workspace" in lib.wh_status_string(2)
+
+
+def test_argument_validation_without_gpu():
+    """entry points reject bad arguments before touching the device"""
+    lib = hip.lib()
+    assert lib.wh_log_mel(None, 480000, 1, 80, None, None, None, None) == 1
+    assert lib.wh_median_filter(None, None, 1, 10, 7, None) == 1
+    assert lib.wh_dtw_trace(None, 4, 4, None, None) == 1
+    assert lib.wh_encoder_workspace_bytes(None, 1) == 0
+    assert lib.wh_task_workspace_bytes(None, 1, 1, 8, 0) == 0
+
+
+def test_blob_layout_is_deterministic():
+    from whisper_amd.synthetic import dims_for
+    d = dims_for("base")
+    a, na = hip.blob_layout(d, hip.WH_F16)
+    b, nb = hip.blob_layout(d, hip.WH_F16)
+    assert a == b and na == nb
+    offs = sorted(v[0] for v in a.values())
+    assert all(o % 256 == 0 for o in offs) and len(set(offs)) == len(offs)
+    # fp16 step-weight bytes of SURVEY.md Appendix A: 14*D^2*L + V*D parameters
+    D, L, V = d.n_text_state, d.n_text_layer, d.n_vocab
+    mats = sum(2 * int(torch.tensor(s).prod()) for n, (o, s, m) in a.items()
+               if m and n.startswith("dec.") and not n.endswith("ckv_w")) + 2 * V * D    # ckv_w is per-window, not per-step
+    assert mats == 2 * (14 * D * D * L + V * D)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback():
+    import numpy as np
+    import whisper_amd
+    with pytest.raises(hip.HipError):
+        whisper_amd.log_mel_spectrogram(np.zeros(16000, dtype=np.float32))
+    from whisper_amd.synthetic import dims_for, synthetic_state_dict
+    from whisper_amd.model import ModelDimensions, Whisper
+    from oracle.model import dims_dict
+    dims = dims_for("micro.en")
+    model = Whisper(ModelDimensions(**dims_dict(dims)), {}, device="cpu")
+    with pytest.raises(hip.HipError):
+        model.encoder(torch.zeros(1, 80, 3000))
