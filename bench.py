@@ -29,6 +29,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+_T0 = time.perf_counter()
+
+
+def log(msg: str) -> None:
+    """progress to stderr (stdout carries exactly one JSON line)"""
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s float4-copy achievable)
 
 
@@ -76,6 +84,9 @@ def main():
     else:
         dist = None
 
+    import faulthandler
+    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
+    log(f"rank {rank}/{world} device ready")
     from whisper_amd import hip
     from whisper_amd.audio import log_mel_spectrogram
     from whisper_amd.launcher import broadcast_weights
@@ -93,6 +104,7 @@ def main():
         torch.cuda.empty_cache()
     blob = broadcast_weights(blob, dims, dtype, device, dist)
     model = hip.HipModel(dims, dtype, blob)
+    log(f"weights packed: {blob.numel() / 1e9:.2f} GB")
 
     B, N = args.batch, args.sample_len
     multilingual = dims.n_vocab >= 51865
@@ -132,6 +144,8 @@ def main():
 
     for _ in range(args.warmup):
         n_tok = one_pass()
+        torch.cuda.synchronize(device)
+        log("warmup pass done")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -144,6 +158,7 @@ def main():
         elapsed = float(tmax.item())
     assert n_tok == T0 + N, (n_tok, T0, N)
     ms_per_step = elapsed / args.steps * 1e3
+    log(f"timed: {ms_per_step:.1f} ms per pass")
     audio_s = 30.0 * B * world * args.steps
     value = audio_s / elapsed
 
@@ -165,6 +180,7 @@ def main():
         kern = {}
         for name, kind in kinds.items():
             ms, nbytes = task.bench_kernel(kind, 64 if kind else 16)
+            log(f"kernel {name}: {ms * 1e3:.1f} us, {nbytes / (ms * 1e-3) / 1e9:.0f} GB/s")
             kern[name] = {"avg_us": round(ms * 1e3, 2), "bytes": nbytes, "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1)}
         dom = kern["attn_decode_cross"]
         out["roofline"] = {"bound": "hbm", "kernel": "attn_decode_kernel<half> (cross-attention KV stream)",
@@ -190,8 +206,10 @@ def cpu_baseline(args, dims, init, suppress, tok, audio_np):
     from whisper_amd.synthetic import synthetic_state_dict
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: building {args.model} fp32 oracle on {cores} host threads")
     sd = synthetic_state_dict(dims, seed=0, device="cpu")
     om = oracle.OracleModel(dims, sd)
+    log("cpu_baseline: oracle model ready")
     filt = oracle.mel_filterbank(dims.n_mels)
     t0 = time.perf_counter()
     mel = oracle.log_mel_spectrogram(audio_np[0], filt)
@@ -200,6 +218,7 @@ def cpu_baseline(args, dims, init, suppress, tok, audio_np):
     with torch.no_grad():
         feats = om.encoder(mel[None])
     t_enc = time.perf_counter() - t0
+    log(f"cpu_baseline: log-mel {t_mel:.2f}s encoder {t_enc:.2f}s")
     rules = oracle.SamplingRules(sample_begin=len(init), sot_index=0, eot=tok.eot, n_ctx=dims.n_text_ctx,
                                  timestamp_begin=tok.timestamp_begin, no_timestamps=tok.no_timestamps,
                                  suppress_tokens=suppress, blank_token=tok.encode(" ")[0], no_speech=tok.no_speech)
@@ -209,6 +228,7 @@ def cpu_baseline(args, dims, init, suppress, tok, audio_np):
         oracle.greedy_decode(om, feats, init, k, rules)
     t_dec = time.perf_counter() - t0
     per_step = t_dec / k
+    log(f"cpu_baseline: {k} decode steps in {t_dec:.2f}s")
     total = t_mel + t_enc + per_step * args.sample_len
     return {"value": round(30.0 / total, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
             "sample": f"1 clip of the same workload: log-mel {t_mel:.2f}s + encoder {t_enc:.2f}s + {k} decode steps "

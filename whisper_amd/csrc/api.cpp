@@ -274,15 +274,22 @@ struct wh_task {
   float* xsel; void* xseln;
   int* d_pos; int* d_alive; int* d_sel; int* d_src;
   int64_t* step_tokens;
+  float* samp_part;        // greedy sampler stage-1 partials
   void* qcap;              // [L][R*Tcap][D] captured cross-attention queries
-  int cross_splits;
+  int cross_splits, self_splits;
   size_t total;
 };
 
-static int pick_splits(int R, int H) {
+// key-range splits of the decode attention: enough for the register-resident tile to hold a split
+// (attn_decode_capacity) and enough workgroups (>= ~640) to cover the 256 CUs with loads in flight
+static int pick_splits(int R, int H, int max_keys, int dtype) {
+  const int cap = attn_decode_capacity(dtype);
+  const int unit = dtype == WH_F16 ? 32 : 16;          // chunk rounding inside the kernel
   int s = (640 + R * H - 1) / (R * H);
   if (s < 1) s = 1;
-  if (s > 8) s = 8;
+  if (s > DEC_ATTN_MAX_SPLITS) s = DEC_ATTN_MAX_SPLITS;
+  while (s < DEC_ATTN_MAX_SPLITS && ((max_keys + s - 1) / s + unit - 1) / unit * unit > cap) ++s;
+  while (s > 1 && (max_keys + s - 2) / (s - 1) <= unit) --s;   // never more splits than 32-key chunks
   return s;
 }
 
@@ -303,8 +310,8 @@ static void task_carve(wh_task* t, void* base) {
   t->att = c.take(Mx * D * es);
   t->h = c.take(Mx * 4 * D * es);
   t->qbuf = c.take(R * D * es);
-  t->part_o = (float*)c.take(R * H * 8 * 64 * 4);
-  t->part_ml = (float*)c.take(R * H * 8 * 2 * 4);
+  t->part_o = (float*)c.take(R * H * DEC_ATTN_MAX_SPLITS * 64 * 4);
+  t->part_ml = (float*)c.take(R * H * DEC_ATTN_MAX_SPLITS * 2 * 4);
   t->logits = (float*)c.take(R * 2 * V * 4);
   t->xsel = (float*)c.take(Mx * D * 4);
   t->xseln = c.take(Mx * D * es);
@@ -313,6 +320,7 @@ static void task_carve(wh_task* t, void* base) {
   t->d_sel = (int*)c.take(Mx * 4);
   t->d_src = (int*)c.take(R * 4);
   t->step_tokens = (int64_t*)c.take(R * 8);
+  t->samp_part = (float*)c.take(greedy_sample_scratch_bytes((int)R, (int)V));
   t->qcap = (t->flags & WH_TASK_CAPTURE_Q) ? c.take(L * R * C * D * es) : nullptr;
   t->total = align_up(c.off, 256);
 }
@@ -336,7 +344,11 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
   t->m = m; t->B = n_audio; t->G = n_group; t->R = n_audio * n_group; t->Tmax = max_prefill_tokens; t->flags = flags;
   task_carve(t, workspace);
   if (t->total > workspace_bytes) { delete t; return WH_ERR_WORKSPACE; }
-  t->cross_splits = pick_splits(t->R, m->d.n_text_head);
+  t->cross_splits = pick_splits(t->R, m->d.n_text_head, m->d.n_audio_ctx, m->dtype);
+  {  // self-attention: the split count must hold for every cached length up to n_text_ctx
+    const int cap = attn_decode_capacity(m->dtype);
+    t->self_splits = (m->d.n_text_ctx + cap - 1) / cap;
+  }
   hipError_t e = hipMemset(t->d_pos, 0, 4);
   if (e != hipSuccess) { g_last_hip = e; delete t; return WH_ERR_HIP; }
   *out = t;
@@ -496,12 +508,16 @@ static int step_launch(wh_task* t, hipStream_t s) {
       a.q = t->qbuf; a.q_ld = D;
       a.k = self_k_layer(t, l); a.k_ld = D; a.k_bs = (int64_t)C * D;
       a.v = self_v_layer(t, l); a.v_ld = D; a.v_bs = (int64_t)C * D;
-      a.H = H; a.R = R; a.kv_group = 1; a.d_len = t->d_pos; a.len_plus = 1; a.splits = 1;
-      a.out = t->att; a.o_ld = D;
+      a.H = H; a.R = R; a.kv_group = 1; a.d_len = t->d_pos; a.len_plus = 1; a.splits = t->self_splits;
+      a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
       HIPCHK(launch_attn_decode(a, m->dtype, s));
     }
     memset(&g, 0, sizeof(g));
-    g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D;
+    if (t->self_splits > 1) {
+      g.pro = PRO_COMBINE; g.part_o = t->part_o; g.part_ml = t->part_ml; g.splits = t->self_splits; g.H = H;
+    } else {
+      g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D;
+    }
     g.W = L.out_w; g.bias = L.out_b; g.N = D; g.K = D; g.R = R;
     g.epi = EPI_RESID; g.resid = t->x; g.resid_ld = D;
     HIPCHK(launch_gemv(g, m->dtype, s));
@@ -546,9 +562,9 @@ static int step_launch(wh_task* t, hipStream_t s) {
     g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = m->w.dec_ln_w; g.ln_b = m->w.dec_ln_b;
     g.W = m->w.tok_emb; g.bias = nullptr; g.N = V; g.K = D; g.R = R;
     g.epi = EPI_F32; g.y = t->logits; g.y_ld = V;
+    g.bump = t->d_pos; g.bump_by = 1;         // the last kernel of the step advances the position counter
     HIPCHK(launch_gemv(g, m->dtype, s));
   }
-  HIPCHK(launch_add_int(t->d_pos, 1, s));
   return WH_OK;
 }
 
@@ -649,7 +665,7 @@ extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* to
   sa.sample_begin = T0; sa.eot = p->eot; sa.timestamp_begin = p->timestamp_begin; sa.no_timestamps = p->no_timestamps;
   sa.max_initial_ts = p->max_initial_timestamp_index; sa.suppress_blank = p->suppress_blank;
   sa.blank_token = p->blank_token; sa.suppress_mask = p->suppress_mask; sa.sum_logprobs = sum_logprobs;
-  sa.step_tokens = t->step_tokens; sa.d_alive_step = t->d_alive;
+  sa.step_tokens = t->step_tokens; sa.d_alive_step = t->d_alive; sa.partials = t->samp_part;
 
   sa.logits = t->logits + (size_t)(n_sel - 1) * V; sa.logits_ld = (int64_t)n_sel * V;
   HIPCHK(launch_greedy_sample(sa, s));
@@ -716,8 +732,8 @@ extern "C" int wh_task_bench_kernel(wh_task* t, int kind, int iters, double* byt
         a.q = t->qbuf; a.q_ld = D;
         a.k = self_k_layer(t, l); a.k_ld = D; a.k_bs = (int64_t)C * D;
         a.v = self_v_layer(t, l); a.v_ld = D; a.v_bs = (int64_t)C * D;
-        a.H = H; a.R = R; a.kv_group = 1; a.d_len = t->d_pos; a.len_plus = 0; a.splits = 1;
-        a.out = t->att; a.o_ld = D;
+        a.H = H; a.R = R; a.kv_group = 1; a.d_len = t->d_pos; a.len_plus = 0; a.splits = t->self_splits;
+        a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
         HIPCHK(launch_attn_decode(a, m->dtype, s));
         bytes = (double)R * t->pos * 2.0 * D * es;
       } break;

@@ -278,106 +278,110 @@ __global__ __launch_bounds__(256, 2) void attn_flash_f16_kernel(
 }
 
 // =============================================================================================
-// decode attention: one query per row
+// decode attention: one query per row.  The whole K and V slice of a workgroup is requested up front
+// (2 x NL 16-byte loads per lane, non-temporal) and held in registers: one HBM round trip per launch,
+// scores never touch LDS, softmax statistics travel by wave shuffles + two 4-entry LDS exchanges.
 // =============================================================================================
-constexpr int DEC_MAX_KEYS = 1536;
+constexpr int DEC_NL = 16;            // wave-loads of K (and of V) per lane
 
-template <typename T>
+template <typename T, int NL>
 __global__ __launch_bounds__(256) void attn_decode_kernel(whk::DecAttnArgs a) {
   typedef typename ET<T>::unit_t unit_t;
   constexpr int UNIT = ET<T>::UNIT;
   constexpr int LPK = 64 / UNIT;     // lanes per key (8 fp16 / 16 fp32)
   constexpr int KPW = 64 / LPK;      // keys per wave instruction
-  __shared__ float sc[DEC_MAX_KEYS];
   __shared__ float red[4][64];
-  __shared__ float redm[4];
+  __shared__ float redm[4], reds[4];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int s = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
   const int S = a.splits;
   const int Tk = a.d_len ? (*a.d_len + a.len_plus) : a.Tk;
   int chunk = (Tk + S - 1) / S;
-  chunk = (chunk + 31) & ~31;
+  chunk = (chunk + 4 * KPW - 1) / (4 * KPW) * (4 * KPW);
   const int k0 = s * chunk;
   int k1 = k0 + chunk; if (k1 > Tk) k1 = Tk;
   const int nkeys = k1 > k0 ? k1 - k0 : 0;
 
+  const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  (void)wgid;
+  WH_PROBE_AT(a, wgid, 0);
   const int kvb = r / a.kv_group;
-  const T* kp = (const T*)a.k + (int64_t)kvb * a.k_bs + h * 64;
-  const T* vp = (const T*)a.v + (int64_t)kvb * a.v_bs + h * 64;
   const int cu = lane % LPK;          // unit within the head row
   const int ks = lane / LPK;          // key slot within the wave instruction
+  const T* kp = (const T*)a.k + (int64_t)kvb * a.k_bs + h * 64 + cu * UNIT;
+  const T* vp = (const T*)a.v + (int64_t)kvb * a.v_bs + h * 64 + cu * UNIT;
+
+  // branch-free loads (a zero-fill else-arm would make the compiler drain vmcnt at every join): slots past
+  // the split re-read its last key and are neutralised through score = -inf / p = 0 below.
+  const int klast = Tk > 0 ? Tk - 1 : 0;
+  // q first (L2 hit, needed first): loads return in issue order
+  const unit_t qu = *(const unit_t*)((const T*)a.q + (int64_t)r * a.q_ld + h * 64 + cu * UNIT);
+  asm volatile("" ::: "memory");
+  unit_t ku[NL], vu[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    int key = k0 + (i * 4 + wave) * KPW + ks; if (key > klast) key = klast;
+    ku[i] = __builtin_nontemporal_load((const unit_t*)(kp + (int64_t)key * a.k_ld));
+  }
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    int key = k0 + (i * 4 + wave) * KPW + ks; if (key > klast) key = klast;
+    vu[i] = __builtin_nontemporal_load((const unit_t*)(vp + (int64_t)key * a.v_ld));
+  }
+
+  WH_PROBE_AT(a, wgid, 1);
 
   float qv[UNIT];
-  {
-    const unit_t qu = *(const unit_t*)((const T*)a.q + (int64_t)r * a.q_ld + h * 64 + cu * UNIT);
 #pragma unroll
-    for (int e = 0; e < UNIT; ++e) qv[e] = to_f32(qu[e]) * SCALE;
-  }
+  for (int e = 0; e < UNIT; ++e) qv[e] = to_f32(qu[e]) * SCALE;
 
-  // ---- phase 1: scores
-  const int per_iter = 4 * KPW;
-  const int niter = (nkeys + per_iter - 1) / per_iter;
-#pragma unroll 4
-  for (int it = 0; it < niter; ++it) {
-    const int kk = (it * 4 + wave) * KPW + ks;
-    float d = 0.f;
-    if (kk < nkeys) {
-      const unit_t ku = *(const unit_t*)(kp + (int64_t)(k0 + kk) * a.k_ld + cu * UNIT);
-#pragma unroll
-      for (int e = 0; e < UNIT; ++e) d = __builtin_fmaf(qv[e], to_f32(ku[e]), d);
-    }
-#pragma unroll
-    for (int o = LPK / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-    if (cu == 0 && kk < nkeys) sc[kk] = d;
-  }
-  __syncthreads();
-
-  // ---- softmax over this split
+  // ---- scores (registers), split max
+  float sc[NL];
   float mx = WH_NEG_INF;
-  for (int i = tid; i < nkeys; i += 256) mx = fmaxf(mx, sc[i]);
-  mx = wave_max(mx);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int kk = (i * 4 + wave) * KPW + ks;
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < UNIT; ++e) d = __builtin_fmaf(qv[e], to_f32(ku[i][e]), d);
+    d = LPK == 8 ? group8_sum(d) : group16_sum(d);
+    sc[i] = (kk < nkeys) ? d : WH_NEG_INF;
+    mx = fmaxf(mx, sc[i]);
+  }
+  mx = LPK == 8 ? across_groups8_max(mx) : across_groups16_max(mx);
   if (lane == 0) redm[wave] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
-  float sum = 0.f;
-  for (int i = tid; i < nkeys; i += 256) {
-    const float p = __expf(sc[i] - mx);
-    sc[i] = p;
-    sum += p;
-  }
-  sum = wave_sum(sum);
-  __syncthreads();                 // p values visible; redm reads done
-  if (lane == 0) redm[wave] = sum;
+  WH_PROBE_AT(a, wgid, 2);
 
-  // ---- phase 2: o = sum_k p[k] V[k]
+  // ---- p = exp(s - max), o = sum_k p[k] V[k]
   float acc[UNIT];
 #pragma unroll
   for (int e = 0; e < UNIT; ++e) acc[e] = 0.f;
-#pragma unroll 4
-  for (int it = 0; it < niter; ++it) {
-    const int kk = (it * 4 + wave) * KPW + ks;
-    if (kk < nkeys) {
-      const unit_t vu = *(const unit_t*)(vp + (int64_t)(k0 + kk) * a.v_ld + cu * UNIT);
-      const float p = sc[kk];
+  float sum = 0.f;
 #pragma unroll
-      for (int e = 0; e < UNIT; ++e) acc[e] = __builtin_fmaf(p, to_f32(vu[e]), acc[e]);
-    }
+  for (int i = 0; i < NL; ++i) {
+    const float p = (sc[i] == WH_NEG_INF) ? 0.f : __expf(sc[i] - mx);
+    sum += p;
+#pragma unroll
+    for (int e = 0; e < UNIT; ++e) acc[e] = __builtin_fmaf(p, to_f32(vu[i][e]), acc[e]);
   }
-  // reduce over key slots (lane bits above log2(LPK))
+  // reduce over key slots (lane bits above log2(LPK)); every lane of a key group holds the same p
+  sum = LPK == 8 ? across_groups8_sum(sum) : across_groups16_sum(sum);
 #pragma unroll
-  for (int o = LPK; o < 64; o <<= 1) {
-#pragma unroll
-    for (int e = 0; e < UNIT; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
-  }
+  for (int e = 0; e < UNIT; ++e) acc[e] = LPK == 8 ? across_groups8_sum(acc[e]) : across_groups16_sum(acc[e]);
   if (ks == 0) {
 #pragma unroll
     for (int e = 0; e < UNIT; ++e) red[wave][cu * UNIT + e] = acc[e];
   }
+  if (lane == 0) reds[wave] = sum;
   __syncthreads();
+  WH_PROBE_AT(a, wgid, 3);
   if (tid < 64) {
     const float o = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-    const float l = redm[0] + redm[1] + redm[2] + redm[3];
+    const float l = reds[0] + reds[1] + reds[2] + reds[3];
     if (S == 1) {
       ((T*)a.out)[(int64_t)r * a.o_ld + h * 64 + tid] = from_f32<T>(o / l);
     } else {
@@ -389,6 +393,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(whk::DecAttnArgs a) {
       }
     }
   }
+  WH_PROBE_AT(a, wgid, 4);
 }
 
 // =============================================================================================
@@ -430,13 +435,28 @@ hipError_t launch_attn_flash_f16(const void* q, int64_t q_ld, int64_t q_bs, cons
   return hipGetLastError();
 }
 
-hipError_t launch_attn_decode(const DecAttnArgs& a, int dtype, hipStream_t stream) {
-  const int maxk = a.d_len ? 4096 : a.Tk;
-  (void)maxk;
+int attn_decode_capacity(int dtype) { return dtype == 1 ? 4 * 8 * DEC_NL : 4 * 4 * DEC_NL; }
+
+template <typename T>
+static hipError_t launch_attn_decode_t(const DecAttnArgs& a, hipStream_t stream) {
+  constexpr int KPL = 4 * ET<T>::UNIT;            // keys per wave-load round of the workgroup (32 fp16 / 16 fp32)
   dim3 grid(a.splits, a.H, a.R), block(256);
-  if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((attn_decode_kernel<float>), grid, block, 0, stream, a);
+  int rounds = DEC_NL;                            // cached length unknown at capture time: full tile
+  if (!a.d_len) {
+    const int chunk = (a.Tk + a.splits - 1) / a.splits;
+    rounds = (chunk + KPL - 1) / KPL;
+    if (rounds > DEC_NL) return hipErrorInvalidValue;
+  }
+  if (rounds <= 8) hipLaunchKernelGGL((attn_decode_kernel<T, 8>), grid, block, 0, stream, a);
+  else if (rounds <= 12) hipLaunchKernelGGL((attn_decode_kernel<T, 12>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((attn_decode_kernel<T, DEC_NL>), grid, block, 0, stream, a);
   return hipGetLastError();
+}
+
+hipError_t launch_attn_decode(const DecAttnArgs& a, int dtype, hipStream_t stream) {
+  // a split must fit the register-resident K/V tile: callers size `splits` with attn_decode_capacity()
+  if (a.splits < 1 || a.splits > DEC_ATTN_MAX_SPLITS) return hipErrorInvalidValue;
+  return dtype == 1 ? launch_attn_decode_t<half_t>(a, stream) : launch_attn_decode_t<float>(a, stream);
 }
 
 hipError_t launch_cross_qk(const void* q, int64_t q_ld, const void* k, int64_t k_ld, int head, int n_tok,

@@ -57,17 +57,76 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// wave reductions (64 lanes)
+// cross-lane exchange without LDS.  __shfl_xor compiles to ds_bpermute_b32 (an LDS-pipe round trip of
+// ~100 cycles per step); a latency-bound decode kernel cannot afford 6 of those per reduction.  On
+// gfx950 every xor distance has a VALU form:
+//   xor 1, 2   DPP quad_perm            xor 8   DPP row_ror:8 (rotation by half a 16-lane row)
+//   xor 16     v_permlane16_swap        xor 32  v_permlane32_swap
+//   xor 4      has no exact DPP form on gfx9-class DPP; row_half_mirror (lane i <-> 7-i of each 8) is
+//              used instead, which is a valid butterfly step only when the lanes of each quad already
+//              agree (i.e. right after the xor 1, xor 2 steps of a reduction) — group8_sum / wave_sum.
+// The xor 8 / 16 / 32 steps are exact exchanges: across_groups*_sum may be applied to per-lane-distinct
+// data (the decode attention reduces 8 different head dims per key group this way).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_mov<0xB1>(v); }     // quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float v) { return dpp_mov<0x4E>(v); }     // quad_perm [2,3,0,1]
+__device__ __forceinline__ float lane_mirror8(float v) { return dpp_mov<0x141>(v); }  // row_half_mirror
+__device__ __forceinline__ float lane_xor8(float v) { return dpp_mov<0x128>(v); }     // row_ror:8 == xor 8 exactly
+// value held by the partner row (xor 16) / partner half (xor 32), given both copies start equal
+__device__ __forceinline__ void lane_swap16(float v, float& a, float& b) {
+  typedef unsigned uint2s __attribute__((ext_vector_type(2)));
+  const uint2s r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void lane_swap32(float v, float& a, float& b) {
+  typedef unsigned uint2s __attribute__((ext_vector_type(2)));
+  const uint2s r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+
+// sum / max over groups of 8, 16 or 64 lanes; every lane of the group ends with the result
+__device__ __forceinline__ float group8_sum(float v) {
+  v += lane_xor1(v); v += lane_xor2(v); v += lane_mirror8(v);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float group16_sum(float v) {
+  v = group8_sum(v); v += lane_xor8(v);
   return v;
+}
+// reduce across the 8 (or 4) groups of a wave once each group already agrees internally
+__device__ __forceinline__ float across_groups8_sum(float v) {   // groups of 8 lanes -> wave
+  float a, b;
+  v += lane_xor8(v);
+  lane_swap16(v, a, b); v = a + b;
+  lane_swap32(v, a, b); v = a + b;
+  return v;
+}
+__device__ __forceinline__ float across_groups16_sum(float v) {  // groups of 16 lanes -> wave
+  float a, b;
+  lane_swap16(v, a, b); v = a + b;
+  lane_swap32(v, a, b); v = a + b;
+  return v;
+}
+__device__ __forceinline__ float across_groups8_max(float v) {
+  float a, b;
+  v = fmaxf(v, lane_xor8(v));
+  lane_swap16(v, a, b); v = fmaxf(a, b);
+  lane_swap32(v, a, b); v = fmaxf(a, b);
+  return v;
+}
+__device__ __forceinline__ float across_groups16_max(float v) {
+  float a, b;
+  lane_swap16(v, a, b); v = fmaxf(a, b);
+  lane_swap32(v, a, b); v = fmaxf(a, b);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return across_groups8_sum(group8_sum(v)); }
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, lane_xor1(v)); v = fmaxf(v, lane_xor2(v)); v = fmaxf(v, lane_mirror8(v));
+  return across_groups8_max(v);
 }
 
 // ---------------------------------------------------------------------------------------------

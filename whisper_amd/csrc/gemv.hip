@@ -3,17 +3,26 @@
 // (whisper/model.py:44-50) at T = 1, i.e. TextDecoder.forward (model.py:227-249) inside
 // DecodingTask._main_loop (whisper/decoding.py:686-687) — the HBM-bound part of the path: every
 // decoder weight is streamed from HBM exactly once per step for the whole batch.  No MFMA here: the
-// arithmetic intensity is R FLOP/byte; the job is to keep >= 10 KB of 16-byte loads in flight per CU.
+// arithmetic intensity is R FLOP/byte.
 //
-// Workgroup = 256 threads (4 waves) owns 8 consecutive output features.  A wave instruction loads
-// 8 rows x 128 contiguous bytes of W (8 lanes x 16 B per row: whole cache lines, fully coalesced); the
-// four waves split K; five such loads are issued back-to-back before any is consumed.  x (after the
-// fused prologue) sits in LDS in the element type and is read with broadcast ds_read_b128; products are
-// v_dot2_f32_f16 (fp32 accumulate).  Partial sums are reduced over the 8 lanes of a row with
-// xor-shuffles, over the 4 waves through LDS, and the epilogue is applied by 8*R threads.
+// A decode-step matrix is tiny next to the machine (D x D fp16 = 12.8 KB per CU at D = 1280), so a
+// launch is a LATENCY chain, not a bandwidth problem.  The kernel is built around that:
+//   * loads come back in issue order (vmcnt), so the issue order IS the schedule: first the few
+//     L2-resident operands the prologue and the epilogue need (x rows, LayerNorm parameters, attention
+//     partials, bias, residual), then the wave's whole share of the weight tile (up to NU = 10 x 16 B
+//     per lane, non-temporal).  The prologue arithmetic then runs while the weights are in flight;
+//   * the LayerNorm prologue is single-pass: a wave holds a whole fp32 row in registers
+//     (K / 64 floats per lane), so mean / variance / normalise cost one L2 round trip;
+//   * x sits in LDS in the element type and is read back with conflict-free broadcast ds_read_b128;
+//     products are v_dot2_f32_f16 with fp32 accumulation;
+//   * a wave-load covers 64 / LPR weight rows x LPR*16 contiguous bytes (LPR = 8 -> 128 B lines,
+//     LPR = 16 -> 256 B for K >= 2048 so that N = D matrices still give >= 320 workgroups);
+//     the four waves of a workgroup split K; partial sums meet in LDS;
+//   * a workgroup may walk several feature groups (logits: V = 51866 rows) re-using the staged x,
+//     with the next group's weights already in flight (double-buffered registers).
 //
 // Fused prologues: plain copy | LayerNorm of the fp32 residual stream (model.py:39-41) |
-//                  merge of split-K cross-attention partials (attention.hip, attn_decode).
+//                  merge of split-K attention partials (attention.hip, attn_decode).
 // Fused epilogues: store | q + in-place KV-cache append (replaces torch.cat, model.py:332) |
 //                  residual add | exact GELU | fp32 logits.
 #include "common.h"
@@ -21,193 +30,418 @@
 
 namespace {
 
-constexpr int NB = 8;          // output features per workgroup
-constexpr int UNROLL = 5;      // weight loads in flight per lane
-constexpr int XS_BUDGET = 96 * 1024;
+// compiler-only fence: the machine scheduler otherwise hoists the (independent) weight loads above the
+// prologue's own loads, and loads return in issue order
+#define ISSUE_FENCE() asm volatile("" ::: "memory")
 
-template <typename T, int RT>
-__global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int kseg) {
+constexpr int NU = 10;         // weight units (16 B) in flight per lane per buffer
+constexpr int CT = 10;         // PRO_COMBINE fast path: (row, head, 4 dims) tasks per thread ...
+constexpr int CS = 4;          // ... and splits held in registers
+
+template <typename T> struct Pack4;
+template <> struct Pack4<float> {
+  static __device__ __forceinline__ void store(float* p, float a, float b, float c, float d) {
+    *(float4v*)p = float4v{a, b, c, d};
+  }
+};
+template <> struct Pack4<half_t> {
+  static __device__ __forceinline__ void store(half_t* p, float a, float b, float c, float d) {
+    *(half4v*)p = half4v{(half_t)a, (half_t)b, (half_t)c, (half_t)d};
+  }
+};
+
+// PRO: prologue kind (whk::PRO_*), LNJ: float4 per lane per row held by the LayerNorm prologue (K <= 256*LNJ)
+// MULTI: the workgroup walks more than one (feature group, K batch) item -> second weight buffer
+template <typename T, int RT, int LPR, int PRO, int LNJ, bool MULTI>
+__global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int red_alias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename ET<T>::unit_t unit_t;
   constexpr int UNIT = ET<T>::UNIT;
-  T* xs = (T*)smem;                                  // [RT][kseg]
-  float* red = (float*)(smem + (size_t)RT * kseg * sizeof(T));   // [4][NB][RT]
+  constexpr int NB = 64 / LPR;           // output features per group (= weight rows per wave-load)
+  constexpr int BLK = LPR * UNIT;        // K elements covered by one wave-load
+  constexpr int NR = RT >= 8 ? 2 : 1;    // LayerNorm rows per wave per pass
+  constexpr int XJ = LNJ;                // PRO_PLAIN: 16-byte units per thread per row (K <= 256 * XJ * UNIT)
+  const int K = a.K;
+  T* xs = (T*)smem;                                              // [RT][K]
+  // cross-wave partial sums [4][NB][RT]; aliases xs when the workgroup owns a single feature group
+  float* red = red_alias ? (float*)smem : (float*)(smem + (size_t)RT * K * sizeof(T));
+  float* csc = red + 4 * NB * RT;                                // PRO_COMBINE: [RT*H][CS] merge weights
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * NB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sub = lane % LPR, fr = lane / LPR;
   const int r0 = blockIdx.y * RT;
   int R = a.R - r0; if (R > RT) R = RT;
-  const int K = a.K;
+  const int nblk = K / BLK;
+  const int nbatch = ((nblk + 3) / 4 + NU - 1) / NU;       // batches of NU wave-loads per group (uniform)
+  const int ngroups = (a.N + NB - 1) / NB;
+  const int g0 = blockIdx.x * gp;
+  int g1 = g0 + gp; if (g1 > ngroups) g1 = ngroups;
+  const int total = (g1 - g0) * nbatch;
+  const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
+  (void)wgid;
+  WH_PROBE_AT(a, wgid, 0);
+
+  auto load_item = [&](int it, unit_t* w) {
+    const int g = g0 + it / nbatch, b = it - (it / nbatch) * nbatch;
+    int n = g * NB + fr; if (n > a.N - 1) n = a.N - 1;
+    const T* base = (const T*)a.W + (int64_t)n * K + sub * UNIT;
+    // branch-free: a predicated load with a zero-fill else-arm makes the compiler drain vmcnt at the join,
+    // which would serialise the whole prologue behind the weight stream.  Out-of-range slots re-read the
+    // last block (valid address) and are skipped by compute_item.
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      int ub = wave + 4 * (b * NU + u); if (ub > nblk - 1) ub = nblk - 1;
+      w[u] = __builtin_nontemporal_load((const unit_t*)(base + (size_t)ub * BLK));
+    }
+  };
+  unit_t wa[NU], wb[MULTI ? NU : 1];
+
+  // epilogue operands of the first group, requested ahead of the weights
+  const int ej = tid % NB, er = tid / NB;
+  float e_bias = 0.f, e_res = 0.f;
+  if (tid < NB * R) {
+    const int n = g0 * NB + ej;
+    if (n < a.N) {
+      if (a.bias) e_bias = a.bias[n];
+      if (a.epi == whk::EPI_RESID) e_res = a.resid[(int64_t)(r0 + er) * a.resid_ld + n];
+    }
+  }
+
+  // ---------------------------------------------------------------------- prologue -> xs
+  if (PRO == whk::PRO_PLAIN) {
+    // row-major staging without integer divisions: thread t moves units t, t+256, ... of every row
+    const int upr = K / UNIT;
+    unit_t xv[RT][XJ];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      const T* src = (const T*)a.x + (int64_t)(r0 + (r < R ? r : R - 1)) * a.x_ld;   // padded rows re-read a valid row
+#pragma unroll
+      for (int j = 0; j < XJ; ++j) {
+        int u = j * 256 + tid; if (u > upr - 1) u = upr - 1;                          // branch-free, clamped
+        xv[r][j] = *(const unit_t*)(src + u * UNIT);
+      }
+    }
+    ISSUE_FENCE(); load_item(0, wa); ISSUE_FENCE(); WH_PROBE_AT(a, wgid, 1);
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+#pragma unroll
+      for (int j = 0; j < XJ; ++j) {
+        const int u = j * 256 + tid;
+        if (u < upr) {
+          unit_t v = xv[r][j];
+          if (r >= R) {
+#pragma unroll
+            for (int e = 0; e < UNIT; ++e) v[e] = 0;
+          }
+          *(unit_t*)(xs + (size_t)r * K + u * UNIT) = v;
+        }
+      }
+    }
+  } else if (PRO == whk::PRO_LN) {
+    // single pass: rows wave, wave+4 (and +8, +12 for RT = 16) live in registers
+#pragma unroll
+    for (int rb = 0; rb < RT; rb += 4 * NR) {
+      float4v v[NR][LNJ], w4[LNJ], b4[LNJ];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int r = rb + wave + 4 * i;
+        const float* src = a.xf + (int64_t)(r0 + (r < R ? r : 0)) * a.xf_ld;
+#pragma unroll
+        for (int j = 0; j < LNJ; ++j) {
+          int k = (j * 64 + lane) * 4; if (k > K - 4) k = K - 4;      // branch-free; masked at use
+          v[i][j] = *(const float4v*)(src + k);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < LNJ; ++j) {
+        int k = (j * 64 + lane) * 4; if (k > K - 4) k = K - 4;
+        w4[j] = *(const float4v*)(a.ln_w + k);
+        b4[j] = *(const float4v*)(a.ln_b + k);
+      }
+      if (rb == 0) { ISSUE_FENCE(); load_item(0, wa); ISSUE_FENCE(); WH_PROBE_AT(a, wgid, 1); }
+      const float invK = 1.0f / (float)K;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int r = rb + wave + 4 * i;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < LNJ; ++j) {
+          const float t = (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
+          s += ((j * 64 + lane) * 4 < K) ? t : 0.f;
+        }
+        const float mean = wave_sum(s) * invK;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < LNJ; ++j) {
+          const int k = (j * 64 + lane) * 4;
+          if (k < K) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][j][e] - mean; ss = __builtin_fmaf(d, d, ss); }
+          }
+        }
+        const float rstd = rsqrtf(wave_sum(ss) * invK + 1e-5f);
+        T* xr = xs + (size_t)r * K;
+#pragma unroll
+        for (int j = 0; j < LNJ; ++j) {
+          const int k = (j * 64 + lane) * 4;
+          if (k < K) {
+            if (r < R)
+              Pack4<T>::store(xr + k, (v[i][j][0] - mean) * rstd * w4[j][0] + b4[j][0],
+                              (v[i][j][1] - mean) * rstd * w4[j][1] + b4[j][1],
+                              (v[i][j][2] - mean) * rstd * w4[j][2] + b4[j][2],
+                              (v[i][j][3] - mean) * rstd * w4[j][3] + b4[j][3]);
+            else
+              Pack4<T>::store(xr + k, 0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      }
+    }
+  } else {  // PRO_COMBINE: merge split-K attention partials (m, l, o[64]) per (row, head); K == H * 64
+    const int S = a.splits, H = a.H;
+    const int per_row = H * 16, ntask = RT * per_row;
+    const bool fast = S <= CS && ntask <= 256 * CT && RT * H <= 256;
+    if (fast) {
+      // all partial sums requested before the weights; scale factors exp(m_s - M) / den via LDS
+      float4v o[CT][CS];
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        int i = j * 256 + tid; if (i > ntask - 1) i = ntask - 1;       // branch-free loads, clamped
+        int r = i / per_row; const int rem = i - r * per_row;
+        if (r > R - 1) r = R - 1;
+        const int h = rem >> 4, d4 = rem & 15;
+        const int64_t pb = ((int64_t)(r0 + r) * H + h) * S;
+#pragma unroll
+        for (int s = 0; s < CS; ++s)
+          o[j][s] = *(const float4v*)(a.part_o + (pb + (s < S ? s : S - 1)) * 64 + d4 * 4);
+      }
+      float2v ml[CS];
+      const int pt = tid < RT * H ? tid : RT * H - 1;
+      const int pr = pt / H, ph = pt - pr * H;                   // one (row, head) pair per thread
+      const bool pair = tid < RT * H && pr < R;
+#pragma unroll
+      for (int s = 0; s < CS; ++s)
+        ml[s] = *(const float2v*)(a.part_ml + (((int64_t)(r0 + (pr < R ? pr : R - 1)) * H + ph) * S + (s < S ? s : S - 1)) * 2);
+      ISSUE_FENCE(); load_item(0, wa); ISSUE_FENCE(); WH_PROBE_AT(a, wgid, 1);
+#pragma unroll
+      for (int s = 0; s < CS; ++s)
+        if (s >= S) ml[s] = float2v{WH_NEG_INF, 0.f};
+      if (tid < RT * H) {
+        float M = WH_NEG_INF;
+#pragma unroll
+        for (int s = 0; s < CS; ++s) M = fmaxf(M, ml[s][0]);
+        float w[CS], den = 0.f;
+#pragma unroll
+        for (int s = 0; s < CS; ++s) { w[s] = (ml[s][0] == WH_NEG_INF) ? 0.f : __expf(ml[s][0] - M); den = __builtin_fmaf(w[s], ml[s][1], den); }
+        const float inv = pair ? 1.0f / den : 0.f;
+#pragma unroll
+        for (int s = 0; s < CS; ++s) csc[tid * CS + s] = w[s] * inv;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const int i = j * 256 + tid;
+        if (i < ntask) {
+          const int r = i / per_row, rem = i - r * per_row;
+          const int h = rem >> 4, d4 = rem & 15;
+          const float* f = csc + (r * H + h) * CS;
+          float4v num = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < CS; ++s) {
+            const float w = f[s];
+            num[0] = __builtin_fmaf(w, o[j][s][0], num[0]); num[1] = __builtin_fmaf(w, o[j][s][1], num[1]);
+            num[2] = __builtin_fmaf(w, o[j][s][2], num[2]); num[3] = __builtin_fmaf(w, o[j][s][3], num[3]);
+          }
+          Pack4<T>::store(xs + (size_t)r * K + h * 64 + d4 * 4, num[0], num[1], num[2], num[3]);
+        }
+      }
+    } else {
+      // generic path (many splits / wide rows): merge first, then start the weight stream
+      for (int i = tid; i < ntask; i += 256) {
+        const int r = i / per_row, rem = i - r * per_row;
+        const int h = rem >> 4, d4 = rem & 15;
+        float4v num = {0.f, 0.f, 0.f, 0.f};
+        float den = 1.f;
+        if (r < R) {
+          const int64_t pb = ((int64_t)(r0 + r) * H + h) * S;
+          float M = WH_NEG_INF;
+          for (int s = 0; s < S; ++s) M = fmaxf(M, a.part_ml[(pb + s) * 2]);
+          den = 0.f;
+          for (int s = 0; s < S; ++s) {
+            const float2v ml = *(const float2v*)(a.part_ml + (pb + s) * 2);
+            const float w = __expf(ml[0] - M);
+            const float4v o = *(const float4v*)(a.part_o + (pb + s) * 64 + d4 * 4);
+            num[0] = __builtin_fmaf(w, o[0], num[0]); num[1] = __builtin_fmaf(w, o[1], num[1]);
+            num[2] = __builtin_fmaf(w, o[2], num[2]); num[3] = __builtin_fmaf(w, o[3], num[3]);
+            den = __builtin_fmaf(w, ml[1], den);
+          }
+        }
+        const float inv = 1.0f / den;
+        Pack4<T>::store(xs + (size_t)r * K + h * 64 + d4 * 4, num[0] * inv, num[1] * inv, num[2] * inv, num[3] * inv);
+      }
+      load_item(0, wa);
+    }
+  }
+  WH_PROBE_AT(a, wgid, 2);
+  __syncthreads();
+  WH_PROBE_AT(a, wgid, 3);
 
   float acc[RT];
 #pragma unroll
   for (int r = 0; r < RT; ++r) acc[r] = 0.f;
 
-  int wrow = n0 + (lane >> 3); if (wrow > a.N - 1) wrow = a.N - 1;
-  const T* wp = (const T*)a.W + (int64_t)wrow * K + (lane & 7) * UNIT;
+  // x of weight unit u for all rows, read one unit ahead of the dot products
+  auto compute_item = [&](int it, const unit_t* w) {
+    const int b = it - (it / nbatch) * nbatch;
+    unit_t xc[RT], xn[RT];
+    auto fetch = [&](int u, unit_t* x) {
+      int ub = wave + 4 * (b * NU + u); if (ub > nblk - 1) ub = nblk - 1;
+      const T* xb = xs + (size_t)ub * BLK + sub * UNIT;
+#pragma unroll
+      for (int r = 0; r < RT; ++r) x[r] = *(const unit_t*)(xb + (size_t)r * K);
+    };
+    fetch(0, xc);
+#pragma unroll
+    for (int u = 0; u < NU; u += 2) {
+      if (u + 1 < NU) fetch(u + 1, xn);
+      if (wave + 4 * (b * NU + u) < nblk) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = dot_unit(w[u], xc[r], acc[r]);
+      }
+      if (u + 2 < NU) fetch(u + 2, xc);
+      if (u + 1 < NU && wave + 4 * (b * NU + u + 1) < nblk) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = dot_unit(w[u + 1], xn[r], acc[r]);
+      }
+    }
+  };
 
-  for (int ks = 0; ks < K; ks += kseg) {
-    const int klen = (K - ks) < kseg ? (K - ks) : kseg;
-    if (ks > 0) __syncthreads();
-    // ------------------------------------------------------------------ prologue -> xs
-    if (a.pro == whk::PRO_PLAIN) {
-      const int upr = klen / UNIT;
-      for (int i = tid; i < RT * upr; i += 256) {
-        const int r = i / upr, u = i - r * upr;
-        unit_t v;
-        if (r < R) v = *(const unit_t*)((const T*)a.x + (int64_t)(r0 + r) * a.x_ld + ks + u * UNIT);
-        else {
+  auto finish_group = [&](int it) {
+    const int g = g0 + it / nbatch;
 #pragma unroll
-          for (int e = 0; e < UNIT; ++e) v[e] = 0;
-        }
-        *(unit_t*)(xs + (size_t)r * kseg + u * UNIT) = v;
-      }
-    } else if (a.pro == whk::PRO_LN) {
-      // one wave per row: fp32 statistics exactly as layer_norm (mean, biased variance, eps 1e-5)
-      for (int r = wave; r < RT; r += 4) {
-        T* xr = xs + (size_t)r * kseg;
-        if (r >= R) {
-          for (int k = lane; k < K; k += 64) xr[k] = from_f32<T>(0.f);
-          continue;
-        }
-        const float* src = a.xf + (int64_t)(r0 + r) * a.xf_ld;
-        float s = 0.f;
-        for (int k = lane * 4; k < K; k += 256) {
-          const float4v t = *(const float4v*)(src + k);
-          s += (t[0] + t[1]) + (t[2] + t[3]);
-        }
-        s = wave_sum(s);
-        const float mean = s / (float)K;
-        float ss = 0.f;
-        for (int k = lane * 4; k < K; k += 256) {
-          const float4v t = *(const float4v*)(src + k);
+    for (int r = 0; r < RT; ++r) {
+      acc[r] = LPR == 8 ? group8_sum(acc[r]) : group16_sum(acc[r]);
+    }
+    if (red_alias) __syncthreads();           // every wave is done reading xs before `red` overwrites it
+    if (sub == 0) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const float d = t[e] - mean; ss = __builtin_fmaf(d, d, ss); }
-        }
-        ss = wave_sum(ss);
-        const float rstd = rsqrtf(ss / (float)K + 1e-5f);
-        for (int k = lane * 4; k < K; k += 256) {
-          const float4v t = *(const float4v*)(src + k);
-          const float4v w4 = *(const float4v*)(a.ln_w + k);
-          const float4v b4 = *(const float4v*)(a.ln_b + k);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xr[k + e] = from_f32<T>((t[e] - mean) * rstd * w4[e] + b4[e]);
-        }
-      }
-    } else {  // PRO_COMBINE: merge split-K attention partials (m, l, o[64]) per (row, head)
-      const int S = a.splits;
-      for (int i = tid; i < RT * K; i += 256) {
-        const int r = i / K, c = i - r * K;
-        float v = 0.f;
-        if (r < R) {
-          const int h = c >> 6, d = c & 63;
-          const int64_t pb = ((int64_t)(r0 + r) * a.H + h) * S;
-          float M = WH_NEG_INF;
-          for (int s = 0; s < S; ++s) M = fmaxf(M, a.part_ml[(pb + s) * 2]);
-          float num = 0.f, den = 0.f;
-          for (int s = 0; s < S; ++s) {
-            const float w = __expf(a.part_ml[(pb + s) * 2] - M);
-            num = __builtin_fmaf(w, a.part_o[(pb + s) * 64 + d], num);
-            den = __builtin_fmaf(w, a.part_ml[(pb + s) * 2 + 1], den);
-          }
-          v = num / den;
-        }
-        xs[(size_t)r * kseg + c] = from_f32<T>(v);
-      }
+      for (int r = 0; r < RT; ++r) red[(wave * NB + fr) * RT + r] = acc[r];
     }
     __syncthreads();
-
-    // ------------------------------------------------------------------ stream W
-    const int nub = klen / (8 * UNIT);            // blocks of 8 units (128 bytes per row)
-    const T* wseg = wp + ks;
-    for (int ub0 = wave; ub0 < nub; ub0 += 4 * UNROLL) {
-      unit_t w[UNROLL];
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const int ub = ub0 + 4 * u;
-        if (ub < nub) w[u] = __builtin_nontemporal_load((const unit_t*)(wseg + (size_t)ub * 8 * UNIT));
-        else {
-#pragma unroll
-          for (int e = 0; e < UNIT; ++e) w[u][e] = 0;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const int ub = ub0 + 4 * u;
-        if (ub < nub) {
-          const T* xb = xs + (size_t)(ub * 8 + (lane & 7)) * UNIT;
-#pragma unroll
-          for (int r = 0; r < RT; ++r) {
-            const unit_t xu = *(const unit_t*)(xb + (size_t)r * kseg);
-            acc[r] = dot_unit(w[u], xu, acc[r]);
-          }
+    if (tid < NB * R) {
+      const int n = g * NB + ej;
+      if (n < a.N) {
+        float v = red[(0 * NB + ej) * RT + er] + red[(1 * NB + ej) * RT + er] + red[(2 * NB + ej) * RT + er] +
+                  red[(3 * NB + ej) * RT + er];
+        const int64_t rr = r0 + er;
+        if (g == g0) v += e_bias;
+        else if (a.bias) v += a.bias[n];
+        switch (a.epi) {
+          case whk::EPI_STORE: ((T*)a.y)[rr * a.y_ld + n] = from_f32<T>(v); break;
+          case whk::EPI_GELU: ((T*)a.y)[rr * a.y_ld + n] = from_f32<T>(gelu_erf(v)); break;
+          case whk::EPI_F32: ((float*)a.y)[rr * a.y_ld + n] = v; break;
+          case whk::EPI_RESID:
+            a.resid[rr * a.resid_ld + n] = (g == g0 ? e_res : a.resid[rr * a.resid_ld + n]) + v;
+            break;
+          case whk::EPI_QKV: {
+            const int D = a.D;
+            if (n < D) ((T*)a.y)[rr * a.y_ld + n] = from_f32<T>(v);
+            else {
+              const int64_t pos = *a.d_pos;
+              if (n < 2 * D) ((T*)a.kcache)[rr * a.cache_bs + pos * D + (n - D)] = from_f32<T>(v);
+              else ((T*)a.vcache)[rr * a.cache_bs + pos * D + (n - 2 * D)] = from_f32<T>(v);
+            }
+          } break;
         }
       }
     }
-  }
-
-  // ---------------------------------------------------------------------- reduce
 #pragma unroll
-  for (int r = 0; r < RT; ++r) {
-    float v = acc[r];
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    acc[r] = v;
-  }
-  if ((lane & 7) == 0) {
-#pragma unroll
-    for (int r = 0; r < RT; ++r) red[(wave * NB + (lane >> 3)) * RT + r] = acc[r];
-  }
-  __syncthreads();
+    for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+    if (it + 1 < total) __syncthreads();      // `red` is reused by the next group
+  };
 
-  // ---------------------------------------------------------------------- epilogue
-  for (int t = tid; t < NB * R; t += 256) {
-    const int j = t & (NB - 1), r = t >> 3;
-    const int n = n0 + j;
-    if (n >= a.N) continue;
-    float v = red[(0 * NB + j) * RT + r] + red[(1 * NB + j) * RT + r] + red[(2 * NB + j) * RT + r] +
-              red[(3 * NB + j) * RT + r];
-    if (a.bias) v += a.bias[n];
-    const int64_t rr = r0 + r;
-    switch (a.epi) {
-      case whk::EPI_STORE: ((T*)a.y)[rr * a.y_ld + n] = from_f32<T>(v); break;
-      case whk::EPI_GELU: ((T*)a.y)[rr * a.y_ld + n] = from_f32<T>(gelu_erf(v)); break;
-      case whk::EPI_F32: ((float*)a.y)[rr * a.y_ld + n] = v; break;
-      case whk::EPI_RESID: a.resid[rr * a.resid_ld + n] += v; break;
-      case whk::EPI_QKV: {
-        const int D = a.D;
-        if (n < D) ((T*)a.y)[rr * a.y_ld + n] = from_f32<T>(v);
-        else {
-          const int64_t pos = *a.d_pos;
-          if (n < 2 * D) ((T*)a.kcache)[rr * a.cache_bs + pos * D + (n - D)] = from_f32<T>(v);
-          else ((T*)a.vcache)[rr * a.cache_bs + pos * D + (n - 2 * D)] = from_f32<T>(v);
-        }
-      } break;
+  if (MULTI) {
+    for (int it = 0; it < total; it += 2) {
+      if (it + 1 < total) load_item(it + 1, wb);
+      compute_item(it, wa);
+      if (it == 0) WH_PROBE_AT(a, wgid, 4);
+      if ((it + 1) % nbatch == 0) finish_group(it);
+      if (it == 0) WH_PROBE_AT(a, wgid, 5);
+      if (it + 1 < total) {
+        if (it + 2 < total) load_item(it + 2, wa);
+        compute_item(it + 1, wb);
+        if ((it + 2) % nbatch == 0) finish_group(it + 1);
+      }
     }
+  } else if (total > 0) {
+    compute_item(0, wa);
+    WH_PROBE_AT(a, wgid, 4);
+    finish_group(0);
+    WH_PROBE_AT(a, wgid, 5);
   }
+
+  WH_PROBE_AT(a, wgid, 6);
+  if (a.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.bump, a.bump_by);
+}
+
+template <typename T, int RT, int LPR, int PRO, int LNJ, bool MULTI>
+hipError_t launch_cfg(const whk::GemvArgs& a, int gp, hipStream_t stream) {
+  constexpr int NB = 64 / LPR;
+  const int ngroups = (a.N + NB - 1) / NB;
+  const int red_alias = (gp == 1 && PRO != whk::PRO_COMBINE) ? 1 : 0;
+  size_t lds = (size_t)RT * a.K * sizeof(T);
+  if (!red_alias) lds += 4 * NB * RT * sizeof(float);
+  if (PRO == whk::PRO_COMBINE) lds += (size_t)RT * a.H * CS * sizeof(float);   // merge weights behind `red`
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemv_kernel<T, RT, LPR, PRO, LNJ, MULTI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid((ngroups + gp - 1) / gp, (a.R + RT - 1) / RT), block(256);
+  hipLaunchKernelGGL((gemv_kernel<T, RT, LPR, PRO, LNJ, MULTI>), grid, block, lds, stream, a, gp, red_alias);
+  return hipGetLastError();
+}
+
+template <typename T, int RT, int LPR, bool MULTI>
+hipError_t launch_pro(const whk::GemvArgs& a, int gp, hipStream_t stream) {
+  switch (a.pro) {
+    case whk::PRO_PLAIN: {
+      const int upr = a.K / ET<T>::UNIT;            // LNJ doubles as units-per-thread-per-row here
+      if (upr <= 256) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 1, MULTI>(a, gp, stream);
+      if (upr <= 768) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 3, MULTI>(a, gp, stream);
+      if (upr <= 1536) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 6, MULTI>(a, gp, stream);
+      return hipErrorInvalidValue;
+    }
+    case whk::PRO_LN:
+      if (a.K <= 256 * 5) return launch_cfg<T, RT, LPR, whk::PRO_LN, 5, MULTI>(a, gp, stream);
+      if (a.K <= 256 * 8) return launch_cfg<T, RT, LPR, whk::PRO_LN, 8, MULTI>(a, gp, stream);
+      return hipErrorInvalidValue;
+    case whk::PRO_COMBINE:
+      if (a.K != a.H * 64) return hipErrorInvalidValue;
+      return launch_cfg<T, RT, LPR, whk::PRO_COMBINE, 1, MULTI>(a, gp, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+template <typename T, int RT, int LPR>
+hipError_t launch_lpr(const whk::GemvArgs& a, hipStream_t stream) {
+  constexpr int NB = 64 / LPR, BLK = LPR * ET<T>::UNIT;
+  const int ngroups = (a.N + NB - 1) / NB;
+  const int gp = (ngroups + 1023) / 1024;
+  const int nbatch = ((a.K / BLK + 3) / 4 + NU - 1) / NU;
+  if (gp * nbatch > 1) return launch_pro<T, RT, LPR, true>(a, gp, stream);
+  return launch_pro<T, RT, LPR, false>(a, gp, stream);
 }
 
 template <typename T, int RT>
 hipError_t launch_rt(const whk::GemvArgs& a, hipStream_t stream) {
   constexpr int UNIT = ET<T>::UNIT;
-  const int quantum = 32 * UNIT;                       // 4 waves x 8 units
+  if (a.K >= 2048 && a.K % (16 * UNIT) == 0) return launch_lpr<T, RT, 16>(a, stream);
   if (a.K % (8 * UNIT) != 0) return hipErrorInvalidValue;
-  int kseg = XS_BUDGET / (RT * (int)sizeof(T));
-  kseg = (kseg / quantum) * quantum;
-  if (kseg >= a.K) kseg = a.K;
-  else if (a.pro != whk::PRO_PLAIN) return hipErrorInvalidValue;   // LN / combine need the whole row
-  const size_t lds = (size_t)RT * kseg * sizeof(T) + 4 * NB * RT * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemv_kernel<T, RT>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, XS_BUDGET + 8192);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  dim3 grid((a.N + NB - 1) / NB, (a.R + RT - 1) / RT), block(256);
-  hipLaunchKernelGGL((gemv_kernel<T, RT>), grid, block, lds, stream, a, kseg);
-  return hipGetLastError();
+  return launch_lpr<T, RT, 8>(a, stream);
 }
 
 }  // namespace
@@ -218,13 +452,11 @@ hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream) {
   if (a.R <= 0) return hipErrorInvalidValue;
   if (dtype == 1) {
     if (a.R <= 4) return launch_rt<half_t, 4>(a, stream);
-    if (a.R <= 8) return launch_rt<half_t, 8>(a, stream);
-    if (a.R <= 16) return launch_rt<half_t, 16>(a, stream);
-    return launch_rt<half_t, 32>(a, stream);
+    return launch_rt<half_t, 8>(a, stream);           // R > 8: row tiles of 8 on grid.y
   }
-  if (a.R <= 4) return launch_rt<float, 4>(a, stream);
-  if (a.R <= 8) return launch_rt<float, 8>(a, stream);
-  return launch_rt<float, 16>(a, stream);
+  // fp32 (strict-parity mode): x rows are twice as wide in LDS
+  if (a.R <= 4 || (size_t)a.K * 8 * sizeof(float) > 128 * 1024) return launch_rt<float, 4>(a, stream);
+  return launch_rt<float, 8>(a, stream);
 }
 
 }  // namespace whk

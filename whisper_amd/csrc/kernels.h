@@ -3,6 +3,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// developer probe (tools/probe_decode.cpp builds the kernels with -DWH_PROBE): thread 0 of every
+// workgroup records s_memtime at phase boundaries.  Compiled out of libwhisper_hip.so.
+#ifdef WH_PROBE
+#define WH_PROBE_FIELD long long* probe;
+#define WH_PROBE_AT(args, wg, i) \
+  do { if ((args).probe && threadIdx.x == 0) (args).probe[(size_t)(wg) * 8 + (i)] = clock64(); } while (0)
+#else
+#define WH_PROBE_FIELD
+#define WH_PROBE_AT(args, wg, i) do {} while (0)
+#endif
+
 namespace whk {
 
 // dtype: 0 = fp32, 1 = fp16 (matches WH_F32 / WH_F16)
@@ -75,7 +86,11 @@ struct DecAttnArgs {
   int splits;                                     // key-range splits
   void* out; int64_t o_ld;                        // splits==1: normalized output, element type
   float* part_o; float* part_ml;                  // splits>1: [R][H][S][64], [R][H][S][2]
+  WH_PROBE_FIELD
 };
+constexpr int DEC_ATTN_MAX_SPLITS = 16;
+// keys one workgroup of attn_decode can hold in registers (per split)
+int attn_decode_capacity(int dtype);
 hipError_t launch_attn_decode(const DecAttnArgs& a, int dtype, hipStream_t stream);
 // scores of selected (layer, head) pairs: out[pair][t][j] = scale^2 * q[t]·k[j]
 hipError_t launch_cross_qk(const void* q, int64_t q_ld, const void* k, int64_t k_ld, int head, int n_tok,
@@ -98,6 +113,8 @@ struct GemvArgs {
   void* y; int64_t y_ld;                          // EPI_STORE / EPI_GELU (element type), EPI_F32 (float)
   float* resid; int64_t resid_ld;                 // EPI_RESID: resid[r][n] += y
   void* kcache; void* vcache; int64_t cache_bs; const int* d_pos; int D;  // EPI_QKV
+  int* bump; int bump_by;                         // optional: *bump += bump_by once per launch (position counter)
+  WH_PROBE_FIELD
 };
 hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream);
 
@@ -112,7 +129,9 @@ struct SampleArgs {
   float* sum_logprobs;        // [R]
   int64_t* step_tokens;       // [R] next-step input tokens (may be null)
   int* d_alive_step;          // device: set to ntok by every row whose sampled token is not EOT
+  float* partials;            // scratch: greedy_sample_scratch_bytes(R, V)
 };
+size_t greedy_sample_scratch_bytes(int R, int V);
 hipError_t launch_greedy_sample(const SampleArgs& a, hipStream_t stream);
 hipError_t launch_no_speech(const float* logits_row0, int64_t row_stride, int R, int V, int no_speech,
                             float* out, hipStream_t stream);

@@ -1,10 +1,10 @@
 // sampling.hip — the logits epilogue of DecodingTask._main_loop (whisper/decoding.py:696-703) for
-// greedy decoding, as ONE kernel per step with no host synchronisation:
+// greedy decoding, as two small kernels per step (vocabulary-parallel partials, per-row decision) with
+// no host synchronisation:
 //   SuppressBlank (decoding.py:423-430) -> SuppressTokens (:433-438) -> ApplyTimestampRules (:441-505)
 //   -> GreedyDecoder.update at temperature 0 (:277-293): argmax, log_softmax of the *filtered* logits,
 //   sum_logprobs accumulation for rows not yet at EOT, EOT stickiness.
-// One workgroup per row; a single pass over the fp32 logits keeps separate online (max, sum-exp,
-// arg-max) statistics for the text range [0, timestamp_begin) and the timestamp range, from which the
+// A single pass over the fp32 logits keeps separate online (max, sum-exp, arg-max) statistics for the text range [0, timestamp_begin) and the timestamp range, from which the
 // "timestamp probability mass > best text token" rule (:498-505) and the final normaliser follow
 // without re-reading the row.  The row's token history (needed by the pairing / monotonicity rules)
 // is scanned in parallel.
@@ -41,15 +41,26 @@ __device__ __forceinline__ void stat_wave_reduce(Stat& a) {
   }
 }
 
-__global__ __launch_bounds__(256) void greedy_sample_kernel(whk::SampleArgs a) {
+constexpr int SCHUNK = 1024;    // vocabulary entries per stage-1 workgroup (256 threads x 4)
+
+// Stage 1: grid (chunks, rows).  Applies the filters to one 1024-entry slice of the row and reduces it
+// to two partial statistics (text range, timestamp range): {max, sum exp(x - max), first arg-max}.
+// All four logits of a thread are requested before any is used (one L2 round trip per workgroup).
+__global__ __launch_bounds__(256) void greedy_partial_kernel(whk::SampleArgs a) {
   __shared__ int sh_last_ts;
   __shared__ float sh_m[2][4], sh_s[2][4];
   __shared__ int sh_i[2][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k = blockIdx.x;
-  const int ntok = *a.d_ntok;
-  int64_t* row = a.tokens + (int64_t)k * a.token_stride;
+  const int c = blockIdx.x, k = blockIdx.y;
   const float* x = a.logits + (int64_t)k * a.logits_ld;
+  float xv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int v = c * SCHUNK + j * 256 + tid;
+    xv[j] = v < a.V ? x[v] : WH_NEG_INF;
+  }
+  const int ntok = *a.d_ntok;
+  const int64_t* row = a.tokens + (int64_t)k * a.token_stride;
   const int L = ntok - a.sample_begin;
   const int TB = a.timestamp_begin;       // < 0: timestamp rules disabled (without_timestamps)
   const bool ts_rules = TB >= 0;
@@ -62,7 +73,6 @@ __global__ __launch_bounds__(256) void greedy_sample_kernel(whk::SampleArgs a) {
   }
   __syncthreads();
 
-  const int64_t last_tok = row[ntok - 1];
   bool last_ts = false, pen_ts = false;
   int ts_lo = 0, ts_hi = 0;              // forbidden timestamp interval [ts_lo, ts_hi)
   if (ts_rules) {
@@ -79,7 +89,10 @@ __global__ __launch_bounds__(256) void greedy_sample_kernel(whk::SampleArgs a) {
   Stat st[2];
   st[0] = Stat{WH_NEG_INF, 0.f, 0x7fffffff};
   st[1] = Stat{WH_NEG_INF, 0.f, 0x7fffffff};
-  for (int v = tid; v < a.V; v += 256) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int v = c * SCHUNK + j * 256 + tid;
+    if (v >= a.V) continue;
     bool masked = a.suppress_mask && a.suppress_mask[v];
     if (a.suppress_blank && L == 0 && (v == a.blank_token || v == a.eot)) masked = true;
     if (ts_rules) {
@@ -95,8 +108,41 @@ __global__ __launch_bounds__(256) void greedy_sample_kernel(whk::SampleArgs a) {
       }
     }
     if (masked) continue;
-    const float xv = x[v];
-    if (v < split) stat_add(st[0], xv, v); else stat_add(st[1], xv, v);
+    if (v < split) stat_add(st[0], xv[j], v); else stat_add(st[1], xv[j], v);
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    stat_wave_reduce(st[g]);
+    if (lane == 0) { sh_m[g][wave] = st[g].m; sh_s[g][wave] = st[g].s; sh_i[g][wave] = st[g].idx; }
+  }
+  __syncthreads();
+  if (tid < 2) {
+    Stat t = Stat{WH_NEG_INF, 0.f, 0x7fffffff};
+    for (int w = 0; w < 4; ++w) stat_merge(t, sh_m[tid][w], sh_s[tid][w], sh_i[tid][w]);
+    float* o = a.partials + (((int64_t)k * gridDim.x + c) * 2 + tid) * 4;
+    o[0] = t.m; o[1] = t.s; o[2] = __int_as_float(t.idx);
+  }
+}
+
+// Stage 2: one workgroup per row merges the chunk partials, applies the "timestamp mass" rule and
+// GreedyDecoder.update, and appends the token.
+__global__ __launch_bounds__(256) void greedy_final_kernel(whk::SampleArgs a, int nchunk) {
+  __shared__ float sh_m[2][4], sh_s[2][4];
+  __shared__ int sh_i[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.x;
+  const int ntok = *a.d_ntok;
+  int64_t* row = a.tokens + (int64_t)k * a.token_stride;
+  const bool ts_rules = a.timestamp_begin >= 0;
+  Stat st[2];
+  st[0] = Stat{WH_NEG_INF, 0.f, 0x7fffffff};
+  st[1] = Stat{WH_NEG_INF, 0.f, 0x7fffffff};
+  for (int c = tid; c < nchunk; c += 256) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float* o = a.partials + (((int64_t)k * nchunk + c) * 2 + g) * 4;
+      stat_merge(st[g], o[0], o[1], __float_as_int(o[2]));
+    }
   }
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
@@ -105,6 +151,7 @@ __global__ __launch_bounds__(256) void greedy_sample_kernel(whk::SampleArgs a) {
   }
   __syncthreads();
   if (tid == 0) {
+    const int64_t last_tok = row[ntok - 1];
     Stat tx = Stat{WH_NEG_INF, 0.f, 0x7fffffff}, ts = tx;
     for (int w = 0; w < 4; ++w) {
       stat_merge(tx, sh_m[0][w], sh_s[0][w], sh_i[0][w]);
@@ -174,8 +221,13 @@ __global__ void gather_tokens_kernel(const int64_t* __restrict__ src, int64_t st
 
 namespace whk {
 
+size_t greedy_sample_scratch_bytes(int R, int V) { return (size_t)R * ((V + SCHUNK - 1) / SCHUNK) * 2 * 4 * sizeof(float); }
+
 hipError_t launch_greedy_sample(const SampleArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(greedy_sample_kernel, dim3(a.R), dim3(256), 0, stream, a);
+  const int nchunk = (a.V + SCHUNK - 1) / SCHUNK;
+  if (!a.partials) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(greedy_partial_kernel, dim3(nchunk, a.R), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(greedy_final_kernel, dim3(a.R), dim3(256), 0, stream, a, nchunk);
   return hipGetLastError();
 }
 
