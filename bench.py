@@ -51,6 +51,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=12, help="decode steps timed on the CPU baseline")
+    p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = all usable cores)")
     return p.parse_args()
 
 
@@ -125,6 +126,8 @@ def main():
     audio = synth_audio(B, rank, device)
     task = hip.HipTask(model, B, 1, max(T0, 8))
     tokens = torch.zeros(B, T0 + N + 1, dtype=torch.int64, device=device)
+    init_t = torch.tensor(init, device=device)
+    sot_index = tok.sot_sequence.index(tok.sot)
 
     def one_pass():
         mel = log_mel_spectrogram(audio, dims.n_mels)            # (B, n_mels, 3000) fp32 on device
@@ -132,8 +135,8 @@ def main():
         task.reset()
         task.set_audio(feats)
         tokens.zero_()
-        tokens[:, :T0] = torch.tensor(init, device=device)
-        n, sum_lp, nsp = task.greedy(tokens, params, tok.sot_sequence.index(tok.sot), tok.no_speech)
+        tokens[:, :T0] = init_t
+        n, sum_lp, nsp = task.greedy(tokens, params, sot_index, tok.no_speech)
         return n
 
     def barrier():
@@ -183,9 +186,21 @@ def main():
             log(f"kernel {name}: {ms * 1e3:.1f} us, {nbytes / (ms * 1e-3) / 1e9:.0f} GB/s")
             kern[name] = {"avg_us": round(ms * 1e3, 2), "bytes": nbytes, "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1)}
         dom = kern["attn_decode_cross"]
+        # HBM traffic per launch from the PMC counters: they cannot be read from inside this process, so the
+        # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/, per round),
+        # and only when it was taken on this very workload; otherwise null.
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.isfile(tf) and args.model == "large-v3" and B == 8:
+            with open(tf) as f:
+                pm = json.load(f)["kernels"].get("attn_decode_cross")
+            if pm:
+                traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes_raw"]
         out["roofline"] = {"bound": "hbm", "kernel": "attn_decode_kernel<half> (cross-attention KV stream)",
                            "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 "
+                                             "correction + WRITE_SIZE raw, bytes per launch)" if traffic else None,
                            "bytes_per_launch": dom["bytes"], "avg_us": dom["avg_us"], "all_kernels": kern}
     task.close()
 
@@ -199,12 +214,32 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores() -> int:
+    """host cores this process may really use: affinity mask capped by the cgroup CPU quota (a container that
+    sees 256 CPUs under a 16-CPU quota is throttled ~20x when torch spawns one thread per visible CPU)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota|max> <period>"
+            q, p = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        try:                                                           # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(args, dims, init, suppress, tok, audio_np):
     """Oracle = "port": same algorithm as the reference's CPU fp32 path.  Bounded sample: 1 clip, log-mel +
     encoder + `cpu_steps` decode steps; audio-s/s extrapolated linearly to `sample_len` steps."""
     import oracle
     from whisper_amd.synthetic import synthetic_state_dict
-    cores = os.cpu_count() or 1
+    cores = getattr(args, "cpu_threads", 0) or usable_cores()
     torch.set_num_threads(cores)
     log(f"cpu_baseline: building {args.model} fp32 oracle on {cores} host threads")
     sd = synthetic_state_dict(dims, seed=0, device="cpu")

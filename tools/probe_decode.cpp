@@ -79,6 +79,19 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("empty kernel %d wgs: %.2f us/launch\n", wgs, ms * 1e3f / 200);
   }
+  {  // the same empty launches replayed from a hipGraph
+    hipGraph_t graph; hipGraphExec_t exec;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(empty_kernel, dim3(320), dim3(256), 0, st, (int*)nullptr);
+    CK(hipStreamEndCapture(st, &graph));
+    CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(exec, st)); CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < 5; ++i) CK(hipGraphLaunch(exec, st));
+    CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("empty kernel 320 wgs, hipGraph replay: %.2f us/launch\n", ms * 1e3f / 1000);
+  }
   struct Case { const char* name; int pro, epi, N, K; size_t woff; };
   Case cases[] = {
     {"gemv LN->qkv (3D x D)", whk::PRO_LN, whk::EPI_STORE, 3 * D, D, 0},

@@ -16,9 +16,24 @@ def short(name: str) -> str:
     return name[:90]
 
 
+def pmc_summary(c, out_csv):
+    """per-kernel average of every collected counter (rocprofv3 --pmc run): `counters_collection` view"""
+    rows = c.execute("select kernel_name, grid_size_x, grid_size_y, grid_size_z, counter_name, count(*), avg(value), "
+                     "min(value), max(value) from counters_collection group by 1,2,3,4,5 order by 7 desc").fetchall()
+    out = ["kernel,counter,dispatches,avg,min,max"]
+    for r in rows:
+        out.append(f'"{short(r[0])} grid=({r[1]},{r[2]},{r[3]})",{r[4]},{r[5]},{r[6]:.1f},{r[7]:.1f},{r[8]:.1f}')
+    txt = "\n".join(out)
+    if out_csv:
+        open(out_csv, "w").write(txt + "\n")
+    print(txt)
+
+
 def main():
     db = sys.argv[1]
     c = sqlite3.connect(db)
+    if "--pmc" in sys.argv:
+        return pmc_summary(c, sys.argv[sys.argv.index("--csv") + 1] if "--csv" in sys.argv else None)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     by_grid = "--grid" in sys.argv
     key = "name, grid_x, grid_y, grid_z" if by_grid and "grid_x" in cols else "name"

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int 
   WH_PROBE_AT(a, wgid, 0);
 
   auto load_item = [&](int it, unit_t* w) {
-    const int g = g0 + it / nbatch, b = it - (it / nbatch) * nbatch;
+    const int g = MULTI ? g0 + it / nbatch : g0, b = MULTI ? it - (it / nbatch) * nbatch : 0;
     int n = g * NB + fr; if (n > a.N - 1) n = a.N - 1;
     const T* base = (const T*)a.W + (int64_t)n * K + sub * UNIT;
     // branch-free: a predicated load with a zero-fill else-arm makes the compiler drain vmcnt at the join,
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int 
 
   // x of weight unit u for all rows, read one unit ahead of the dot products
   auto compute_item = [&](int it, const unit_t* w) {
-    const int b = it - (it / nbatch) * nbatch;
+    const int b = MULTI ? it - (it / nbatch) * nbatch : 0;
     unit_t xc[RT], xn[RT];
     auto fetch = [&](int u, unit_t* x) {
       int ub = wave + 4 * (b * NU + u); if (ub > nblk - 1) ub = nblk - 1;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int 
   };
 
   auto finish_group = [&](int it) {
-    const int g = g0 + it / nbatch;
+    const int g = MULTI ? g0 + it / nbatch : g0;
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
       acc[r] = LPR == 8 ? group8_sum(acc[r]) : group16_sum(acc[r]);

@@ -328,7 +328,8 @@ class HipModel:
 class HipTask:
     """wh_task: KV caches + workspace of one DecodingTask (whisper/decoding.py:144-176 PyTorchInference)."""
 
-    def __init__(self, model: HipModel, n_audio: int, n_group: int, max_prefill: int, capture_q: bool = False):
+    def __init__(self, model: HipModel, n_audio: int, n_group: int, max_prefill: int, capture_q: bool = False,
+                 stream: Optional[torch.cuda.Stream] = None):
         self.model = model
         self.n_audio, self.n_group, self.n_rows = n_audio, n_group, n_audio * n_group
         self.max_prefill = max_prefill
@@ -342,7 +343,7 @@ class HipTask:
         check(lib().wh_task_create(model.handle, n_audio, n_group, max_prefill, flags, self.ws.data_ptr(),
                                    self.ws.numel(), C.byref(h)), "wh_task_create")
         self.handle = h
-        self.stream = model.stream
+        self.stream = stream if stream is not None else model.stream   # independent tasks may run on own streams
 
     def close(self):
         if getattr(self, "handle", None):
