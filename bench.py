@@ -178,7 +178,7 @@ def main():
 
     # ---- roofline of the dominant kernels: HIP events on the launch stream, layer-rotated (HBM-cold) ----
     if rank == 0 and not args.no_roofline:
-        kinds = {"decode_step": 0, "attn_decode_cross": 1, "gemv_qkv": 3, "gemv_fc1": 4, "gemv_fc2": 5,
+        kinds = {"decode_step": 0, "attn_decode_cross": 1, "attn_decode_self": 2, "gemv_qkv": 3, "gemv_fc1": 4, "gemv_fc2": 5,
                  "gemv_logits": 6, "gemv_out": 7}
         kern = {}
         for name, kind in kinds.items():

@@ -46,6 +46,8 @@ __global__ void empty_kernel(int* p) { if (p && threadIdx.x == 9999) *p = 1; }
 
 int main(int argc, char** argv) {
   const int D = 1280, H = 20, R = argc > 1 ? atoi(argv[1]) : 8, L = 8, V = 51866, Ta = 1500;
+  const int LR = argc > 2 ? atoi(argv[2]) : L;      // layers actually rotated over (1-2: MALL / L2 resident)
+  printf("rows %d, rotating over %d layer copies\n", R, LR);
   const int iters = 40;
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -95,29 +97,33 @@ int main(int argc, char** argv) {
   struct Case { const char* name; int pro, epi, N, K; size_t woff; };
   Case cases[] = {
     {"gemv LN->qkv (3D x D)", whk::PRO_LN, whk::EPI_STORE, 3 * D, D, 0},
+    {"gemv LN->cq store (DxD)", whk::PRO_LN, whk::EPI_STORE, D, D, (size_t)5 * D * D},
     {"gemv plain->out resid (DxD)", whk::PRO_PLAIN, whk::EPI_RESID, D, D, (size_t)3 * D * D},
     {"gemv combine->cout resid", whk::PRO_COMBINE, whk::EPI_RESID, D, D, (size_t)4 * D * D},
     {"gemv LN->fc1 gelu (4D x D)", whk::PRO_LN, whk::EPI_GELU, 4 * D, D, (size_t)6 * D * D},
     {"gemv plain->fc2 resid (Dx4D)", whk::PRO_PLAIN, whk::EPI_RESID, D, 4 * D, (size_t)10 * D * D},
   };
-  for (const Case& c : cases) {
-    for (int rep = 0; rep < 2; ++rep) {
+  const char* vnames[] = {"heuristic", "4w LPR8", "4w LPR16", "8w LPR8", "16w LPR8", "8w LPR16", "8w GS2", "16w GS2", "16w GS4"};
+  for (const Case& c : cases) for (int variant = 0; variant <= 8; ++variant) {
+    if (variant == 4 && c.K < 4 * D) { }
+    bool ok = true;
+    for (int rep = 0; rep < 2 && ok; ++rep) {
       if (rep == 1) CK(hipEventRecord(e0, st));
       for (int i = 0; i < iters; ++i) {
         whk::GemvArgs g; memset(&g, 0, sizeof(g));
         g.pro = c.pro; g.x = xh; g.x_ld = c.K; g.xf = xf; g.xf_ld = D; g.ln_w = lnw; g.ln_b = lnb;
         g.part_o = part_o; g.part_ml = part_ml; g.splits = 3; g.H = H;
-        g.W = W + wl * (i % L) + c.woff; g.bias = bias; g.N = c.N; g.K = c.K; g.R = R;
+        g.W = W + wl * (i % LR) + c.woff; g.bias = bias; g.N = c.N; g.K = c.K; g.R = R;
         g.epi = c.epi; g.y = y; g.y_ld = c.N; g.resid = resid; g.resid_ld = D;
-        g.probe = d_probe;
-        CK(whk::launch_gemv(g, 1, st));
+        g.probe = nullptr; g.variant = variant;
+        if (whk::launch_gemv(g, 1, st) != hipSuccess) { ok = false; (void)hipGetLastError(); break; }
       }
-      if (rep == 1) CK(hipEventRecord(e1, st));
+      if (rep == 1 && ok) CK(hipEventRecord(e1, st));
       CK(hipStreamSynchronize(st));
     }
+    if (!ok) continue;
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    const int LPR = c.K >= 2048 ? 16 : 8, NB = 64 / LPR;
-    report(c.name, ms * 1e3f / iters, (double)c.N * c.K * 2, d_probe, (c.N + NB - 1) / NB, 7);
+    printf("%-30s %-10s %7.2f us/launch %7.0f GB/s\n", c.name, vnames[variant], ms * 1e3f / iters, (double)c.N * c.K * 2 / (ms * 1e3f / iters) * 1e-3);
   }
   {  // logits
     for (int rep = 0; rep < 2; ++rep) {
@@ -135,13 +141,13 @@ int main(int argc, char** argv) {
     const int ngroups = (V + 7) / 8, gp = (ngroups + 1023) / 1024;
     report("gemv LN->logits (V x D)", ms * 1e3f / 10, (double)V * D * 2, d_probe, (ngroups + gp - 1) / gp, 7);
   }
-  for (int S = 3; S <= 6; ++S) {   // cross attention
+  for (int S = 3; S <= 8; ++S) {   // cross attention
     for (int rep = 0; rep < 2; ++rep) {
       if (rep == 1) CK(hipEventRecord(e0, st));
       for (int i = 0; i < iters; ++i) {
         whk::DecAttnArgs a; memset(&a, 0, sizeof(a));
-        a.q = q; a.q_ld = D; a.k = kv + kvl * (i % L); a.k_ld = 2 * D; a.k_bs = (int64_t)Ta * 2 * D;
-        a.v = kv + kvl * (i % L) + D; a.v_ld = 2 * D; a.v_bs = a.k_bs;
+        a.q = q; a.q_ld = D; a.k = kv + kvl * (i % LR); a.k_ld = 2 * D; a.k_bs = (int64_t)Ta * 2 * D;
+        a.v = kv + kvl * (i % LR) + D; a.v_ld = 2 * D; a.v_bs = a.k_bs;
         a.H = H; a.R = R; a.kv_group = 1; a.Tk = Ta; a.splits = S; a.out = att; a.o_ld = D; a.part_o = part_o; a.part_ml = part_ml;
         a.probe = d_probe;
         CK(whk::launch_attn_decode(a, 1, st));

@@ -284,7 +284,7 @@ struct wh_task {
 // (attn_decode_capacity) and enough workgroups (>= ~640) to cover the 256 CUs with loads in flight
 static int pick_splits(int R, int H, int max_keys, int dtype) {
   const int cap = attn_decode_capacity(dtype);
-  const int unit = dtype == WH_F16 ? 32 : 16;          // chunk rounding inside the kernel
+  const int unit = dtype == WH_F16 ? 32 : 16;          // chunk rounding inside the kernel (keys per 4-wave round)
   int s = (480 + R * H - 1) / (R * H);      // measured: 480 workgroups of 512 keys beat 640 x 384 (probe_decode)
   if (s < 1) s = 1;
   if (s > DEC_ATTN_MAX_SPLITS) s = DEC_ATTN_MAX_SPLITS;

@@ -280,18 +280,43 @@ __global__ __launch_bounds__(256, 2) void attn_flash_f16_kernel(
 // =============================================================================================
 // decode attention: one query per row.  The whole K and V slice of a workgroup is requested up front
 // (2 x NL 16-byte loads per lane, non-temporal) and held in registers: one HBM round trip per launch,
-// scores never touch LDS, softmax statistics travel by wave shuffles + two 4-entry LDS exchanges.
+// scores never touch LDS, softmax statistics travel by DPP / permlane + two small LDS exchanges.
+// A wave issues one VALU instruction per ~8.6 cycles, so the per-wave instruction chain is kept short:
+// WAVES = 8 waves per (split, head, row), v_dot2_f32_f16 for q.k, 32-bit offsets with a clamped stride walk.
 // =============================================================================================
-constexpr int DEC_NL = 16;            // wave-loads of K (and of V) per lane
 
-template <typename T, int NL>
-__global__ __launch_bounds__(256) void attn_decode_kernel(whk::DecAttnArgs a) {
+__device__ __forceinline__ float qk_unit(half8v q, half8v k) {
+  float d = __builtin_amdgcn_fdot2(half2v{q[0], q[1]}, half2v{k[0], k[1]}, 0.f, false);
+  d = __builtin_amdgcn_fdot2(half2v{q[2], q[3]}, half2v{k[2], k[3]}, d, false);
+  d = __builtin_amdgcn_fdot2(half2v{q[4], q[5]}, half2v{k[4], k[5]}, d, false);
+  d = __builtin_amdgcn_fdot2(half2v{q[6], q[7]}, half2v{k[6], k[7]}, d, false);
+  return d;
+}
+__device__ __forceinline__ float qk_unit(float4v q, float4v k) {
+  float d = q[0] * k[0];
+  d = __builtin_fmaf(q[1], k[1], d); d = __builtin_fmaf(q[2], k[2], d); d = __builtin_fmaf(q[3], k[3], d);
+  return d;
+}
+// q * 0.125 is exact in fp16 (power of two) unless the product is subnormal — irrelevant at |q| ~ 1
+__device__ __forceinline__ half8v scale_q(half8v q) {
+  half8v r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (half_t)((float)q[e] * SCALE);
+  return r;
+}
+__device__ __forceinline__ float4v scale_q(float4v q) { return q * SCALE; }
+
+// SKIP: rounds beyond the live key count are skipped by wave-uniform branches (self attention, where the
+// cached length is only known on the device); without it every round is issued unconditionally.
+template <typename T, int NL, int WAVES, bool SKIP>
+__global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArgs a) {
   typedef typename ET<T>::unit_t unit_t;
   constexpr int UNIT = ET<T>::UNIT;
   constexpr int LPK = 64 / UNIT;     // lanes per key (8 fp16 / 16 fp32)
   constexpr int KPW = 64 / LPK;      // keys per wave instruction
-  __shared__ float red[4][64];
-  __shared__ float redm[4], reds[4];
+  constexpr int KPR = WAVES * KPW;   // keys per round of the workgroup
+  __shared__ float red[WAVES][64];
+  __shared__ float redm[WAVES], reds[WAVES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -299,10 +324,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(whk::DecAttnArgs a) {
   const int S = a.splits;
   const int Tk = a.d_len ? (*a.d_len + a.len_plus) : a.Tk;
   int chunk = (Tk + S - 1) / S;
-  chunk = (chunk + 4 * KPW - 1) / (4 * KPW) * (4 * KPW);
+  chunk = (chunk + KPR - 1) / KPR * KPR;
   const int k0 = s * chunk;
   int k1 = k0 + chunk; if (k1 > Tk) k1 = Tk;
   const int nkeys = k1 > k0 ? k1 - k0 : 0;
+  const int nround = (nkeys + KPR - 1) / KPR;          // uniform: rounds that hold at least one key
 
   const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   (void)wgid;
@@ -310,50 +336,59 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(whk::DecAttnArgs a) {
   const int kvb = r / a.kv_group;
   const int cu = lane % LPK;          // unit within the head row
   const int ks = lane / LPK;          // key slot within the wave instruction
-  const T* kp = (const T*)a.k + (int64_t)kvb * a.k_bs + h * 64 + cu * UNIT;
+  const T* kp = (const T*)a.k + (int64_t)kvb * a.k_bs + h * 64 + cu * UNIT;   // wave-uniform part folded by the compiler
   const T* vp = (const T*)a.v + (int64_t)kvb * a.v_bs + h * 64 + cu * UNIT;
 
-  // branch-free loads (a zero-fill else-arm would make the compiler drain vmcnt at every join): slots past
-  // the split re-read its last key and are neutralised through score = -inf / p = 0 below.
-  const int klast = Tk > 0 ? Tk - 1 : 0;
   // q first (L2 hit, needed first): loads return in issue order
-  const unit_t qu = *(const unit_t*)((const T*)a.q + (int64_t)r * a.q_ld + h * 64 + cu * UNIT);
+  const unit_t qraw = *(const unit_t*)((const T*)a.q + (int64_t)r * a.q_ld + h * 64 + cu * UNIT);
   asm volatile("" ::: "memory");
+  // key of round i for this lane: kk_i = (i * WAVES + wave) * KPW + ks; element offset = (k0 + kk_i) * ld,
+  // walked with a constant stride and clamped to the last valid key of the split (branch-free loads: a
+  // zero-fill else-arm would make the compiler drain vmcnt at every join).  Rounds >= nround are skipped by a
+  // wave-uniform branch; slots past the split inside a live round are neutralised by score = -inf.
+  const int kk0 = wave * KPW + ks;
+  const int klast = nkeys > 0 ? nkeys - 1 : 0;
+  const uint32_t ldk = (uint32_t)a.k_ld, ldv = (uint32_t)a.v_ld;
+  const uint32_t ok0 = (uint32_t)(k0 + kk0) * ldk, okl = (uint32_t)(k0 + klast) * ldk;
+  const uint32_t ov0 = (uint32_t)(k0 + kk0) * ldv, ovl = (uint32_t)(k0 + klast) * ldv;
   unit_t ku[NL], vu[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
-    int key = k0 + (i * 4 + wave) * KPW + ks; if (key > klast) key = klast;
-    ku[i] = __builtin_nontemporal_load((const unit_t*)(kp + (int64_t)key * a.k_ld));
+    if (!SKIP || i < nround) {
+      uint32_t o = ok0 + (uint32_t)(i * KPR) * ldk; if (o > okl) o = okl;
+      ku[i] = __builtin_nontemporal_load((const unit_t*)(kp + o));
+    }
   }
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
-    int key = k0 + (i * 4 + wave) * KPW + ks; if (key > klast) key = klast;
-    vu[i] = __builtin_nontemporal_load((const unit_t*)(vp + (int64_t)key * a.v_ld));
+    if (!SKIP || i < nround) {
+      uint32_t o = ov0 + (uint32_t)(i * KPR) * ldv; if (o > ovl) o = ovl;
+      vu[i] = __builtin_nontemporal_load((const unit_t*)(vp + o));
+    }
   }
-
   WH_PROBE_AT(a, wgid, 1);
 
-  float qv[UNIT];
-#pragma unroll
-  for (int e = 0; e < UNIT; ++e) qv[e] = to_f32(qu[e]) * SCALE;
+  const unit_t qs = scale_q(qraw);
 
   // ---- scores (registers), split max
   float sc[NL];
   float mx = WH_NEG_INF;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
-    const int kk = (i * 4 + wave) * KPW + ks;
-    float d = 0.f;
-#pragma unroll
-    for (int e = 0; e < UNIT; ++e) d = __builtin_fmaf(qv[e], to_f32(ku[i][e]), d);
-    d = LPK == 8 ? group8_sum(d) : group16_sum(d);
-    sc[i] = (kk < nkeys) ? d : WH_NEG_INF;
-    mx = fmaxf(mx, sc[i]);
+    sc[i] = WH_NEG_INF;
+    if (!SKIP || i < nround) {
+      float d = qk_unit(qs, ku[i]);
+      d = LPK == 8 ? group8_sum(d) : group16_sum(d);
+      sc[i] = (kk0 + i * KPR < nkeys) ? d : WH_NEG_INF;
+      mx = fmaxf(mx, sc[i]);
+    }
   }
   mx = LPK == 8 ? across_groups8_max(mx) : across_groups16_max(mx);
   if (lane == 0) redm[wave] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+  mx = redm[0];
+#pragma unroll
+  for (int w = 1; w < WAVES; ++w) mx = fmaxf(mx, redm[w]);
   WH_PROBE_AT(a, wgid, 2);
 
   // ---- p = exp(s - max), o = sum_k p[k] V[k]
@@ -363,10 +398,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(whk::DecAttnArgs a) {
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
-    const float p = (sc[i] == WH_NEG_INF) ? 0.f : __expf(sc[i] - mx);
-    sum += p;
+    if (!SKIP || i < nround) {
+      const float p = (sc[i] == WH_NEG_INF) ? 0.f : __expf(sc[i] - mx);
+      sum += p;
 #pragma unroll
-    for (int e = 0; e < UNIT; ++e) acc[e] = __builtin_fmaf(p, to_f32(vu[i][e]), acc[e]);
+      for (int e = 0; e < UNIT; ++e) acc[e] = __builtin_fmaf(p, to_f32(vu[i][e]), acc[e]);
+    }
   }
   // reduce over key slots (lane bits above log2(LPK)); every lane of a key group holds the same p
   sum = LPK == 8 ? across_groups8_sum(sum) : across_groups16_sum(sum);
@@ -380,8 +417,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(whk::DecAttnArgs a) {
   __syncthreads();
   WH_PROBE_AT(a, wgid, 3);
   if (tid < 64) {
-    const float o = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-    const float l = reds[0] + reds[1] + reds[2] + reds[3];
+    float o = red[0][tid], l = reds[0];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) { o += red[w][tid]; l += reds[w]; }
     if (S == 1) {
       ((T*)a.out)[(int64_t)r * a.o_ld + h * 64 + tid] = from_f32<T>(o / l);
     } else {
@@ -435,27 +473,33 @@ hipError_t launch_attn_flash_f16(const void* q, int64_t q_ld, int64_t q_bs, cons
   return hipGetLastError();
 }
 
-int attn_decode_capacity(int dtype) { return dtype == 1 ? 4 * 8 * DEC_NL : 4 * 4 * DEC_NL; }
+int attn_decode_capacity(int dtype) { return 512 / (dtype == 1 ? 1 : 2); }   // 4 x 16 or 8 x 8 rounds of 8 (4) keys
 
+// Cross attention (fixed 1500 keys, HBM-bound): 4 waves x up to 16 rounds measured fastest (11.7 us vs 12.9 us for
+// 8 x 8 at large-v3 B = 8).  Self attention (cached length read on the device): 8 waves x 8 rounds — short
+// chains, and rounds beyond the cached length are skipped by a wave-uniform branch.
 template <typename T>
 static hipError_t launch_attn_decode_t(const DecAttnArgs& a, hipStream_t stream) {
-  constexpr int KPL = 4 * ET<T>::UNIT;            // keys per wave-load round of the workgroup (32 fp16 / 16 fp32)
-  dim3 grid(a.splits, a.H, a.R), block(256);
-  int rounds = DEC_NL;                            // cached length unknown at capture time: full tile
-  if (!a.d_len) {
-    const int chunk = (a.Tk + a.splits - 1) / a.splits;
-    rounds = (chunk + KPL - 1) / KPL;
-    if (rounds > DEC_NL) return hipErrorInvalidValue;
+  constexpr int KPW = ET<T>::UNIT;                 // keys per wave-load: 64 lanes / (64 / UNIT lanes per key)
+  if (a.d_len) {
+    dim3 grid(a.splits, a.H, a.R), block(8 * 64);
+    hipLaunchKernelGGL((attn_decode_kernel<T, 8, 8, true>), grid, block, 0, stream, a);
+    return hipGetLastError();
   }
-  if (rounds <= 8) hipLaunchKernelGGL((attn_decode_kernel<T, 8>), grid, block, 0, stream, a);
-  else if (rounds <= 12) hipLaunchKernelGGL((attn_decode_kernel<T, 12>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((attn_decode_kernel<T, DEC_NL>), grid, block, 0, stream, a);
+  dim3 grid(a.splits, a.H, a.R), block(4 * 64);
+  const int chunk = (a.Tk + a.splits - 1) / a.splits;
+  const int rounds = (chunk + 4 * KPW - 1) / (4 * KPW);
+  if (rounds > 16) return hipErrorInvalidValue;
+  if (rounds <= 8) hipLaunchKernelGGL((attn_decode_kernel<T, 8, 4, false>), grid, block, 0, stream, a);
+  else if (rounds <= 12) hipLaunchKernelGGL((attn_decode_kernel<T, 12, 4, false>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((attn_decode_kernel<T, 16, 4, false>), grid, block, 0, stream, a);
   return hipGetLastError();
 }
 
 hipError_t launch_attn_decode(const DecAttnArgs& a, int dtype, hipStream_t stream) {
   // a split must fit the register-resident K/V tile: callers size `splits` with attn_decode_capacity()
   if (a.splits < 1 || a.splits > DEC_ATTN_MAX_SPLITS) return hipErrorInvalidValue;
+  if ((int64_t)a.k_ld * 2048 > 0x7fffffff || (int64_t)a.v_ld * 2048 > 0x7fffffff) return hipErrorInvalidValue;
   return dtype == 1 ? launch_attn_decode_t<half_t>(a, stream) : launch_attn_decode_t<float>(a, stream);
 }
 

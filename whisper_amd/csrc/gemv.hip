@@ -34,9 +34,7 @@ namespace {
 // prologue's own loads, and loads return in issue order
 #define ISSUE_FENCE() asm volatile("" ::: "memory")
 
-constexpr int NU = 10;         // weight units (16 B) in flight per lane per buffer
-constexpr int CT = 10;         // PRO_COMBINE fast path: (row, head, 4 dims) tasks per thread ...
-constexpr int CS = 4;          // ... and splits held in registers
+constexpr int CS = 4;          // PRO_COMBINE fast path: splits held in registers
 
 template <typename T> struct Pack4;
 template <> struct Pack4<float> {
@@ -50,40 +48,50 @@ template <> struct Pack4<half_t> {
   }
 };
 
-// PRO: prologue kind (whk::PRO_*), LNJ: float4 per lane per row held by the LayerNorm prologue (K <= 256*LNJ)
-// MULTI: the workgroup walks more than one (feature group, K batch) item -> second weight buffer
-template <typename T, int RT, int LPR, int PRO, int LNJ, bool MULTI>
-__global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int red_alias) {
+// PRO: prologue kind (whk::PRO_*); J: float4 per lane per row held by the LayerNorm prologue (K <= 256*J) or
+// 16-byte x units per thread per row staged by PRO_PLAIN; MULTI: the workgroup walks several (feature group,
+// K batch) items with double-buffered weights (WAVES == 4, GS == 1 only);
+// WAVES x 64 threads per workgroup, arranged as GS feature-group slots x KS = WAVES / GS splits of K.
+// A single wave issues one VALU instruction every ~8.6 cycles (tools/ubench_valu), so the per-wave
+// instruction chain — not FLOPs — bounds these kernels: wide workgroups cut the chain per wave.
+template <typename T, int RT, int LPR, int PRO, int J, bool MULTI, int WAVES, int GS>
+__global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int gp, int red_alias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename ET<T>::unit_t unit_t;
   constexpr int UNIT = ET<T>::UNIT;
+  constexpr int NT = WAVES * 64;
+  constexpr int KS = WAVES / GS;         // waves splitting K for one feature group
+  constexpr int NU = WAVES == 4 ? 10 : 5;   // weight units (16 B) in flight per lane per buffer
   constexpr int NB = 64 / LPR;           // output features per group (= weight rows per wave-load)
   constexpr int BLK = LPR * UNIT;        // K elements covered by one wave-load
-  constexpr int NR = RT >= 8 ? 2 : 1;    // LayerNorm rows per wave per pass
-  constexpr int XJ = LNJ;                // PRO_PLAIN: 16-byte units per thread per row (K <= 256 * XJ * UNIT)
+  constexpr int NR = (RT + WAVES - 1) / WAVES;   // LayerNorm rows per wave
+  constexpr int TPR = NT / RT;           // PRO_PLAIN: threads staging one row
+  constexpr int CT = NT == 256 ? 10 : (NT == 512 ? 5 : 3);   // PRO_COMBINE fast path: tasks per thread
+  static_assert(!MULTI || (WAVES == 4 && GS == 1), "MULTI is the 4-wave streaming form");
   const int K = a.K;
   T* xs = (T*)smem;                                              // [RT][K]
-  // cross-wave partial sums [4][NB][RT]; aliases xs when the workgroup owns a single feature group
+  // cross-wave partial sums [WAVES][NB][RT]; aliases xs when the workgroup makes a single pass
   float* red = red_alias ? (float*)smem : (float*)(smem + (size_t)RT * K * sizeof(T));
-  float* csc = red + 4 * NB * RT;                                // PRO_COMBINE: [RT*H][CS] merge weights
+  float* csc = red + WAVES * NB * RT;                            // PRO_COMBINE: [RT*H][CS] merge weights
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = wave / KS, kw = wave % KS;
   const int sub = lane % LPR, fr = lane / LPR;
   const int r0 = blockIdx.y * RT;
   int R = a.R - r0; if (R > RT) R = RT;
   const int nblk = K / BLK;
-  const int nbatch = ((nblk + 3) / 4 + NU - 1) / NU;       // batches of NU wave-loads per group (uniform)
+  const int nbatch = ((nblk + KS - 1) / KS + NU - 1) / NU;  // batches of NU wave-loads per group (uniform)
   const int ngroups = (a.N + NB - 1) / NB;
-  const int g0 = blockIdx.x * gp;
-  int g1 = g0 + gp; if (g1 > ngroups) g1 = ngroups;
-  const int total = (g1 - g0) * nbatch;
+  const int g0 = MULTI ? blockIdx.x * gp : blockIdx.x * GS;
+  int g1 = g0 + (MULTI ? gp : GS); if (g1 > ngroups) g1 = ngroups;
+  const int total = MULTI ? (g1 - g0) * nbatch : 1;
   const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
   (void)wgid;
   WH_PROBE_AT(a, wgid, 0);
 
   auto load_item = [&](int it, unit_t* w) {
-    const int g = MULTI ? g0 + it / nbatch : g0, b = MULTI ? it - (it / nbatch) * nbatch : 0;
+    const int g = MULTI ? g0 + it / nbatch : g0 + slot, b = MULTI ? it - (it / nbatch) * nbatch : 0;
     int n = g * NB + fr; if (n > a.N - 1) n = a.N - 1;
     const T* base = (const T*)a.W + (int64_t)n * K + sub * UNIT;
     // branch-free: a predicated load with a zero-fill else-arm makes the compiler drain vmcnt at the join,
@@ -91,17 +99,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int 
     // last block (valid address) and are skipped by compute_item.
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      int ub = wave + 4 * (b * NU + u); if (ub > nblk - 1) ub = nblk - 1;
+      int ub = kw + KS * (b * NU + u); if (ub > nblk - 1) ub = nblk - 1;
       w[u] = __builtin_nontemporal_load((const unit_t*)(base + (size_t)ub * BLK));
     }
   };
   unit_t wa[NU], wb[MULTI ? NU : 1];
 
-  // epilogue operands of the first group, requested ahead of the weights
-  const int ej = tid % NB, er = tid / NB;
+  // epilogue operands of the first pass, requested ahead of the weights: thread -> (slot, row, feature)
+  const int es = tid / (NB * RT), er = (tid / NB) % RT, ej = tid % NB;
+  const bool e_on = es < GS && er < R;
   float e_bias = 0.f, e_res = 0.f;
-  if (tid < NB * R) {
-    const int n = g0 * NB + ej;
+  if (e_on) {
+    const int n = (g0 + es) * NB + ej;
     if (n < a.N) {
       if (a.bias) e_bias = a.bias[n];
       if (a.epi == whk::EPI_RESID) e_res = a.resid[(int64_t)(r0 + er) * a.resid_ld + n];
@@ -110,70 +119,67 @@ __global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int 
 
   // ---------------------------------------------------------------------- prologue -> xs
   if (PRO == whk::PRO_PLAIN) {
-    // row-major staging without integer divisions: thread t moves units t, t+256, ... of every row
+    // row-major staging without integer divisions: TPR threads per row, thread moves units c, c+TPR, ...
     const int upr = K / UNIT;
-    unit_t xv[RT][XJ];
+    const int r = tid / TPR, c = tid % TPR;
+    const T* src = (const T*)a.x + (int64_t)(r0 + (r < R ? r : R - 1)) * a.x_ld;     // padded rows re-read a valid row
+    unit_t xv[J];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) {
-      const T* src = (const T*)a.x + (int64_t)(r0 + (r < R ? r : R - 1)) * a.x_ld;   // padded rows re-read a valid row
-#pragma unroll
-      for (int j = 0; j < XJ; ++j) {
-        int u = j * 256 + tid; if (u > upr - 1) u = upr - 1;                          // branch-free, clamped
-        xv[r][j] = *(const unit_t*)(src + u * UNIT);
-      }
+    for (int j = 0; j < J; ++j) {
+      int u = j * TPR + c; if (u > upr - 1) u = upr - 1;                              // branch-free, clamped
+      xv[j] = *(const unit_t*)(src + u * UNIT);
     }
     ISSUE_FENCE(); load_item(0, wa); ISSUE_FENCE(); WH_PROBE_AT(a, wgid, 1);
 #pragma unroll
-    for (int r = 0; r < RT; ++r) {
+    for (int j = 0; j < J; ++j) {
+      const int u = j * TPR + c;
+      if (u < upr) {
+        unit_t v = xv[j];
+        if (r >= R) {
 #pragma unroll
-      for (int j = 0; j < XJ; ++j) {
-        const int u = j * 256 + tid;
-        if (u < upr) {
-          unit_t v = xv[r][j];
-          if (r >= R) {
-#pragma unroll
-            for (int e = 0; e < UNIT; ++e) v[e] = 0;
-          }
-          *(unit_t*)(xs + (size_t)r * K + u * UNIT) = v;
+          for (int e = 0; e < UNIT; ++e) v[e] = 0;
         }
+        *(unit_t*)(xs + (size_t)r * K + u * UNIT) = v;
       }
     }
   } else if (PRO == whk::PRO_LN) {
-    // single pass: rows wave, wave+4 (and +8, +12 for RT = 16) live in registers
-#pragma unroll
-    for (int rb = 0; rb < RT; rb += 4 * NR) {
-      float4v v[NR][LNJ], w4[LNJ], b4[LNJ];
+    // single pass: row(s) wave, wave + WAVES, ... live in registers; waves beyond RT only stream weights
+    float4v v[NR][J], w4[J], b4[J];
+    const bool ln_wave = wave < RT;
+    if (ln_wave) {
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
-        const int r = rb + wave + 4 * i;
+        const int r = wave + WAVES * i;
         const float* src = a.xf + (int64_t)(r0 + (r < R ? r : 0)) * a.xf_ld;
 #pragma unroll
-        for (int j = 0; j < LNJ; ++j) {
+        for (int j = 0; j < J; ++j) {
           int k = (j * 64 + lane) * 4; if (k > K - 4) k = K - 4;      // branch-free; masked at use
           v[i][j] = *(const float4v*)(src + k);
         }
       }
 #pragma unroll
-      for (int j = 0; j < LNJ; ++j) {
+      for (int j = 0; j < J; ++j) {
         int k = (j * 64 + lane) * 4; if (k > K - 4) k = K - 4;
         w4[j] = *(const float4v*)(a.ln_w + k);
         b4[j] = *(const float4v*)(a.ln_b + k);
       }
-      if (rb == 0) { ISSUE_FENCE(); load_item(0, wa); ISSUE_FENCE(); WH_PROBE_AT(a, wgid, 1); }
+    }
+    ISSUE_FENCE(); load_item(0, wa); ISSUE_FENCE(); WH_PROBE_AT(a, wgid, 1);
+    if (ln_wave) {
       const float invK = 1.0f / (float)K;
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
-        const int r = rb + wave + 4 * i;
+        const int r = wave + WAVES * i;
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < LNJ; ++j) {
+        for (int j = 0; j < J; ++j) {
           const float t = (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
           s += ((j * 64 + lane) * 4 < K) ? t : 0.f;
         }
         const float mean = wave_sum(s) * invK;
         float ss = 0.f;
 #pragma unroll
-        for (int j = 0; j < LNJ; ++j) {
+        for (int j = 0; j < J; ++j) {
           const int k = (j * 64 + lane) * 4;
           if (k < K) {
 #pragma unroll
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int 
         const float rstd = rsqrtf(wave_sum(ss) * invK + 1e-5f);
         T* xr = xs + (size_t)r * K;
 #pragma unroll
-        for (int j = 0; j < LNJ; ++j) {
+        for (int j = 0; j < J; ++j) {
           const int k = (j * 64 + lane) * 4;
           if (k < K) {
             if (r < R)
@@ -200,13 +206,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int 
   } else {  // PRO_COMBINE: merge split-K attention partials (m, l, o[64]) per (row, head); K == H * 64
     const int S = a.splits, H = a.H;
     const int per_row = H * 16, ntask = RT * per_row;
-    const bool fast = S <= CS && ntask <= 256 * CT && RT * H <= 256;
+    const bool fast = S <= CS && ntask <= NT * CT && RT * H <= NT;
     if (fast) {
       // all partial sums requested before the weights; scale factors exp(m_s - M) / den via LDS
       float4v o[CT][CS];
 #pragma unroll
       for (int j = 0; j < CT; ++j) {
-        int i = j * 256 + tid; if (i > ntask - 1) i = ntask - 1;       // branch-free loads, clamped
+        int i = j * NT + tid; if (i > ntask - 1) i = ntask - 1;        // branch-free loads, clamped
         int r = i / per_row; const int rem = i - r * per_row;
         if (r > R - 1) r = R - 1;
         const int h = rem >> 4, d4 = rem & 15;
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int 
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < CT; ++j) {
-        const int i = j * 256 + tid;
+        const int i = j * NT + tid;
         if (i < ntask) {
           const int r = i / per_row, rem = i - r * per_row;
           const int h = rem >> 4, d4 = rem & 15;
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int 
       }
     } else {
       // generic path (many splits / wide rows): merge first, then start the weight stream
-      for (int i = tid; i < ntask; i += 256) {
+      for (int i = tid; i < ntask; i += NT) {
         const int r = i / per_row, rem = i - r * per_row;
         const int h = rem >> 4, d4 = rem & 15;
         float4v num = {0.f, 0.f, 0.f, 0.f};
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int 
     const int b = MULTI ? it - (it / nbatch) * nbatch : 0;
     unit_t xc[RT], xn[RT];
     auto fetch = [&](int u, unit_t* x) {
-      int ub = wave + 4 * (b * NU + u); if (ub > nblk - 1) ub = nblk - 1;
+      int ub = kw + KS * (b * NU + u); if (ub > nblk - 1) ub = nblk - 1;
       const T* xb = xs + (size_t)ub * BLK + sub * UNIT;
 #pragma unroll
       for (int r = 0; r < RT; ++r) x[r] = *(const unit_t*)(xb + (size_t)r * K);
@@ -304,12 +310,12 @@ __global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int 
 #pragma unroll
     for (int u = 0; u < NU; u += 2) {
       if (u + 1 < NU) fetch(u + 1, xn);
-      if (wave + 4 * (b * NU + u) < nblk) {
+      if (kw + KS * (b * NU + u) < nblk) {
 #pragma unroll
         for (int r = 0; r < RT; ++r) acc[r] = dot_unit(w[u], xc[r], acc[r]);
       }
       if (u + 2 < NU) fetch(u + 2, xc);
-      if (u + 1 < NU && wave + 4 * (b * NU + u + 1) < nblk) {
+      if (u + 1 < NU && kw + KS * (b * NU + u + 1) < nblk) {
 #pragma unroll
         for (int r = 0; r < RT; ++r) acc[r] = dot_unit(w[u + 1], xn[r], acc[r]);
       }
@@ -317,31 +323,31 @@ __global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int 
   };
 
   auto finish_group = [&](int it) {
-    const int g = MULTI ? g0 + it / nbatch : g0;
+    const int gbase = MULTI ? g0 + it / nbatch : g0;     // group of slot 0 in this pass
 #pragma unroll
-    for (int r = 0; r < RT; ++r) {
-      acc[r] = LPR == 8 ? group8_sum(acc[r]) : group16_sum(acc[r]);
-    }
+    for (int r = 0; r < RT; ++r) acc[r] = LPR == 8 ? group8_sum(acc[r]) : group16_sum(acc[r]);
     if (red_alias) __syncthreads();           // every wave is done reading xs before `red` overwrites it
     if (sub == 0) {
 #pragma unroll
       for (int r = 0; r < RT; ++r) red[(wave * NB + fr) * RT + r] = acc[r];
     }
     __syncthreads();
-    if (tid < NB * R) {
+    if (e_on) {
+      const int g = gbase + es;
       const int n = g * NB + ej;
-      if (n < a.N) {
-        float v = red[(0 * NB + ej) * RT + er] + red[(1 * NB + ej) * RT + er] + red[(2 * NB + ej) * RT + er] +
-                  red[(3 * NB + ej) * RT + er];
+      if (g < ngroups && n < a.N) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) v += red[((es * KS + k) * NB + ej) * RT + er];
         const int64_t rr = r0 + er;
-        if (g == g0) v += e_bias;
+        if (gbase == g0) v += e_bias;
         else if (a.bias) v += a.bias[n];
         switch (a.epi) {
           case whk::EPI_STORE: ((T*)a.y)[rr * a.y_ld + n] = from_f32<T>(v); break;
           case whk::EPI_GELU: ((T*)a.y)[rr * a.y_ld + n] = from_f32<T>(gelu_erf(v)); break;
           case whk::EPI_F32: ((float*)a.y)[rr * a.y_ld + n] = v; break;
           case whk::EPI_RESID:
-            a.resid[rr * a.resid_ld + n] = (g == g0 ? e_res : a.resid[rr * a.resid_ld + n]) + v;
+            a.resid[rr * a.resid_ld + n] = (gbase == g0 ? e_res : a.resid[rr * a.resid_ld + n]) + v;
             break;
           case whk::EPI_QKV: {
             const int D = a.D;
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int 
         if ((it + 2) % nbatch == 0) finish_group(it + 1);
       }
     }
-  } else if (total > 0) {
+  } else {
     compute_item(0, wa);
     WH_PROBE_AT(a, wgid, 4);
     finish_group(0);
@@ -384,64 +390,97 @@ __global__ __launch_bounds__(256) void gemv_kernel(whk::GemvArgs a, int gp, int 
   if (a.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.bump, a.bump_by);
 }
 
-template <typename T, int RT, int LPR, int PRO, int LNJ, bool MULTI>
+template <typename T, int RT, int LPR, int PRO, int J, bool MULTI, int WAVES, int GS>
 hipError_t launch_cfg(const whk::GemvArgs& a, int gp, hipStream_t stream) {
   constexpr int NB = 64 / LPR;
   const int ngroups = (a.N + NB - 1) / NB;
-  const int red_alias = (gp == 1 && PRO != whk::PRO_COMBINE) ? 1 : 0;
+  const int red_alias = (!MULTI || gp == 1) && PRO != whk::PRO_COMBINE ? 1 : 0;
   size_t lds = (size_t)RT * a.K * sizeof(T);
-  if (!red_alias) lds += 4 * NB * RT * sizeof(float);
+  const size_t red_bytes = (size_t)WAVES * NB * RT * sizeof(float);
+  if (!red_alias) lds += red_bytes;
+  else if (lds < red_bytes) lds = red_bytes;
   if (PRO == whk::PRO_COMBINE) lds += (size_t)RT * a.H * CS * sizeof(float);   // merge weights behind `red`
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemv_kernel<T, RT, LPR, PRO, LNJ, MULTI>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemv_kernel<T, RT, LPR, PRO, J, MULTI, WAVES, GS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  dim3 grid((ngroups + gp - 1) / gp, (a.R + RT - 1) / RT), block(256);
-  hipLaunchKernelGGL((gemv_kernel<T, RT, LPR, PRO, LNJ, MULTI>), grid, block, lds, stream, a, gp, red_alias);
+  constexpr int KS_ = WAVES / GS, NU_ = WAVES == 4 ? 10 : 5, BLK_ = LPR * ET<T>::UNIT;
+  if (!MULTI && (a.K / BLK_ + KS_ - 1) / KS_ > NU_) return hipErrorInvalidValue;   // one batch per wave only
+  const int per_wg = MULTI ? gp : GS;
+  dim3 grid((ngroups + per_wg - 1) / per_wg, (a.R + RT - 1) / RT), block(WAVES * 64);
+  hipLaunchKernelGGL((gemv_kernel<T, RT, LPR, PRO, J, MULTI, WAVES, GS>), grid, block, lds, stream, a, gp, red_alias);
   return hipGetLastError();
 }
 
-template <typename T, int RT, int LPR, bool MULTI>
+template <typename T, int RT, int LPR, bool MULTI, int WAVES, int GS>
 hipError_t launch_pro(const whk::GemvArgs& a, int gp, hipStream_t stream) {
+  constexpr int TPR = WAVES * 64 / RT;
   switch (a.pro) {
     case whk::PRO_PLAIN: {
-      const int upr = a.K / ET<T>::UNIT;            // LNJ doubles as units-per-thread-per-row here
-      if (upr <= 256) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 1, MULTI>(a, gp, stream);
-      if (upr <= 768) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 3, MULTI>(a, gp, stream);
-      if (upr <= 1536) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 6, MULTI>(a, gp, stream);
+      const int upr = a.K / ET<T>::UNIT;            // J = 16-byte units per thread per row
+      if (upr <= TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 1, MULTI, WAVES, GS>(a, gp, stream);
+      if (upr <= 3 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 3, MULTI, WAVES, GS>(a, gp, stream);
+      if (upr <= 6 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 6, MULTI, WAVES, GS>(a, gp, stream);
+      if (WAVES == 4) {                              // narrow workgroups stage long rows with more units per thread
+        if (upr <= 12 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 12, MULTI, WAVES, GS>(a, gp, stream);
+        if (upr <= 24 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 24, MULTI, WAVES, GS>(a, gp, stream);
+      }
       return hipErrorInvalidValue;
     }
     case whk::PRO_LN:
-      if (a.K <= 256 * 5) return launch_cfg<T, RT, LPR, whk::PRO_LN, 5, MULTI>(a, gp, stream);
-      if (a.K <= 256 * 8) return launch_cfg<T, RT, LPR, whk::PRO_LN, 8, MULTI>(a, gp, stream);
+      if (a.K <= 256 * 5) return launch_cfg<T, RT, LPR, whk::PRO_LN, 5, MULTI, WAVES, GS>(a, gp, stream);
+      if (a.K <= 256 * 8) return launch_cfg<T, RT, LPR, whk::PRO_LN, 8, MULTI, WAVES, GS>(a, gp, stream);
       return hipErrorInvalidValue;
     case whk::PRO_COMBINE:
       if (a.K != a.H * 64) return hipErrorInvalidValue;
-      return launch_cfg<T, RT, LPR, whk::PRO_COMBINE, 1, MULTI>(a, gp, stream);
+      return launch_cfg<T, RT, LPR, whk::PRO_COMBINE, 1, MULTI, WAVES, GS>(a, gp, stream);
   }
   return hipErrorInvalidValue;
 }
 
-template <typename T, int RT, int LPR>
-hipError_t launch_lpr(const whk::GemvArgs& a, hipStream_t stream) {
-  constexpr int NB = 64 / LPR, BLK = LPR * ET<T>::UNIT;
-  const int ngroups = (a.N + NB - 1) / NB;
-  const int gp = (ngroups + 1023) / 1024;
-  const int nbatch = ((a.K / BLK + 3) / 4 + NU - 1) / NU;
-  if (gp * nbatch > 1) return launch_pro<T, RT, LPR, true>(a, gp, stream);
-  return launch_pro<T, RT, LPR, false>(a, gp, stream);
-}
+// shape heuristics (large-v3, R = 8, every candidate measured with tools/probe_decode; see profiles/).
+// Fewer, fatter workgroups win whenever a prologue is shared: a CU sustains >= 50 B/clk on this stream, so
+// covering all 256 CUs is not the constraint — the redundant LayerNorm / merge prologues and the per-wave
+// instruction chain are.
+//   V x D logits ................ 4-wave streaming form, several groups per workgroup
+//   D x 4D (fc2) ................ one 16-wave workgroup per 8-feature group (K split 16 ways)
+//   LN + 4D x D (fc1) ........... 16 waves = 4 groups x 4 K-splits   (160 workgroups)
+//   LN + 3D x D (qkv) ........... 8 waves = 2 groups x 4 K-splits    (240 workgroups)
+//   LN / merge + D x D .......... 8 waves, one group
+//   plain D x D (out) ........... 4 waves, one group
+constexpr int PRO_LN_ = whk::PRO_LN, PRO_PLAIN_ = whk::PRO_PLAIN;
 
 template <typename T, int RT>
 hipError_t launch_rt(const whk::GemvArgs& a, hipStream_t stream) {
   constexpr int UNIT = ET<T>::UNIT;
-  if (a.K >= 2048 && a.K % (16 * UNIT) == 0) return launch_lpr<T, RT, 16>(a, stream);
   if (a.K % (8 * UNIT) != 0) return hipErrorInvalidValue;
-  return launch_lpr<T, RT, 8>(a, stream);
+  const int ngroups8 = (a.N + 7) / 8;
+  const int nblk8 = a.K / (8 * UNIT);
+  const int force = a.variant;                           // developer override (probe tool); 0 = heuristic
+  if (force == 0) {
+    if (ngroups8 > 1024) return launch_pro<T, RT, 8, true, 4, 1>(a, (ngroups8 + 1023) / 1024, stream);
+    if (nblk8 >= 64 && (nblk8 + 15) / 16 <= 5) return launch_pro<T, RT, 8, false, 16, 1>(a, 1, stream);
+    if (a.pro == PRO_LN_ && ngroups8 >= 600 && (nblk8 + 3) / 4 <= 5) return launch_pro<T, RT, 8, false, 16, 4>(a, 1, stream);
+    if (a.pro == PRO_LN_ && ngroups8 >= 400 && (nblk8 + 3) / 4 <= 5) return launch_pro<T, RT, 8, false, 8, 2>(a, 1, stream);
+    if (a.pro != PRO_PLAIN_ && (nblk8 + 7) / 8 <= 5) return launch_pro<T, RT, 8, false, 8, 1>(a, 1, stream);
+    if ((nblk8 + 3) / 4 <= 10) return launch_pro<T, RT, 8, false, 4, 1>(a, 1, stream);
+    return launch_pro<T, RT, 8, true, 4, 1>(a, 1, stream);
+  }
+  switch (force) {
+    case 1: return launch_pro<T, RT, 8, false, 4, 1>(a, 1, stream);
+    case 2: return launch_pro<T, RT, 16, false, 4, 1>(a, 1, stream);
+    case 3: return launch_pro<T, RT, 8, false, 8, 1>(a, 1, stream);
+    case 4: return launch_pro<T, RT, 8, false, 16, 1>(a, 1, stream);
+    case 5: return launch_pro<T, RT, 16, false, 8, 1>(a, 1, stream);
+    case 6: return launch_pro<T, RT, 8, false, 8, 2>(a, 1, stream);
+    case 7: return launch_pro<T, RT, 8, false, 16, 2>(a, 1, stream);
+    case 8: return launch_pro<T, RT, 8, false, 16, 4>(a, 1, stream);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace

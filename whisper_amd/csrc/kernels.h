@@ -114,6 +114,7 @@ struct GemvArgs {
   float* resid; int64_t resid_ld;                 // EPI_RESID: resid[r][n] += y
   void* kcache; void* vcache; int64_t cache_bs; const int* d_pos; int D;  // EPI_QKV
   int* bump; int bump_by;                         // optional: *bump += bump_by once per launch (position counter)
+  int variant;                                    // 0 = shape heuristic; > 0 forces a kernel shape (tools/probe_decode)
   WH_PROBE_FIELD
 };
 hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream);
