@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DWH_PROBE -I include tools/probe_decode.cpp -o tools/probe_decode
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -98,13 +99,17 @@ int main(int argc, char** argv) {
   Case cases[] = {
     {"gemv LN->qkv (3D x D)", whk::PRO_LN, whk::EPI_STORE, 3 * D, D, 0},
     {"gemv LN->cq store (DxD)", whk::PRO_LN, whk::EPI_STORE, D, D, (size_t)5 * D * D},
+    {"gemv plain->store (DxD)", whk::PRO_PLAIN, whk::EPI_STORE, D, D, (size_t)3 * D * D},
+    {"gemv plain->store (Dx4D)", whk::PRO_PLAIN, whk::EPI_STORE, D, 4 * D, (size_t)10 * D * D},
     {"gemv plain->out resid (DxD)", whk::PRO_PLAIN, whk::EPI_RESID, D, D, (size_t)3 * D * D},
     {"gemv combine->cout resid", whk::PRO_COMBINE, whk::EPI_RESID, D, D, (size_t)4 * D * D},
     {"gemv LN->fc1 gelu (4D x D)", whk::PRO_LN, whk::EPI_GELU, 4 * D, D, (size_t)6 * D * D},
     {"gemv plain->fc2 resid (Dx4D)", whk::PRO_PLAIN, whk::EPI_RESID, D, 4 * D, (size_t)10 * D * D},
   };
-  const char* vnames[] = {"heuristic", "4w LPR8", "4w LPR16", "8w LPR8", "16w LPR8", "8w LPR16", "8w GS2", "16w GS2", "16w GS4"};
-  for (const Case& c : cases) for (int variant = 0; variant <= 8; ++variant) {
+  const char* vnames[] = {"heuristic", "4w LPR8", "4w LPR16", "8w LPR8", "16w LPR8", "8w LPR16", "8w GS2", "16w GS2", "16w GS4", "", "",
+                          "MF 4w", "MF 8w", "MF 8w GS2", "MF 16w GS4", "MF 16w", "MF 16w GS2", "MF stream"};
+  for (const Case& c : cases) for (int variant = 0; variant <= 17; ++variant) {
+    if (variant == 9 || variant == 10 || variant == 2 || variant == 5 || variant == 7) continue;
     if (variant == 4 && c.K < 4 * D) { }
     bool ok = true;
     for (int rep = 0; rep < 2 && ok; ++rep) {
@@ -123,7 +128,41 @@ int main(int argc, char** argv) {
     }
     if (!ok) continue;
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("%-30s %-10s %7.2f us/launch %7.0f GB/s\n", c.name, vnames[variant], ms * 1e3f / iters, (double)c.N * c.K * 2 / (ms * 1e3f / iters) * 1e-3);
+    char verdict[64] = "";
+    if (c.epi == whk::EPI_STORE && (c.pro == whk::PRO_LN || c.pro == whk::PRO_PLAIN)) {
+      // numerics of the last launch (layer (iters-1) % LR) against a double-precision host reference
+      const size_t woff = wl * ((iters - 1) % LR) + c.woff;
+      std::vector<half_t> hw((size_t)c.N * c.K), hy((size_t)R * c.N), hx((size_t)R * c.K);
+      std::vector<float> hxf((size_t)R * D), hlw(D), hlb(D), hb(c.N);
+      CK(hipMemcpy(hw.data(), W + woff, hw.size() * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hy.data(), y, hy.size() * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hx.data(), xh, hx.size() * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hxf.data(), xf, hxf.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hlw.data(), lnw, D * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hlb.data(), lnb, D * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hb.data(), bias, c.N * 4, hipMemcpyDeviceToHost));
+      double maxerr = 0;
+      for (int r = 0; r < R; ++r) {
+        std::vector<double> xin(c.K);
+        if (c.pro == whk::PRO_LN) {
+          double m = 0, v = 0;
+          for (int k = 0; k < c.K; ++k) m += hxf[(size_t)r * D + k];
+          m /= c.K;
+          for (int k = 0; k < c.K; ++k) v += (hxf[(size_t)r * D + k] - m) * (hxf[(size_t)r * D + k] - m);
+          const double rstd = 1.0 / sqrt(v / c.K + 1e-5);
+          for (int k = 0; k < c.K; ++k) xin[k] = (double)(half_t)(float)((hxf[(size_t)r * D + k] - m) * rstd * hlw[k] + hlb[k]);
+        } else {
+          for (int k = 0; k < c.K; ++k) xin[k] = (double)hx[(size_t)r * c.K + k];
+        }
+        for (int n = 0; n < c.N; n += 7) {
+          double acc = hb[n];
+          for (int k = 0; k < c.K; ++k) acc += xin[k] * (double)hw[(size_t)n * c.K + k];
+          maxerr = fmax(maxerr, fabs(acc - (double)hy[(size_t)r * c.N + n]));
+        }
+      }
+      snprintf(verdict, sizeof verdict, "  max|err| %.4f %s", maxerr, maxerr < 0.02 ? "ok" : "MISMATCH");
+    }
+    printf("%-30s %-10s %7.2f us/launch %7.0f GB/s%s\n", c.name, vnames[variant], ms * 1e3f / iters, (double)c.N * c.K * 2 / (ms * 1e3f / iters) * 1e-3, verdict);
   }
   {  // logits
     for (int rep = 0; rep < 2; ++rep) {
@@ -132,6 +171,7 @@ int main(int argc, char** argv) {
         whk::GemvArgs g; memset(&g, 0, sizeof(g));
         g.pro = whk::PRO_LN; g.xf = xf; g.xf_ld = D; g.ln_w = lnw; g.ln_b = lnb;
         g.W = W + wl * L; g.N = V; g.K = D; g.R = R; g.epi = whk::EPI_F32; g.y = logits; g.y_ld = V; g.probe = d_probe;
+        g.variant = argc > 3 ? atoi(argv[3]) : 0;
         CK(whk::launch_gemv(g, 1, st));
       }
       if (rep == 1) CK(hipEventRecord(e1, st));

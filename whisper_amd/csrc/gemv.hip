@@ -54,30 +54,38 @@ template <> struct Pack4<half_t> {
 // WAVES x 64 threads per workgroup, arranged as GS feature-group slots x KS = WAVES / GS splits of K.
 // A single wave issues one VALU instruction every ~8.6 cycles (tools/ubench_valu), so the per-wave
 // instruction chain — not FLOPs — bounds these kernels: wide workgroups cut the chain per wave.
-template <typename T, int RT, int LPR, int PRO, int J, bool MULTI, int WAVES, int GS>
+// MF (fp16 only, EXPERIMENT — instantiated only by tools/probe_decode): the dot products of a wave-load run
+// as ONE v_mfma_f32_16x16x32_f16 instead of 8 x 4 v_dot2 per lane — a wave-load is then 16 weight rows x 64 B
+// (lane -> row lane % 16, k-chunk lane / 16, i.e. exactly the MFMA A fragment), x is the B fragment.  Measured on
+// MI355X at R = 8: no faster than the v_dot2 forms (launch + memory latency dominate, not the dot products), so
+// the product path keeps the decode projections on the VALU as BASELINE.json's north_star asks.
+template <typename T, int RT, int LPR, int PRO, int J, bool MULTI, int WAVES, int GS, bool MF>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int gp, int red_alias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename ET<T>::unit_t unit_t;
   constexpr int UNIT = ET<T>::UNIT;
   constexpr int NT = WAVES * 64;
   constexpr int KS = WAVES / GS;         // waves splitting K for one feature group
-  constexpr int NU = WAVES == 4 ? 10 : 5;   // weight units (16 B) in flight per lane per buffer
-  constexpr int NB = 64 / LPR;           // output features per group (= weight rows per wave-load)
+  constexpr int NU = (WAVES == 4 || MF) ? 10 : 5;   // weight units (16 B) in flight per lane per buffer
+  constexpr int NB = 64 / LPR;           // output features per group (= weight rows per wave-load); MF: LPR == 4
   constexpr int BLK = LPR * UNIT;        // K elements covered by one wave-load
+  static_assert(!MF || (sizeof(T) == 2 && LPR == 4 && RT >= 8), "MFMA form: fp16, 16 rows x 32 k per wave-load");
   constexpr int NR = (RT + WAVES - 1) / WAVES;   // LayerNorm rows per wave
   constexpr int TPR = NT / RT;           // PRO_PLAIN: threads staging one row
   constexpr int CT = NT == 256 ? 10 : (NT == 512 ? 5 : 3);   // PRO_COMBINE fast path: tasks per thread
   static_assert(!MULTI || (WAVES == 4 && GS == 1), "MULTI is the 4-wave streaming form");
   const int K = a.K;
-  T* xs = (T*)smem;                                              // [RT][K]
+  const int xld = MF ? K + 16 : K;       // MF: +32 B per row spreads the 8 x-rows of a B-fragment read over all banks
+  T* xs = (T*)smem;                                              // [RT][xld]
   // cross-wave partial sums [WAVES][NB][RT]; aliases xs when the workgroup makes a single pass
-  float* red = red_alias ? (float*)smem : (float*)(smem + (size_t)RT * K * sizeof(T));
+  float* red = red_alias ? (float*)smem : (float*)(smem + (size_t)RT * xld * sizeof(T));
   float* csc = red + WAVES * NB * RT;                            // PRO_COMBINE: [RT*H][CS] merge weights
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slot = wave / KS, kw = wave % KS;
-  const int sub = lane % LPR, fr = lane / LPR;
+  // VALU form: LPR lanes walk one weight row (sub = 16-byte unit, fr = row); MFMA form: the A-fragment map
+  const int sub = MF ? lane / 16 : lane % LPR, fr = MF ? lane % 16 : lane / LPR;
   const int r0 = blockIdx.y * RT;
   int R = a.R - r0; if (R > RT) R = RT;
   const int nblk = K / BLK;
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
 #pragma unroll
           for (int e = 0; e < UNIT; ++e) v[e] = 0;
         }
-        *(unit_t*)(xs + (size_t)r * K + u * UNIT) = v;
+        *(unit_t*)(xs + (size_t)r * xld + u * UNIT) = v;
       }
     }
   } else if (PRO == whk::PRO_LN) {
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
           }
         }
         const float rstd = rsqrtf(wave_sum(ss) * invK + 1e-5f);
-        T* xr = xs + (size_t)r * K;
+        T* xr = xs + (size_t)r * xld;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
           const int k = (j * 64 + lane) * 4;
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
             num[0] = __builtin_fmaf(w, o[j][s][0], num[0]); num[1] = __builtin_fmaf(w, o[j][s][1], num[1]);
             num[2] = __builtin_fmaf(w, o[j][s][2], num[2]); num[3] = __builtin_fmaf(w, o[j][s][3], num[3]);
           }
-          Pack4<T>::store(xs + (size_t)r * K + h * 64 + d4 * 4, num[0], num[1], num[2], num[3]);
+          Pack4<T>::store(xs + (size_t)r * xld + h * 64 + d4 * 4, num[0], num[1], num[2], num[3]);
         }
       }
     } else {
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
           }
         }
         const float inv = 1.0f / den;
-        Pack4<T>::store(xs + (size_t)r * K + h * 64 + d4 * 4, num[0] * inv, num[1] * inv, num[2] * inv, num[3] * inv);
+        Pack4<T>::store(xs + (size_t)r * xld + h * 64 + d4 * 4, num[0] * inv, num[1] * inv, num[2] * inv, num[3] * inv);
       }
       load_item(0, wa);
     }
@@ -295,16 +303,29 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
   float acc[RT];
 #pragma unroll
   for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+  float4v macc = {0.f, 0.f, 0.f, 0.f};   // MF: out[x row lane % 16][feature 4 * (lane / 16) + e]
 
   // x of weight unit u for all rows, read one unit ahead of the dot products
   auto compute_item = [&](int it, const unit_t* w) {
     const int b = MULTI ? it - (it / nbatch) * nbatch : 0;
+    if constexpr (MF) {
+      const T* xrow = xs + (size_t)(fr % RT) * xld + sub * UNIT;      // B fragment: column = x row (duplicated)
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int ub = kw + KS * (b * NU + u);
+        if (ub < nblk) {
+          const unit_t xf = *(const unit_t*)(xrow + (size_t)ub * BLK);
+          macc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u], xf, macc, 0, 0, 0);
+        }
+      }
+      return;
+    }
     unit_t xc[RT], xn[RT];
     auto fetch = [&](int u, unit_t* x) {
       int ub = kw + KS * (b * NU + u); if (ub > nblk - 1) ub = nblk - 1;
       const T* xb = xs + (size_t)ub * BLK + sub * UNIT;
 #pragma unroll
-      for (int r = 0; r < RT; ++r) x[r] = *(const unit_t*)(xb + (size_t)r * K);
+      for (int r = 0; r < RT; ++r) x[r] = *(const unit_t*)(xb + (size_t)r * xld);
     };
     fetch(0, xc);
 #pragma unroll
@@ -324,10 +345,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
 
   auto finish_group = [&](int it) {
     const int gbase = MULTI ? g0 + it / nbatch : g0;     // group of slot 0 in this pass
+    if constexpr (!MF) {
 #pragma unroll
-    for (int r = 0; r < RT; ++r) acc[r] = LPR == 8 ? group8_sum(acc[r]) : group16_sum(acc[r]);
+      for (int r = 0; r < RT; ++r) acc[r] = LPR == 8 ? group8_sum(acc[r]) : group16_sum(acc[r]);
+    }
     if (red_alias) __syncthreads();           // every wave is done reading xs before `red` overwrites it
-    if (sub == 0) {
+    if constexpr (MF) {
+      if (fr < RT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[(wave * NB + sub * 4 + e) * RT + fr] = macc[e];
+      }
+      macc = float4v{0.f, 0.f, 0.f, 0.f};
+    } else if (sub == 0) {
 #pragma unroll
       for (int r = 0; r < RT; ++r) red[(wave * NB + fr) * RT + r] = acc[r];
     }
@@ -390,12 +419,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
   if (a.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.bump, a.bump_by);
 }
 
-template <typename T, int RT, int LPR, int PRO, int J, bool MULTI, int WAVES, int GS>
+template <typename T, int RT, int LPR, int PRO, int J, bool MULTI, int WAVES, int GS, bool MF = false>
 hipError_t launch_cfg(const whk::GemvArgs& a, int gp, hipStream_t stream) {
   constexpr int NB = 64 / LPR;
   const int ngroups = (a.N + NB - 1) / NB;
   const int red_alias = (!MULTI || gp == 1) && PRO != whk::PRO_COMBINE ? 1 : 0;
-  size_t lds = (size_t)RT * a.K * sizeof(T);
+  size_t lds = (size_t)RT * (a.K + (MF ? 16 : 0)) * sizeof(T);
   const size_t red_bytes = (size_t)WAVES * NB * RT * sizeof(float);
   if (!red_alias) lds += red_bytes;
   else if (lds < red_bytes) lds = red_bytes;
@@ -403,41 +432,41 @@ hipError_t launch_cfg(const whk::GemvArgs& a, int gp, hipStream_t stream) {
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemv_kernel<T, RT, LPR, PRO, J, MULTI, WAVES, GS>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemv_kernel<T, RT, LPR, PRO, J, MULTI, WAVES, GS, MF>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  constexpr int KS_ = WAVES / GS, NU_ = WAVES == 4 ? 10 : 5, BLK_ = LPR * ET<T>::UNIT;
+  constexpr int KS_ = WAVES / GS, NU_ = (WAVES == 4 || MF) ? 10 : 5, BLK_ = LPR * ET<T>::UNIT;
   if (!MULTI && (a.K / BLK_ + KS_ - 1) / KS_ > NU_) return hipErrorInvalidValue;   // one batch per wave only
   const int per_wg = MULTI ? gp : GS;
   dim3 grid((ngroups + per_wg - 1) / per_wg, (a.R + RT - 1) / RT), block(WAVES * 64);
-  hipLaunchKernelGGL((gemv_kernel<T, RT, LPR, PRO, J, MULTI, WAVES, GS>), grid, block, lds, stream, a, gp, red_alias);
+  hipLaunchKernelGGL((gemv_kernel<T, RT, LPR, PRO, J, MULTI, WAVES, GS, MF>), grid, block, lds, stream, a, gp, red_alias);
   return hipGetLastError();
 }
 
-template <typename T, int RT, int LPR, bool MULTI, int WAVES, int GS>
+template <typename T, int RT, int LPR, bool MULTI, int WAVES, int GS, bool MF = false>
 hipError_t launch_pro(const whk::GemvArgs& a, int gp, hipStream_t stream) {
   constexpr int TPR = WAVES * 64 / RT;
   switch (a.pro) {
     case whk::PRO_PLAIN: {
       const int upr = a.K / ET<T>::UNIT;            // J = 16-byte units per thread per row
-      if (upr <= TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 1, MULTI, WAVES, GS>(a, gp, stream);
-      if (upr <= 3 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 3, MULTI, WAVES, GS>(a, gp, stream);
-      if (upr <= 6 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 6, MULTI, WAVES, GS>(a, gp, stream);
+      if (upr <= TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 1, MULTI, WAVES, GS, MF>(a, gp, stream);
+      if (upr <= 3 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 3, MULTI, WAVES, GS, MF>(a, gp, stream);
+      if (upr <= 6 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 6, MULTI, WAVES, GS, MF>(a, gp, stream);
       if (WAVES == 4) {                              // narrow workgroups stage long rows with more units per thread
-        if (upr <= 12 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 12, MULTI, WAVES, GS>(a, gp, stream);
-        if (upr <= 24 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 24, MULTI, WAVES, GS>(a, gp, stream);
+        if (upr <= 12 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 12, MULTI, WAVES, GS, MF>(a, gp, stream);
+        if (upr <= 24 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 24, MULTI, WAVES, GS, MF>(a, gp, stream);
       }
       return hipErrorInvalidValue;
     }
     case whk::PRO_LN:
-      if (a.K <= 256 * 5) return launch_cfg<T, RT, LPR, whk::PRO_LN, 5, MULTI, WAVES, GS>(a, gp, stream);
-      if (a.K <= 256 * 8) return launch_cfg<T, RT, LPR, whk::PRO_LN, 8, MULTI, WAVES, GS>(a, gp, stream);
+      if (a.K <= 256 * 5) return launch_cfg<T, RT, LPR, whk::PRO_LN, 5, MULTI, WAVES, GS, MF>(a, gp, stream);
+      if (a.K <= 256 * 8) return launch_cfg<T, RT, LPR, whk::PRO_LN, 8, MULTI, WAVES, GS, MF>(a, gp, stream);
       return hipErrorInvalidValue;
     case whk::PRO_COMBINE:
       if (a.K != a.H * 64) return hipErrorInvalidValue;
-      return launch_cfg<T, RT, LPR, whk::PRO_COMBINE, 1, MULTI, WAVES, GS>(a, gp, stream);
+      return launch_cfg<T, RT, LPR, whk::PRO_COMBINE, 1, MULTI, WAVES, GS, MF>(a, gp, stream);
   }
   return hipErrorInvalidValue;
 }
@@ -470,6 +499,23 @@ hipError_t launch_rt(const whk::GemvArgs& a, hipStream_t stream) {
     if ((nblk8 + 3) / 4 <= 10) return launch_pro<T, RT, 8, false, 4, 1>(a, 1, stream);
     return launch_pro<T, RT, 8, true, 4, 1>(a, 1, stream);
   }
+#ifdef WH_PROBE   // MFMA forms: measured, not faster on these latency-bound launches (profiles/r01_gemv_shape_sweep.txt);
+                  // compiled only into tools/probe_decode so the comparison stays reproducible
+  if constexpr (sizeof(T) == 2 && RT >= 8) {
+    if (a.K % 32 == 0) {
+      switch (force) {
+        case 11: return launch_pro<T, RT, 4, false, 4, 1, true>(a, 1, stream);
+        case 12: return launch_pro<T, RT, 4, false, 8, 1, true>(a, 1, stream);
+        case 13: return launch_pro<T, RT, 4, false, 8, 2, true>(a, 1, stream);
+        case 14: return launch_pro<T, RT, 4, false, 16, 4, true>(a, 1, stream);
+        case 15: return launch_pro<T, RT, 4, false, 16, 1, true>(a, 1, stream);
+        case 16: return launch_pro<T, RT, 4, false, 16, 2, true>(a, 1, stream);
+        case 17: return launch_pro<T, RT, 4, true, 4, 1, true>(a, ((a.N + 15) / 16 + 1023) / 1024, stream);
+        default: break;
+      }
+    }
+  }
+#endif
   switch (force) {
     case 1: return launch_pro<T, RT, 8, false, 4, 1>(a, 1, stream);
     case 2: return launch_pro<T, RT, 16, false, 4, 1>(a, 1, stream);
