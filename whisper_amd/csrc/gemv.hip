@@ -516,6 +516,7 @@ hipError_t launch_rt(const whk::GemvArgs& a, hipStream_t stream) {
     }
   }
 #endif
+#ifdef WH_PROBE
   switch (force) {
     case 1: return launch_pro<T, RT, 8, false, 4, 1>(a, 1, stream);
     case 2: return launch_pro<T, RT, 16, false, 4, 1>(a, 1, stream);
@@ -527,6 +528,9 @@ hipError_t launch_rt(const whk::GemvArgs& a, hipStream_t stream) {
     case 8: return launch_pro<T, RT, 8, false, 16, 4>(a, 1, stream);
     default: return hipErrorInvalidValue;
   }
+#else
+  return hipErrorInvalidValue;
+#endif
 }
 
 }  // namespace
