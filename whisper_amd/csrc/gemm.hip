@@ -18,12 +18,14 @@
 // FMA chain.  Workgroup ids are remapped so each XCD's L2 sees a contiguous band of tiles.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
-constexpr int TILE_BYTES = 128 * 128;     // one operand tile: 128 rows x 128 bytes
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+// Two tile shapes share the code: 128x128 (4 waves, 2x2 of 64x64) for small / skinny problems and 256x256
+// (8 waves, 2x4 of 128x64) for the encoder-sized ones.  At 128x128 the L2->LDS stream needs 64 B/clk/CU at MFMA
+// peak (64 FLOP/B = exactly the machine's ridge), which is what capped round 1's first GEMM at ~25 % of peak;
+// 256x256 doubles the FLOP per staged byte.  Either way a wave stages 4 + 4 rows-of-8 per K step.
 
 __device__ __forceinline__ void mma16(half8v a, half8v b, float4v& c) {
   c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -52,16 +54,22 @@ template <> struct Out4<half_t> {
   }
 };
 
-template <typename T, typename OutT>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(whk::GemmArgs p) {
+// WGM x WGN waves, each computing FM x FN MFMA 16x16 tiles
+template <typename T, typename OutT, int WGM, int WGN, int FM, int FN>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(whk::GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename ET<T>::unit_t unit_t;
   constexpr int UNIT = ET<T>::UNIT;
   constexpr int BKE = 128 / (int)sizeof(T);
+  constexpr int NW = WGM * WGN;
+  constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
+  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
+  constexpr int IA = BM / (NW * 8), IW = BN / (NW * 8);      // wave-loads (8 rows each) per wave per K step
+  static_assert(IA * NW * 8 == BM && IW * NW * 8 == BN, "tile rows must split evenly over the waves");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
 
   // XCD-aware, bijective remap of the linear workgroup id (block b runs on XCD b % 8)
   const int nwg = gridDim.x, orig = blockIdx.x;
@@ -74,35 +82,40 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(whk::GemmArgs p) {
   const T* A = (const T*)p.A + bz * p.a_bs;
   const T* W = (const T*)p.W + bz * p.w_bs;
 
-  // staging: wave issues 4 A + 4 W instructions per K step; instruction i covers tile rows
-  // [(wave*4+i)*8, +8): lane -> row (lane>>3), LDS unit slot (lane&7)
-  const T* ga[4];
-  const T* gw[4];
+  // staging: wave issues IA A + IW W instructions per K step; instruction i covers tile rows
+  // [(wave*I+i)*8, +8): lane -> row (lane>>3), LDS unit slot (lane&7)
+  const T* ga[IA];
+  const T* gw[IW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wave * 4 + i) * 8 + (lane >> 3);
+  for (int i = 0; i < IA; ++i) {
+    const int r = (wave * IA + i) * 8 + (lane >> 3);
     const int u = (lane & 7) ^ ((r >> 1) & 7);
     int am = m0 + r; if (am > p.M - 1) am = p.M - 1;
-    int wr = n0 + r; if (wr > p.N - 1) wr = p.N - 1;
     ga[i] = A + (int64_t)am * p.lda + u * UNIT;
+  }
+#pragma unroll
+  for (int i = 0; i < IW; ++i) {
+    const int r = (wave * IW + i) * 8 + (lane >> 3);
+    const int u = (lane & 7) ^ ((r >> 1) & 7);
+    int wr = n0 + r; if (wr > p.N - 1) wr = p.N - 1;
     gw[i] = W + (int64_t)wr * p.ldw + u * UNIT;
   }
 
-  float4v acc[4][4];
+  float4v acc[FN][FM];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FN; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FM; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BKE;
   auto stage = [&](int buf, int kt) {
-    char* sA = smem + buf * STAGE_BYTES + (wave * 4) * 1024;
-    char* sW = sA + TILE_BYTES;
+    char* sA = smem + buf * STAGE_BYTES + (wave * IA) * 1024;
+    char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wave * IW) * 1024;
     const int64_t ko = (int64_t)kt * BKE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(ga[i] + ko, sA + i * 1024);
+    for (int i = 0; i < IA; ++i) glds16(ga[i] + ko, sA + i * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(gw[i] + ko, sW + i * 1024);
+    for (int i = 0; i < IW; ++i) glds16(gw[i] + ko, sW + i * 1024);
   };
 
   stage(0, 0);
@@ -110,6 +123,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(whk::GemmArgs p) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
       stage(cur ^ 1, kt + 1);
+      static_assert(IA + IW == 8, "the counted wait below assumes 8 wave-loads per stage");
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile kt landed; tile kt+1 stays in flight
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -117,40 +131,37 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(whk::GemmArgs p) {
     __builtin_amdgcn_s_barrier();
 
     const char* sA = smem + cur * STAGE_BYTES;
-    const char* sW = sA + TILE_BYTES;
+    const char* sW = sA + A_BYTES;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      unit_t af[4], wf[4];
+      unit_t af[FM], wf[FN];
       const int u = 4 * q + (lane >> 4);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int ra = wm * 64 + t * 16 + (lane & 15);
-        const int rw = wn * 64 + t * 16 + (lane & 15);
-        af[t] = *(const unit_t*)(sA + swz_byte(ra, u));
-        wf[t] = *(const unit_t*)(sW + swz_byte(rw, u));
-      }
+      for (int t = 0; t < FM; ++t) af[t] = *(const unit_t*)(sA + swz_byte(wm * (FM * 16) + t * 16 + (lane & 15), u));
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
+      for (int t = 0; t < FN; ++t) wf[t] = *(const unit_t*)(sW + swz_byte(wn * (FN * 16) + t * 16 + (lane & 15), u));
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm) mma16(wf[tn], af[tm], acc[tn][tm]);
+      for (int tn = 0; tn < FN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < FM; ++tm) mma16(wf[tn], af[tm], acc[tn][tm]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // everyone finished reading buf[cur] before it is refilled
   }
 
-  // ---- epilogue: lane holds C[m][n..n+3] for m = m0+wm*64+tm*16+(lane&15), n = n0+wn*64+tn*16+(lane>>4)*4
+  // ---- epilogue: lane holds C[m][n..n+3] for m = m0+wm*FM*16+tm*16+(lane&15), n = n0+wn*FN*16+tn*16+(lane>>4)*4
   OutT* C = (OutT*)p.C + bz * p.c_bs;
   const float* R = p.res ? p.res + bz * p.r_bs : nullptr;
   const bool vec_ok = ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0);
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
-    const int m = m0 + wm * 64 + tm * 16 + (lane & 15);
+  for (int tm = 0; tm < FM; ++tm) {
+    const int m = m0 + wm * (FM * 16) + tm * 16 + (lane & 15);
     if (m >= p.M) continue;
     const int rm = (p.res_mod > 0) ? (m % p.res_mod) : m;
     const float bm = (p.bias && p.bias_on_m) ? p.bias[m] : 0.f;
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      const int n = n0 + wn * 64 + tn * 16 + (lane >> 4) * 4;
+    for (int tn = 0; tn < FN; ++tn) {
+      const int n = n0 + wn * (FN * 16) + tn * 16 + (lane >> 4) * 4;
       if (n >= p.N) continue;
       float4v v = acc[tn][tm];
       if (p.bias) {
@@ -184,20 +195,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(whk::GemmArgs p) {
   }
 }
 
-template <typename T, typename OutT>
-hipError_t launch_t(const whk::GemmArgs& a, int batch, hipStream_t stream) {
+template <typename T, typename OutT, int WGM, int WGN, int FM, int FN>
+hipError_t launch_shape(const whk::GemmArgs& a, int batch, hipStream_t stream) {
+  constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
+  constexpr int LDS = 2 * (BM + BN) * 128;
   whk::GemmArgs p = a;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              2 * STAGE_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, WGM, WGN, FM, FN>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, OutT>), grid, dim3(256), 2 * STAGE_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, WGM, WGN, FM, FN>), grid, dim3(WGM * WGN * 64), LDS, stream, p);
   return hipGetLastError();
+}
+
+template <typename T, typename OutT>
+hipError_t launch_t(const whk::GemmArgs& a, int batch, hipStream_t stream) {
+  static const int force = [] { const char* e = getenv("WH_GEMM_TILE"); return e ? atoi(e) : 0; }();   // 128 / 256: developer override
+  // measured on MI355X (large-v3 encoder, B = 8): both shapes land within 3 % of each other (550-700 TFLOP/s), so the
+  // limiter is not the L2->LDS stream the big tile was meant to relieve; 128x128 stays the default until the K loop
+  // itself (2-deep LDS ring, two barriers per step, GELU epilogue) is re-worked.
+  const bool big = force == 256;
+  if (big) return launch_shape<T, OutT, 2, 4, 8, 4>(a, batch, stream);
+  return launch_shape<T, OutT, 2, 2, 4, 4>(a, batch, stream);
 }
 
 }  // namespace
