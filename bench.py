@@ -214,31 +214,12 @@ def main():
         dist.destroy_process_group()
 
 
-def usable_cores() -> int:
-    """host cores this process may really use: affinity mask capped by the cgroup CPU quota (a container that
-    sees 256 CPUs under a 16-CPU quota is throttled ~20x when torch spawns one thread per visible CPU)"""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota|max> <period>"
-            q, p = f.read().split()[:2]
-        if q != "max":
-            n = min(n, max(1, -(-int(q) // int(p))))
-    except (OSError, ValueError):
-        try:                                                           # cgroup v1
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0 and p > 0:
-                n = min(n, max(1, -(-q // p)))
-        except (OSError, ValueError):
-            pass
-    return n
-
-
 def cpu_baseline(args, dims, init, suppress, tok, audio_np):
     """Oracle = "port": same algorithm as the reference's CPU fp32 path.  Bounded sample: 1 clip, log-mel +
     encoder + `cpu_steps` decode steps; audio-s/s extrapolated linearly to `sample_len` steps."""
     import oracle
     from whisper_amd.synthetic import synthetic_state_dict
+    from whisper_amd.utils import usable_cores
     cores = getattr(args, "cpu_threads", 0) or usable_cores()
     torch.set_num_threads(cores)
     log(f"cpu_baseline: building {args.model} fp32 oracle on {cores} host threads")

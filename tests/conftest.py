@@ -12,6 +12,14 @@ SHIMS = os.path.join(ROOT, "tests", "shims")
 
 
 def pytest_configure(config):
+    # the CPU oracle runs on torch's intra-op pool: size it by the cores we may really use (cgroup quota), not by
+    # the visible CPU count — on the GPU box that is 16 vs 256 and a 20x difference in oracle time
+    try:
+        import torch
+        from whisper_amd.utils import usable_cores
+        torch.set_num_threads(usable_cores())
+    except Exception:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
     config.addinivalue_line("markers", "reference: needs the read-only reference checkout at /root/reference")
 

@@ -25,6 +25,8 @@ _DIMS = {
     # reduced-depth shapes for fast tests (same widths / vocab as the real ones)
     "micro.en": (80, 384, 6, 2, 2, 51864), "micro": (80, 384, 6, 2, 2, 51865),
     "micro-v3": (128, 384, 6, 2, 2, 51866),
+    # large-v3 widths at 2 + 2 layers: exercises the D = 1280 kernel shapes against the CPU oracle in seconds
+    "wide-v3": (128, 1280, 20, 2, 2, 51866),
 }
 
 

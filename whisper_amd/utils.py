@@ -2,6 +2,7 @@
 The file writers of the reference (utils.py:85-318) are outside the hot-path scope."""
 from __future__ import annotations
 
+import os
 import sys
 import zlib
 from typing import List, Optional
@@ -49,3 +50,26 @@ def get_end(segments: List[dict]) -> Optional[float]:
         for w in reversed(s["words"]):
             return w["end"]
     return segments[-1]["end"] if segments else None
+
+
+def usable_cores() -> int:
+    """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota.  A container that
+    sees 256 CPUs under a 16-CPU quota is throttled ~20x when a thread pool is sized by the visible count; the
+    CPU-side timing helpers (bench.py cpu_baseline, the CPU oracle in tests) size their pools with this."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota|max> <period>"
+            q, p = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        try:                                                           # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
