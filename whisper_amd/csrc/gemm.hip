@@ -217,10 +217,10 @@ hipError_t launch_shape(const whk::GemmArgs& a, int batch, hipStream_t stream) {
 template <typename T, typename OutT>
 hipError_t launch_t(const whk::GemmArgs& a, int batch, hipStream_t stream) {
   static const int force = [] { const char* e = getenv("WH_GEMM_TILE"); return e ? atoi(e) : 0; }();   // 128 / 256: developer override
-  // measured on MI355X (large-v3 encoder, B = 8): both shapes land within 3 % of each other (550-700 TFLOP/s), so the
-  // limiter is not the L2->LDS stream the big tile was meant to relieve; 128x128 stays the default until the K loop
-  // itself (2-deep LDS ring, two barriers per step, GELU epilogue) is re-worked.
-  const bool big = force == 256;
+  // tools/probe_gemm on MI355X (M = 12000): 256x256 is 12-17 % faster on every encoder shape (e.g. N=2560 K=1280:
+  // 648 vs 548 TFLOP/s; N=1280 K=5120: 949 vs 809).  The K loop itself runs at ~1.2 PFLOP/s; at K = 1280 half of a
+  // launch is fixed cost (first-tile latency, fp32 residual read-modify-write epilogue, exact-erf GELU +13 %).
+  const bool big = force ? force == 256 : (a.M >= 1024 && a.N >= 1024);
   if (big) return launch_shape<T, OutT, 2, 4, 8, 4>(a, batch, stream);
   return launch_shape<T, OutT, 2, 2, 4, 4>(a, batch, stream);
 }
