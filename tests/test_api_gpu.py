@@ -204,3 +204,32 @@ def test_transcribe_golden(setup):
     for s in r["segments"]:
         assert {"id", "seek", "start", "end", "text", "tokens", "temperature", "avg_logprob", "compression_ratio",
                 "no_speech_prob", "words"} <= set(s)
+
+
+@pytest.mark.parametrize("cond", [False, True])
+def test_transcribe_batch_equals_sequential(setup, cond):
+    """transcribe_batch (lock-step batching over files) must return exactly what transcribe() returns
+    file by file — same tokens, seeks, boundaries, word times — for files of different lengths (1, 2 and 3 windows),
+    with and without conditioning on the previous window (with it, prompts diverge and rounds fall back to groups
+    of identical prompts).  fp32 strict engine: the batched and single decodes are compared for exact equality."""
+    key, dims, sd, model, mel = setup
+    files = [audio(31, 200000), np.concatenate([audio(32), audio(33, 240000)]),
+             np.concatenate([audio(34), audio(35), audio(36, 100000)]), audio(37, 480000)]
+    kw = dict(temperature=0.0, fp16=False, language="en", sample_len=12, word_timestamps=True,
+              condition_on_previous_text=cond, no_speech_threshold=None, logprob_threshold=None,
+              compression_ratio_threshold=None)
+    want = [model.transcribe(a, **kw) for a in files]
+    got = model.transcribe_batch(files, **kw)
+    assert len(got) == len(want)
+    n_windows = 0
+    for g, w in zip(got, want):
+        assert g["language"] == w["language"] and g["text"] == w["text"]
+        assert [s["tokens"] for s in g["segments"]] == [s["tokens"] for s in w["segments"]]
+        assert [s["seek"] for s in g["segments"]] == [s["seek"] for s in w["segments"]]
+        assert np.allclose([[s["start"], s["end"]] for s in g["segments"]], [[s["start"], s["end"]] for s in w["segments"]])
+        gw = [[x["start"], x["end"]] for s in g["segments"] for x in s["words"]]
+        ww = [[x["start"], x["end"]] for s in w["segments"] for x in s["words"]]
+        assert np.allclose(gw, ww, atol=0.0201)
+        assert np.allclose([s["avg_logprob"] for s in g["segments"]], [s["avg_logprob"] for s in w["segments"]], atol=1e-4)
+        n_windows += len({s["seek"] for s in w["segments"]})
+    assert n_windows >= 6

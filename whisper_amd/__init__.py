@@ -24,7 +24,7 @@ from .decoding import DecodingOptions, DecodingResult, decode, detect_language
 from .model import ModelDimensions, Whisper
 from .registry import ALIGNMENT_HEADS as _ALIGNMENT_HEADS
 from .registry import MODEL_URLS as _MODELS
-from .transcribe import transcribe
+from .transcribe import transcribe, transcribe_batch
 
 __version__ = "0.1.0"
 

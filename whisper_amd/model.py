@@ -24,6 +24,7 @@ from . import hip
 from .decoding import decode as decode_function
 from .decoding import detect_language as detect_language_function
 from .transcribe import transcribe as transcribe_function
+from .transcribe import transcribe_batch as transcribe_batch_function
 
 
 @dataclass
@@ -172,4 +173,5 @@ class Whisper:
 
     detect_language = detect_language_function
     transcribe = transcribe_function
+    transcribe_batch = transcribe_batch_function     # extension: lock-step batching over files
     decode = decode_function

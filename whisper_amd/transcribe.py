@@ -76,32 +76,53 @@ class _Transcriber:
         self.clip_timestamps = clip_timestamps
 
     # ---- one window ------------------------------------------------------------------------------------
-    def decode_with_fallback(self, segment: torch.Tensor) -> DecodingResult:
+    def decode_with_fallback(self, segment: torch.Tensor, first: int = 0) -> DecodingResult:
         """retry at increasing temperature while the output is too repetitive or too improbable
-        (reference transcribe.py:184-224)"""
+        (reference transcribe.py:184-224); `first` skips temperatures already tried by a batched pass"""
         result = None
-        for t in self.temperatures:
-            kwargs = {**self.decode_options}
-            if t > 0:
-                kwargs.pop("beam_size", None)      # sampling: no beams
-                kwargs.pop("patience", None)
-            else:
-                kwargs.pop("best_of", None)        # greedy / beam: no best-of
-            result = self.model.decode(segment, DecodingOptions(**kwargs, temperature=t))
-            retry = False
-            if (self.compression_ratio_threshold is not None
-                    and result.compression_ratio > self.compression_ratio_threshold):
-                retry = True
-            if self.logprob_threshold is not None and result.avg_logprob < self.logprob_threshold:
-                retry = True
-            if (self.no_speech_threshold is not None and result.no_speech_prob > self.no_speech_threshold
-                    and self.logprob_threshold is not None and result.avg_logprob < self.logprob_threshold):
-                retry = False                      # it is silence, not a failure
-            if not retry:
+        for t in self.temperatures[first:]:
+            result = self.model.decode(segment, self._options_for(t))
+            if not self._needs_retry(result):
                 break
         return result
 
+    def _needs_retry(self, result: DecodingResult) -> bool:
+        """the fallback criteria of reference transcribe.py:202-222"""
+        retry = False
+        if (self.compression_ratio_threshold is not None
+                and result.compression_ratio > self.compression_ratio_threshold):
+            retry = True
+        if self.logprob_threshold is not None and result.avg_logprob < self.logprob_threshold:
+            retry = True
+        if (self.no_speech_threshold is not None and result.no_speech_prob > self.no_speech_threshold
+                and self.logprob_threshold is not None and result.avg_logprob < self.logprob_threshold):
+            retry = False                      # it is silence, not a failure
+        return retry
+
+    def _options_for(self, t: float) -> DecodingOptions:
+        kwargs = {**self.decode_options}
+        if t > 0:
+            kwargs.pop("beam_size", None)      # sampling: no beams
+            kwargs.pop("patience", None)
+        else:
+            kwargs.pop("best_of", None)        # greedy / beam: no best-of
+        return DecodingOptions(**kwargs, temperature=t)
+
     def run(self, audio) -> dict:
+        """one file, windows decoded one at a time (the reference's control flow)"""
+        walk = self._walk(audio)
+        try:
+            segment = next(walk)
+            while True:
+                segment = walk.send(self.decode_with_fallback(segment))
+        except StopIteration as stop:
+            return stop.value
+
+    def _walk(self, audio):
+        """The per-file state machine of reference transcribe.py:126-514 as a generator: yields the next 30 s mel
+        window to decode (with `self.decode_options["prompt"]` already set for it) and is sent its DecodingResult;
+        returns the result dict.  `run` drives one file; `transcribe_batch` drives many files in lock-step so that
+        their windows share one batched decode."""
         model, opts = self.model, self.decode_options
         dtype = torch.float16 if opts.get("fp16", True) else torch.float32
         if model.device == torch.device("cpu"):
@@ -197,7 +218,7 @@ class _Transcriber:
                 else:
                     opts["prompt"] = all_tokens[prompt_reset_since:]
 
-                result = self.decode_with_fallback(mel_segment)
+                result = yield mel_segment
                 tokens = torch.tensor(result.tokens)
 
                 if self.no_speech_threshold is not None:
@@ -348,3 +369,70 @@ def transcribe(
         condition_on_previous_text, initial_prompt, carry_initial_prompt, word_timestamps, prepend_punctuations,
         append_punctuations, clip_timestamps, hallucination_silence_threshold, decode_options,
     ).run(audio)
+
+
+def _options_key(opts: dict):
+    """hashable identity of a DecodingOptions kwargs dict: windows may share one batched decode only if every
+    option — including the prompt tokens — is the same (DecodingTask builds ONE initial token sequence per call,
+    reference decoding.py:719)"""
+    def freeze(v):
+        if isinstance(v, (list, tuple)):
+            return tuple(freeze(x) for x in v)
+        if isinstance(v, torch.Tensor):
+            return tuple(v.flatten().tolist())
+        return v
+    return tuple(sorted((k, freeze(v)) for k, v in opts.items()))
+
+
+def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, **kwargs) -> List[dict]:
+    """Transcribe several files at once (no counterpart in the reference, which is strictly
+    one file at a time).  Every file keeps its own seek / prompt / fallback state machine exactly as `transcribe`;
+    the driver advances them in lock-step and decodes the windows that are pending at the same moment — and whose
+    decoding options, prompt included, are identical — as ONE batch of up to `batch_size` rows.  Results are the
+    same dicts `transcribe` returns, in input order.  Windows of one file stay sequential (seek and prompt depend on
+    the previous window); with `condition_on_previous_text=False` all files share their prompt and every round is
+    one batch.  A window whose batched result trips the temperature-fallback criteria is re-decoded on its own
+    from the next temperature, as the reference would."""
+    names = ("verbose", "temperature", "compression_ratio_threshold", "logprob_threshold", "no_speech_threshold",
+             "condition_on_previous_text", "initial_prompt", "carry_initial_prompt", "word_timestamps",
+             "prepend_punctuations", "append_punctuations", "clip_timestamps", "hallucination_silence_threshold")
+    defaults = dict(verbose=None, temperature=(0.0, 0.2, 0.4, 0.6, 0.8, 1.0), compression_ratio_threshold=2.4,
+                    logprob_threshold=-1.0, no_speech_threshold=0.6, condition_on_previous_text=True,
+                    initial_prompt=None, carry_initial_prompt=False, word_timestamps=False,
+                    prepend_punctuations="\"'“¿([{-", append_punctuations="\"'.。,，!！?？:：”)]}、",
+                    clip_timestamps="0", hallucination_silence_threshold=None)
+    fixed = {k: kwargs.pop(k, defaults[k]) for k in names}
+    workers = [_Transcriber(model, *[fixed[k] for k in names], dict(kwargs)) for _ in audios]
+    walks = [w._walk(a) for w, a in zip(workers, audios)]
+    results: List[Optional[dict]] = [None] * len(walks)
+    pending = {}
+
+    def advance(i: int, value):
+        try:
+            pending[i] = walks[i].send(value) if value is not None else next(walks[i])
+        except StopIteration as stop:
+            pending.pop(i, None)
+            results[i] = stop.value
+
+    for i in range(len(walks)):
+        advance(i, None)
+    while pending:
+        groups = {}
+        for i in sorted(pending):
+            groups.setdefault(_options_key(workers[i].decode_options), []).append(i)
+        answers = {}
+        for members in groups.values():
+            for at in range(0, len(members), batch_size):
+                chunk = members[at: at + batch_size]
+                lead = workers[chunk[0]]
+                if len(chunk) == 1:
+                    answers[chunk[0]] = lead.decode_with_fallback(pending[chunk[0]])
+                    continue
+                decoded = model.decode(torch.stack([pending[i] for i in chunk]), lead._options_for(lead.temperatures[0]))
+                for i, result in zip(chunk, decoded):
+                    if workers[i]._needs_retry(result) and len(workers[i].temperatures) > 1:
+                        result = workers[i].decode_with_fallback(pending[i], first=1)
+                    answers[i] = result
+        for i, result in answers.items():
+            advance(i, result)
+    return results
