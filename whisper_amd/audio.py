@@ -59,8 +59,15 @@ def _read_wav(path: str, sr: int) -> Optional[np.ndarray]:
         x = (np.frombuffer(pcm, np.uint8).astype(np.float32) - 128.0) / 128.0
     else:
         return None
-    x = x[: len(x) // channels * channels].reshape(-1, channels).mean(axis=1)
-    if rate != sr:   # linear-phase polyphase resampling
+    x = x[: len(x) // channels * channels].reshape(-1, channels)
+    return _to_mono_s16(x, rate, sr)
+
+
+def _to_mono_s16(x: np.ndarray, rate: int, sr: int) -> np.ndarray:
+    """[frames][channels] float in [-1, 1) -> what `ffmpeg -ac 1 -ar sr -f s16le` hands the reference: equal-weight
+    down-mix, linear-phase polyphase resampling, 16-bit quantisation."""
+    x = x.mean(axis=1)
+    if rate != sr:
         from math import gcd
         from scipy.signal import resample_poly
         g = gcd(int(rate), int(sr))
@@ -69,18 +76,71 @@ def _read_wav(path: str, sr: int) -> Optional[np.ndarray]:
     return (np.clip(np.round(x * 32768.0), -32768, 32767) / 32768.0).astype(np.float32)
 
 
+_AUDIO_LIB = None
+
+
+def _audio_lib():
+    """whisper_amd/libwhisper_audio.so (csrc/flac_decode.c, plain C built by `make -C whisper_amd/csrc`)"""
+    global _AUDIO_LIB
+    if _AUDIO_LIB is None:
+        import ctypes as C
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwhisper_audio.so")
+        if not os.path.isfile(path):
+            raise RuntimeError(f"{path} is missing: build it with `make -C whisper_amd/csrc`")
+        lib = C.CDLL(path)
+        lib.wh_flac_decode.restype = C.c_int
+        lib.wh_flac_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int64),
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.wh_flac_free.restype = None
+        lib.wh_flac_free.argtypes = [C.POINTER(C.c_int32)]
+        lib.wh_flac_error.restype = C.c_char_p
+        lib.wh_flac_error.argtypes = [C.c_int]
+        _AUDIO_LIB = lib
+    return _AUDIO_LIB
+
+
+def decode_flac(data: bytes):
+    """FLAC bytes -> (int32 samples [frames][channels], sample_rate, bits_per_sample); CRC-8/16 of every frame and
+    the STREAMINFO MD5 of the decoded audio are verified by the decoder (RuntimeError otherwise)."""
+    import ctypes as C
+    lib = _audio_lib()
+    ptr, n, ch, rate, bps = C.POINTER(C.c_int32)(), C.c_int64(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib.wh_flac_decode(data, len(data), C.byref(ptr), C.byref(n), C.byref(ch), C.byref(rate), C.byref(bps))
+    if rc != 0:
+        raise RuntimeError(f"Failed to load audio: {lib.wh_flac_error(rc).decode()}")
+    try:
+        pcm = np.ctypeslib.as_array(ptr, shape=(n.value * ch.value,)).reshape(n.value, ch.value).copy()
+    finally:
+        lib.wh_flac_free(ptr)
+    return pcm, rate.value, bps.value
+
+
+def _read_flac(path: str, sr: int) -> Optional[np.ndarray]:
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"fLaC" and data[:3] != b"ID3":
+        return None
+    pcm, rate, bps = decode_flac(data)
+    return _to_mono_s16(pcm.astype(np.float32) / float(1 << (bps - 1)), rate, sr)
+
+
 def load_audio(file: str, sr: int = SAMPLE_RATE) -> np.ndarray:
     """Decode `file` to mono float32 at `sr` Hz.  Same contract as the reference (audio.py:25-62): ffmpeg does
     the decoding / down-mixing / resampling; a RuntimeError is raised when it fails.  When the ffmpeg binary
-    does not exist, RIFF/WAVE files are read natively."""
+    does not exist, RIFF/WAVE files are read natively and FLAC files through the native decoder of
+    csrc/flac_decode.c (frame CRCs and the stream's MD5 signature are verified)."""
     cmd = ["ffmpeg", "-nostdin", "-threads", "0", "-i", file, "-f", "s16le", "-ac", "1",
            "-acodec", "pcm_s16le", "-ar", str(sr), "-"]
     try:
         out = subprocess.run(cmd, capture_output=True, check=True).stdout
     except FileNotFoundError:
-        wav = _read_wav(file, sr) if os.path.isfile(file) else None
+        wav = None
+        if os.path.isfile(file):
+            wav = _read_wav(file, sr)
+            if wav is None:
+                wav = _read_flac(file, sr)
         if wav is None:
-            raise RuntimeError("Failed to load audio: ffmpeg is not installed and the file is not RIFF/WAVE")
+            raise RuntimeError("Failed to load audio: ffmpeg is not installed and the file is neither RIFF/WAVE nor FLAC")
         return wav
     except subprocess.CalledProcessError as e:
         raise RuntimeError(f"Failed to load audio: {e.stderr.decode()}") from e
