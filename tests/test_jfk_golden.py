@@ -1,0 +1,77 @@
+"""BASELINE.json configs[0] — "tiny.en, tests/jfk.flac, greedy" — against the LIVE reference's outputs stored in
+tests/golden/jfk_tiny_en.npz (made by tests/golden/make_golden_jfk.py: the reference's own speech sample, decoded by
+the native FLAC path, tiny.en dims with the seeded synthetic weights because no checkpoint exists offline).
+
+CPU part: the oracle restatement on real speech (mel, encoder, greedy ids).  GPU part: the HIP path end to end through
+the public API — log-mel, model.transcribe() with word timestamps, decode() — token ids exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from whisper_amd.tokenizer import get_tokenizer
+
+J = np.load(os.path.join(os.path.dirname(__file__), "golden", "jfk_tiny_en.npz"))
+AUDIO = J["jfk_pcm16"].astype(np.float32) / 32768.0
+
+
+def test_oracle_on_jfk():
+    dims = oracle.dims_for("tiny.en")
+    filt = oracle.mel_filterbank(dims.n_mels)
+    mel = oracle.log_mel_spectrogram(AUDIO, filt)
+    assert mel.shape == (80, 1100)
+    assert np.abs(mel[:, ::25].numpy() - J["mel_slice"]).max() < 1e-4
+    assert abs(mel.mean().item() - J["mel_stats"][0]) < 1e-5 and abs(mel.max().item() - J["mel_stats"][3]) < 1e-4
+    om = oracle.OracleModel(dims, oracle.synthetic_state_dict(dims, seed=2))
+    padded = torch.nn.functional.pad(mel, (0, 3000 - mel.shape[1]))
+    with torch.no_grad():
+        feats = om.encoder(padded[None])
+    assert np.abs(feats[0, ::50, :32].numpy() - J["enc_slice"]).max() < 2e-4
+    tok = get_tokenizer(False)
+    init = list(tok.sot_sequence_including_notimestamps)
+    suppress = sorted(set(list(tok.non_speech_tokens) + [tok.transcribe, tok.translate, tok.sot, tok.sot_prev,
+                                                         tok.sot_lm, tok.no_speech]))
+    rules = oracle.SamplingRules(sample_begin=len(init), sot_index=0, eot=tok.eot, n_ctx=dims.n_text_ctx,
+                                 timestamp_begin=None, no_timestamps=tok.no_timestamps, suppress_blank=True,
+                                 blank_token=tok.encode(" ")[0], suppress_tokens=suppress, no_speech=tok.no_speech)
+    with torch.no_grad():
+        out = oracle.greedy_decode(om, feats, init, 40, rules)
+    toks = out["tokens"][0, len(init):].tolist()
+    toks = toks[: toks.index(tok.eot)] if tok.eot in toks else toks
+    assert toks == J["greedy_nots_tokens"].tolist()
+    assert abs(out["no_speech_probs"][0] - J["greedy_nots_stats"][1]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_hip_path_on_jfk(gpu_device, tmp_path):
+    import whisper_amd
+    from whisper_amd.synthetic import dims_for, save_checkpoint, synthetic_state_dict
+    dims = dims_for("tiny.en")
+    path = str(tmp_path / "tiny.en.pt")
+    save_checkpoint(path, dims, synthetic_state_dict(dims, seed=2))
+    model = whisper_amd.load_model(path, device=gpu_device)
+    mel = whisper_amd.log_mel_spectrogram(AUDIO, dims.n_mels, device=gpu_device)
+    assert np.abs(mel[:, ::25].cpu().numpy() - J["mel_slice"]).max() < 1e-4            # log-mel atol
+    r = model.transcribe(AUDIO, temperature=0.0, fp16=False, language="en", word_timestamps=True,
+                         condition_on_previous_text=True, no_speech_threshold=None, logprob_threshold=None,
+                         compression_ratio_threshold=None)
+    assert len(r["segments"]) == int(J["n_segments"][0])
+    assert [t for s in r["segments"] for t in s["tokens"]] == J["tokens"].tolist()       # greedy token ids: exact
+    bounds = np.array([[s["seek"], s["start"], s["end"]] for s in r["segments"]])
+    assert np.array_equal(bounds[:, 0], J["seg_bounds"][:, 0])
+    assert np.abs(bounds[:, 1:] - J["seg_bounds"][:, 1:]).max() <= 0.0201
+    assert np.abs(np.array([s["avg_logprob"] for s in r["segments"]]) - J["seg_logprob"]).max() < 1e-3
+    words = np.array([[w["start"], w["end"]] for s in r["segments"] for w in s["words"]]).reshape(-1, 2)
+    assert words.shape == J["word_times"].shape
+    assert np.abs(words - J["word_times"]).max() <= 0.0201                                # one 20 ms frame
+    res = whisper_amd.decode(model, whisper_amd.pad_or_trim(mel, 3000),
+                             whisper_amd.DecodingOptions(language="en", fp16=False, without_timestamps=True, sample_len=40))
+    assert res.tokens == J["greedy_nots_tokens"].tolist()
+    assert abs(res.avg_logprob - J["greedy_nots_stats"][0]) < 1e-4
+    assert abs(res.no_speech_prob - J["greedy_nots_stats"][1]) < 1e-5 + 1e-3 * J["greedy_nots_stats"][1]
+    # the fp16 engine on real speech: same first tokens
+    res16 = whisper_amd.decode(model, whisper_amd.pad_or_trim(mel, 3000),
+                               whisper_amd.DecodingOptions(language="en", fp16=True, without_timestamps=True, sample_len=40))
+    assert res16.tokens[:4] == res.tokens[:4]
