@@ -60,3 +60,21 @@ if which in ("all", "words"):
         nseg = sum(len(o["segments"]) for o in out)
         nw = sum(len(s.get("words", [])) for o in out for s in o["segments"])
         print(f"turbo 4 x 30 s transcribe(word_timestamps={wt}): {1e3 * (t1 - t0):.1f} ms total, {nseg} segments, {nw} words", flush=True)
+
+if which in ("all", "batch"):
+    model, dims = make("turbo")
+    files = [audio(b, 480000 * 2 + 16000 * b) for b in range(8)]          # 8 files of 60-67 s: 3 windows each
+    kw = dict(language="en", temperature=0.0, fp16=True, sample_len=48, condition_on_previous_text=False,
+              no_speech_threshold=None, logprob_threshold=None, compression_ratio_threshold=None)
+    whisper_amd.transcribe(model, files[0], **kw)
+    t0 = sync()
+    seq = [whisper_amd.transcribe(model, a, **kw) for a in files]
+    t1 = sync()
+    whisper_amd.transcribe_batch(model, files[:2], **kw)
+    t2 = sync()
+    bat = whisper_amd.transcribe_batch(model, files, **kw)
+    t3 = sync()
+    same = all([s["tokens"] for s in a["segments"]] == [s["tokens"] for s in b["segments"]] for a, b in zip(seq, bat))
+    secs = sum(len(a) for a in files) / 16000.0
+    print(f"turbo, 8 files ({secs:.0f} audio-s): transcribe() one by one {1e3 * (t1 - t0):.0f} ms = {secs / (t1 - t0):.0f} audio-s/s; "
+          f"transcribe_batch {1e3 * (t3 - t2):.0f} ms = {secs / (t3 - t2):.0f} audio-s/s; identical tokens: {same}", flush=True)

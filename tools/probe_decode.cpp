@@ -199,5 +199,24 @@ int main(int argc, char** argv) {
     char nm[64]; snprintf(nm, sizeof nm, "attn_decode cross S=%d", S);
     report(nm, ms * 1e3f / iters, (double)R * Ta * 2 * D * 2, d_probe, S * H * R, 5);
   }
+  for (int S = 3; S <= 6; S += 3) {   // head-major cross K/V: [row][head][key][64] for K, then the same for V
+    for (int rep = 0; rep < 2; ++rep) {
+      if (rep == 1) CK(hipEventRecord(e0, st));
+      for (int i = 0; i < iters; ++i) {
+        whk::DecAttnArgs a; memset(&a, 0, sizeof(a));
+        half_t* base = kv + kvl * (i % LR);
+        a.q = q; a.q_ld = D; a.k = base; a.k_ld = 64; a.k_bs = (int64_t)Ta * D; a.kv_hs = (int64_t)Ta * 64;
+        a.v = base + (size_t)R * Ta * D; a.v_ld = 64; a.v_bs = a.k_bs;
+        a.H = H; a.R = R; a.kv_group = 1; a.Tk = Ta; a.splits = S; a.out = att; a.o_ld = D; a.part_o = part_o; a.part_ml = part_ml;
+        a.probe = d_probe;
+        CK(whk::launch_attn_decode(a, 1, st));
+      }
+      if (rep == 1) CK(hipEventRecord(e1, st));
+      CK(hipStreamSynchronize(st));
+    }
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    char nm[64]; snprintf(nm, sizeof nm, "attn cross head-major S=%d", S);
+    report(nm, ms * 1e3f / iters, (double)R * Ta * 2 * D * 2, d_probe, S * H * R, 5);
+  }
   return 0;
 }

@@ -336,8 +336,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArg
   const int kvb = r / a.kv_group;
   const int cu = lane % LPK;          // unit within the head row
   const int ks = lane / LPK;          // key slot within the wave instruction
-  const T* kp = (const T*)a.k + (int64_t)kvb * a.k_bs + h * 64 + cu * UNIT;   // wave-uniform part folded by the compiler
-  const T* vp = (const T*)a.v + (int64_t)kvb * a.v_bs + h * 64 + cu * UNIT;
+  const int64_t hs = a.kv_hs ? a.kv_hs : 64;
+  const T* kp = (const T*)a.k + (int64_t)kvb * a.k_bs + h * hs + cu * UNIT;   // wave-uniform part folded by the compiler
+  const T* vp = (const T*)a.v + (int64_t)kvb * a.v_bs + h * hs + cu * UNIT;
 
   // q first (L2 hit, needed first): loads return in issue order
   const unit_t qraw = *(const unit_t*)((const T*)a.q + (int64_t)r * a.q_ld + h * 64 + cu * UNIT);

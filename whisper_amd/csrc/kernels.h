@@ -79,8 +79,9 @@ hipError_t launch_attn_flash_f16(const void* q, int64_t q_ld, int64_t q_bs, cons
 // single-query decode attention with split-K partials
 struct DecAttnArgs {
   const void* q; int64_t q_ld;                    // [R][H*64]
-  const void* k; int64_t k_ld; int64_t k_bs;      // [Bkv][Tk][H*64]
+  const void* k; int64_t k_ld; int64_t k_bs;      // key j of head h at k + b*k_bs + j*k_ld + h*kv_hs
   const void* v; int64_t v_ld; int64_t v_bs;
+  int64_t kv_hs;                                  // head stride in elements: 0 means 64 (heads side by side in a row)
   int H; int R; int kv_group;
   int Tk; const int* d_len; int len_plus;         // Tk fixed, or *d_len + len_plus
   int splits;                                     // key-range splits
