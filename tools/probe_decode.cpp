@@ -120,7 +120,7 @@ int main(int argc, char** argv) {
         g.part_o = part_o; g.part_ml = part_ml; g.splits = 3; g.H = H;
         g.W = W + wl * (i % LR) + c.woff; g.bias = bias; g.N = c.N; g.K = c.K; g.R = R;
         g.epi = c.epi; g.y = y; g.y_ld = c.N; g.resid = resid; g.resid_ld = D;
-        g.probe = nullptr; g.variant = variant;
+        g.probe = (argc > 4 && atoi(argv[4]) == variant) ? d_probe : nullptr; g.variant = variant;
         if (whk::launch_gemv(g, 1, st) != hipSuccess) { ok = false; (void)hipGetLastError(); break; }
       }
       if (rep == 1 && ok) CK(hipEventRecord(e1, st));
@@ -163,6 +163,7 @@ int main(int argc, char** argv) {
       snprintf(verdict, sizeof verdict, "  max|err| %.4f %s", maxerr, maxerr < 0.02 ? "ok" : "MISMATCH");
     }
     printf("%-30s %-10s %7.2f us/launch %7.0f GB/s%s\n", c.name, vnames[variant], ms * 1e3f / iters, (double)c.N * c.K * 2 / (ms * 1e3f / iters) * 1e-3, verdict);
+    if (argc > 4 && atoi(argv[4]) == variant) report("   phases", ms * 1e3f / iters, (double)c.N * c.K * 2, d_probe, 80, 7);
   }
   {  // logits
     for (int rep = 0; rep < 2; ++rep) {
