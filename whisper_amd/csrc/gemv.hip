@@ -475,13 +475,15 @@ hipError_t launch_pro(const whk::GemvArgs& a, int gp, hipStream_t stream) {
 // Fewer, fatter workgroups win whenever a prologue is shared: a CU sustains >= 50 B/clk on this stream, so
 // covering all 256 CUs is not the constraint — the redundant LayerNorm / merge prologues and the per-wave
 // instruction chain are.
-//   V x D logits ................ 4-wave streaming form, several groups per workgroup
+//   V x D logits ................ wave-private streaming kernel (gemv_stream_kernel): no barriers after the prologue
 //   D x 4D (fc2) ................ one 16-wave workgroup per 8-feature group (K split 16 ways)
 //   LN + 4D x D (fc1) ........... 16 waves = 4 groups x 4 K-splits   (160 workgroups)
 //   LN + 3D x D (qkv) ........... 8 waves = 2 groups x 4 K-splits    (240 workgroups)
 //   LN / merge + D x D .......... 8 waves, one group
 //   plain D x D (out) ........... 4 waves, one group
-constexpr int PRO_LN_ = whk::PRO_LN, PRO_PLAIN_ = whk::PRO_PLAIN;
+constexpr int PRO_LN_ = whk::PRO_LN, PRO_PLAIN_ = whk::PRO_PLAIN, EPI_F32_ = whk::EPI_F32;
+
+template <typename T, int RT> hipError_t launch_stream(const whk::GemvArgs& a, hipStream_t stream);
 
 template <typename T, int RT>
 hipError_t launch_rt(const whk::GemvArgs& a, hipStream_t stream) {
@@ -491,6 +493,7 @@ hipError_t launch_rt(const whk::GemvArgs& a, hipStream_t stream) {
   const int nblk8 = a.K / (8 * UNIT);
   const int force = a.variant;                           // developer override (probe tool); 0 = heuristic
   if (force == 0) {
+    if (ngroups8 > 1024 && a.pro == PRO_LN_ && a.epi == EPI_F32_ && a.K <= 2048) return launch_stream<T, RT>(a, stream);
     if (ngroups8 > 1024) return launch_pro<T, RT, 8, true, 4, 1>(a, (ngroups8 + 1023) / 1024, stream);
     if (nblk8 >= 64 && (nblk8 + 15) / 16 <= 5) return launch_pro<T, RT, 8, false, 16, 1>(a, 1, stream);
     if (a.pro == PRO_LN_ && ngroups8 >= 600 && (nblk8 + 3) / 4 <= 5) return launch_pro<T, RT, 8, false, 16, 4>(a, 1, stream);
@@ -531,6 +534,161 @@ hipError_t launch_rt(const whk::GemvArgs& a, hipStream_t stream) {
 #else
   return hipErrorInvalidValue;
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-private streaming form for the tied logits projection (V x D, 133 MB at large-v3): after the shared
+// LayerNorm prologue every wave owns whole 8-feature groups — it walks all of K itself, so there is no cross-wave
+// reduction, no barrier and no LDS traffic besides the broadcast x reads; waves of a workgroup drift apart freely
+// and the matrix streams at the HBM rate.  Epilogue: fp32 logits (EPI_F32) only; 8 waves per workgroup.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int RT, int J>
+__global__ __launch_bounds__(512) void gemv_stream_kernel(whk::GemvArgs a, int groups_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename ET<T>::unit_t unit_t;
+  constexpr int UNIT = ET<T>::UNIT, WAVES = 8, LPR = 8, NB = 8, BLK = LPR * UNIT, NU = 10;
+  constexpr int NR = (RT + WAVES - 1) / WAVES;
+  const int K = a.K;
+  T* xs = (T*)smem;                                              // [RT][K]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sub = lane % LPR, fr = lane / LPR;
+  const int r0 = blockIdx.y * RT;
+  int R = a.R - r0; if (R > RT) R = RT;
+  const int nblk = K / BLK;
+  const int ngroups = (a.N + NB - 1) / NB;
+  const int gfirst = (blockIdx.x * WAVES + wave) * groups_per_wave;
+  int glast = gfirst + groups_per_wave; if (glast > ngroups) glast = ngroups;
+
+  auto load_units = [&](int g, int b0, unit_t* w) {
+    int n = g * NB + fr; if (n > a.N - 1) n = a.N - 1;
+    const T* base = (const T*)a.W + (int64_t)n * K + sub * UNIT;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      int ub = b0 + u; if (ub > nblk - 1) ub = nblk - 1;
+      w[u] = __builtin_nontemporal_load((const unit_t*)(base + (size_t)ub * BLK));
+    }
+  };
+  unit_t w[NU];
+
+  // ---- LayerNorm prologue (rows wave, wave + 8, ...), weights of the first batch issued behind its loads
+  {
+    float4v v[NR][J], w4[J], b4[J];
+    const bool ln_wave = wave < RT;
+    if (ln_wave) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int r = wave + WAVES * i;
+        const float* src = a.xf + (int64_t)(r0 + (r < R ? r : 0)) * a.xf_ld;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          int k = (j * 64 + lane) * 4; if (k > K - 4) k = K - 4;
+          v[i][j] = *(const float4v*)(src + k);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        int k = (j * 64 + lane) * 4; if (k > K - 4) k = K - 4;
+        w4[j] = *(const float4v*)(a.ln_w + k);
+        b4[j] = *(const float4v*)(a.ln_b + k);
+      }
+    }
+    ISSUE_FENCE();
+    if (gfirst < glast) load_units(gfirst, 0, w);
+    ISSUE_FENCE();
+    if (ln_wave) {
+      const float invK = 1.0f / (float)K;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int r = wave + WAVES * i;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const float t = (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
+          s += ((j * 64 + lane) * 4 < K) ? t : 0.f;
+        }
+        const float mean = wave_sum(s) * invK;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const int k = (j * 64 + lane) * 4;
+          if (k < K) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][j][e] - mean; ss = __builtin_fmaf(d, d, ss); }
+          }
+        }
+        const float rstd = rsqrtf(wave_sum(ss) * invK + 1e-5f);
+        T* xr = xs + (size_t)r * K;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const int k = (j * 64 + lane) * 4;
+          if (k < K) {
+            if (r < R)
+              Pack4<T>::store(xr + k, (v[i][j][0] - mean) * rstd * w4[j][0] + b4[j][0],
+                              (v[i][j][1] - mean) * rstd * w4[j][1] + b4[j][1],
+                              (v[i][j][2] - mean) * rstd * w4[j][2] + b4[j][2],
+                              (v[i][j][3] - mean) * rstd * w4[j][3] + b4[j][3]);
+            else
+              Pack4<T>::store(xr + k, 0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- each wave: its groups, all of K, NU wave-loads per batch
+  for (int g = gfirst; g < glast; ++g) {
+    float acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+    for (int b0 = 0; b0 < nblk; b0 += NU) {
+      if (!(g == gfirst && b0 == 0)) load_units(g, b0, w);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (b0 + u < nblk) {
+          const T* xb = xs + (size_t)(b0 + u) * BLK + sub * UNIT;
+#pragma unroll
+          for (int r = 0; r < RT; ++r) acc[r] = dot_unit(w[u], *(const unit_t*)(xb + (size_t)r * K), acc[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = group8_sum(acc[r]);
+    const int n = g * NB + fr;
+    if (n < a.N && sub < R) {
+      // lane `sub` of each feature's 8-lane group stores row `sub`: 8 stores per feature spread over 8 lanes
+      float v = acc[0];
+#pragma unroll
+      for (int r = 1; r < RT; ++r) v = (sub == r) ? acc[r] : v;
+      if (a.bias) v += a.bias[n];
+      ((float*)a.y)[(int64_t)(r0 + sub) * a.y_ld + n] = v;
+    }
+  }
+  if (a.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.bump, a.bump_by);
+}
+
+template <typename T, int RT>
+hipError_t launch_stream(const whk::GemvArgs& a, hipStream_t stream) {
+  constexpr int UNIT = ET<T>::UNIT;
+  static_assert(RT <= 8, "one lane per row in the store epilogue");
+  if (a.pro != whk::PRO_LN || a.epi != whk::EPI_F32 || a.K % (8 * UNIT) != 0 || a.K > 256 * 8) return hipErrorInvalidValue;
+  const size_t lds = (size_t)RT * a.K * sizeof(T);
+  const int ngroups = (a.N + 7) / 8;
+  // ~2 waves per SIMD over the whole chip: 256 CUs x 2 workgroups x 8 waves
+  int gpw = (ngroups + 256 * 2 * 8 - 1) / (256 * 2 * 8);
+  if (gpw < 1) gpw = 1;
+  dim3 grid((ngroups + 8 * gpw - 1) / (8 * gpw), (a.R + RT - 1) / RT), block(512);
+  if (a.K <= 256 * 5) {
+    static bool set5 = false;
+    if (!set5) { (void)hipFuncSetAttribute((const void*)gemv_stream_kernel<T, RT, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set5 = true; }
+    hipLaunchKernelGGL((gemv_stream_kernel<T, RT, 5>), grid, block, lds, stream, a, gpw);
+  } else {
+    static bool set8 = false;
+    if (!set8) { (void)hipFuncSetAttribute((const void*)gemv_stream_kernel<T, RT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set8 = true; }
+    hipLaunchKernelGGL((gemv_stream_kernel<T, RT, 8>), grid, block, lds, stream, a, gpw);
+  }
+  return hipGetLastError();
 }
 
 }  // namespace
