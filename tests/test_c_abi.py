@@ -72,3 +72,16 @@ def test_no_cpu_fallback():
     model = Whisper(ModelDimensions(**dims_dict(dims)), {}, device="cpu")
     with pytest.raises(hip.HipError):
         model.encoder(torch.zeros(1, 80, 3000))
+
+
+def test_audio_library_exports_header():
+    """libwhisper_audio.so exports every function include/whisper_audio.h declares"""
+    import re
+    from whisper_amd import audio
+    text = open(os.path.join(ROOT, "include", "whisper_audio.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(wh_[a-z0-9_]+)\s*\(", text)))
+    assert syms == ["wh_flac_decode", "wh_flac_error", "wh_flac_free"]
+    lib = audio._audio_lib()
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in whisper_audio.h but not exported"
