@@ -626,6 +626,13 @@ extern "C" int wh_task_rearrange(wh_task* t, const int32_t* source_indices, void
   const size_t es = t->m->esize;
   const int64_t row_bytes = (int64_t)d.n_text_ctx * d.n_text_state * es;
   const int64_t used_bytes = (int64_t)t->pos * d.n_text_state * es;
+  bool in_group = t->G <= 8;                       // beam search never takes a source from another audio
+  for (int i = 0; i < t->R && in_group; ++i) in_group = source_indices[i] / t->G == i / t->G;
+  if (in_group) {
+    HIPCHK(launch_permute_groups(t->self_k, t->self_v, d.n_text_layer, (int64_t)t->R * row_bytes, t->B, t->G, row_bytes,
+                                 used_bytes, t->d_src, s));
+    return WH_OK;
+  }
   for (int l = 0; l < d.n_text_layer; ++l) {
     void* caches[2] = {self_k_layer(t, l), self_v_layer(t, l)};
     for (int c = 0; c < 2; ++c) {

@@ -436,6 +436,125 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArg
 }
 
 // =============================================================================================
+// decode cross attention for beam groups: the G rows of one audio (beams) attend to the SAME K/V, so one
+// workgroup per (split, head, audio) loads the tile once and scores all G queries against it — the per-row
+// kernel re-read each audio's K/V once per beam (5x the bytes at beam 5).
+// =============================================================================================
+template <typename T, int NL, int WAVES, int GQ>
+__global__ __launch_bounds__(WAVES * 64) void attn_decode_group_kernel(whk::DecAttnArgs a) {
+  typedef typename ET<T>::unit_t unit_t;
+  constexpr int UNIT = ET<T>::UNIT;
+  constexpr int LPK = 64 / UNIT, KPW = 64 / LPK, KPR = WAVES * KPW;
+  __shared__ float red[WAVES][GQ][64];
+  __shared__ float redm[WAVES][GQ], reds[WAVES][GQ];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int S = a.splits, G = a.kv_group, Tk = a.Tk;
+  int chunk = (Tk + S - 1) / S;
+  chunk = (chunk + KPR - 1) / KPR * KPR;
+  const int k0 = s * chunk;
+  int k1 = k0 + chunk; if (k1 > Tk) k1 = Tk;
+  const int nkeys = k1 > k0 ? k1 - k0 : 0;
+  const int cu = lane % LPK, ks = lane / LPK;
+  const int64_t hs = a.kv_hs ? a.kv_hs : 64;
+  const T* kp = (const T*)a.k + (int64_t)b * a.k_bs + h * hs + cu * UNIT;
+  const T* vp = (const T*)a.v + (int64_t)b * a.v_bs + h * hs + cu * UNIT;
+
+  unit_t qraw[GQ];
+#pragma unroll
+  for (int g = 0; g < GQ; ++g) {
+    const int r = b * G + (g < G ? g : G - 1);
+    qraw[g] = *(const unit_t*)((const T*)a.q + (int64_t)r * a.q_ld + h * 64 + cu * UNIT);
+  }
+  asm volatile("" ::: "memory");
+  const int kk0 = wave * KPW + ks;
+  const int klast = nkeys > 0 ? nkeys - 1 : 0;
+  const uint32_t ldk = (uint32_t)a.k_ld, ldv = (uint32_t)a.v_ld;
+  const uint32_t ok0 = (uint32_t)(k0 + kk0) * ldk, okl = (uint32_t)(k0 + klast) * ldk;
+  const uint32_t ov0 = (uint32_t)(k0 + kk0) * ldv, ovl = (uint32_t)(k0 + klast) * ldv;
+  unit_t ku[NL], vu[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    uint32_t o = ok0 + (uint32_t)(i * KPR) * ldk; if (o > okl) o = okl;
+    ku[i] = __builtin_nontemporal_load((const unit_t*)(kp + o));
+  }
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    uint32_t o = ov0 + (uint32_t)(i * KPR) * ldv; if (o > ovl) o = ovl;
+    vu[i] = __builtin_nontemporal_load((const unit_t*)(vp + o));
+  }
+
+  float sc[GQ][NL], mx[GQ];
+#pragma unroll
+  for (int g = 0; g < GQ; ++g) {
+    mx[g] = WH_NEG_INF;
+    if (g >= G) continue;                  // wave-uniform: beam slots beyond the group size cost nothing
+    const unit_t qs = scale_q(qraw[g]);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float d = qk_unit(qs, ku[i]);
+      d = LPK == 8 ? group8_sum(d) : group16_sum(d);
+      sc[g][i] = (kk0 + i * KPR < nkeys) ? d : WH_NEG_INF;
+      mx[g] = fmaxf(mx[g], sc[g][i]);
+    }
+    mx[g] = LPK == 8 ? across_groups8_max(mx[g]) : across_groups16_max(mx[g]);
+    if (lane == 0) redm[wave][g] = mx[g];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < GQ; ++g) {
+    float m = redm[0][g];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) m = fmaxf(m, redm[w][g]);
+    mx[g] = m;
+  }
+
+#pragma unroll
+  for (int g = 0; g < GQ; ++g) {
+    if (g >= G) continue;
+    float acc[UNIT];
+#pragma unroll
+    for (int e = 0; e < UNIT; ++e) acc[e] = 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const float p = (sc[g][i] == WH_NEG_INF) ? 0.f : __expf(sc[g][i] - mx[g]);
+      sum += p;
+#pragma unroll
+      for (int e = 0; e < UNIT; ++e) acc[e] = __builtin_fmaf(p, to_f32(vu[i][e]), acc[e]);
+    }
+    sum = LPK == 8 ? across_groups8_sum(sum) : across_groups16_sum(sum);
+#pragma unroll
+    for (int e = 0; e < UNIT; ++e) acc[e] = LPK == 8 ? across_groups8_sum(acc[e]) : across_groups16_sum(acc[e]);
+    if (ks == 0) {
+#pragma unroll
+      for (int e = 0; e < UNIT; ++e) red[wave][g][cu * UNIT + e] = acc[e];
+    }
+    if (lane == 0) reds[wave][g] = sum;
+  }
+  __syncthreads();
+  for (int t = tid; t < G * 64; t += WAVES * 64) {
+    const int g = t >> 6, d = t & 63;
+    float o = red[0][g][d], l = reds[0][g];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) { o += red[w][g][d]; l += reds[w][g]; }
+    const int r = b * G + g;
+    if (S == 1) {
+      ((T*)a.out)[(int64_t)r * a.o_ld + h * 64 + d] = from_f32<T>(o / l);
+    } else {
+      const int64_t pi = ((int64_t)r * a.H + h) * S + s;
+      a.part_o[pi * 64 + d] = nkeys > 0 ? o : 0.f;
+      if (d == 0) {
+        a.part_ml[pi * 2 + 0] = nkeys > 0 ? mx[g] : WH_NEG_INF;
+        a.part_ml[pi * 2 + 1] = nkeys > 0 ? l : 0.f;
+      }
+    }
+  }
+}
+
+// =============================================================================================
 // cross QK capture
 // =============================================================================================
 template <typename T>
@@ -487,8 +606,14 @@ static hipError_t launch_attn_decode_t(const DecAttnArgs& a, hipStream_t stream)
     hipLaunchKernelGGL((attn_decode_kernel<T, 8, 8, true>), grid, block, 0, stream, a);
     return hipGetLastError();
   }
-  dim3 grid(a.splits, a.H, a.R), block(4 * 64);
   const int chunk = (a.Tk + a.splits - 1) / a.splits;
+  if (a.kv_group > 1 && a.kv_group <= 8 && a.R % a.kv_group == 0 && chunk <= 8 * 8 * KPW) {
+    // beam groups: one workgroup per (split, head, audio) scores all beams against one K/V tile
+    dim3 ggrid(a.splits, a.H, a.R / a.kv_group), gblock(8 * 64);
+    hipLaunchKernelGGL((attn_decode_group_kernel<T, 8, 8, 8>), ggrid, gblock, 0, stream, a);
+    return hipGetLastError();
+  }
+  dim3 grid(a.splits, a.H, a.R), block(4 * 64);
   const int rounds = (chunk + 4 * KPW - 1) / (4 * KPW);
   if (rounds > 16) return hipErrorInvalidValue;
   if (rounds <= 8) hipLaunchKernelGGL((attn_decode_kernel<T, 8, 4, false>), grid, block, 0, stream, a);

@@ -152,6 +152,36 @@ __global__ void gather_cache_kernel(const uint4v* __restrict__ src, uint4v* __re
     d[u] = s[u];
 }
 
+// Beam reorder in place, ONE launch for every layer and both caches: new row i of an audio's beam group takes the
+// cache of old row src_idx[i] of the SAME group (BeamSearchDecoder never mixes audios, decoding.py:323-382).
+// A thread owns one 16-byte column of all G rows of its (cache, audio): it reads the G units, then writes them back
+// permuted — no staging buffer and no copy-back, because nobody else touches that column.
+template <int GMAX>
+__global__ __launch_bounds__(256) void permute_group_kernel(uint4v* __restrict__ k_base, uint4v* __restrict__ v_base,
+                                                            int64_t layer_units, int64_t row_units, int64_t used_units,
+                                                            const int* __restrict__ src_idx, int G) {
+  const int audio = blockIdx.y, lz = blockIdx.z;
+  uint4v* base = ((lz & 1) ? v_base : k_base) + (int64_t)(lz >> 1) * layer_units + (int64_t)audio * G * row_units;
+  int src[GMAX];
+#pragma unroll
+  for (int g = 0; g < GMAX; ++g) src[g] = g < G ? src_idx[audio * G + g] - audio * G : 0;
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < used_units; u += (int64_t)gridDim.x * 256) {
+    uint4v val[GMAX];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g)
+      if (g < G) val[g] = base[(int64_t)g * row_units + u];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+      if (g < G) {
+        uint4v v = val[0];
+#pragma unroll
+        for (int j = 1; j < GMAX; ++j) v = (src[g] == j) ? val[j] : v;
+        if (src[g] != g) base[(int64_t)g * row_units + u] = v;
+      }
+    }
+  }
+}
+
 __global__ void add_int_kernel(int* p, int v) { *p += v; }
 
 }  // namespace
@@ -219,6 +249,18 @@ hipError_t launch_gather_cache(const void* src, void* dst, const int* src_idx, i
   if (bx > 256) bx = 256;
   hipLaunchKernelGGL(gather_cache_kernel, dim3(bx, R), dim3(256), 0, stream, (const uint4v*)src, (uint4v*)dst,
                      src_idx, row_units, used_units);
+  return hipGetLastError();
+}
+
+hipError_t launch_permute_groups(void* k_base, void* v_base, int n_layers, int64_t layer_bytes, int n_audio, int G,
+                                 int64_t row_bytes, int64_t used_bytes, const int* src_idx, hipStream_t stream) {
+  if (used_bytes <= 0) return hipSuccess;
+  if (G > 8) return hipErrorInvalidValue;
+  const int64_t used_units = used_bytes / 16;
+  int bx = (int)((used_units + 255) / 256);
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(permute_group_kernel<8>, dim3(bx, n_audio, n_layers * 2), dim3(256), 0, stream, (uint4v*)k_base,
+                     (uint4v*)v_base, layer_bytes / 16, row_bytes / 16, used_units, src_idx, G);
   return hipGetLastError();
 }
 

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
   static_assert(!MF || (sizeof(T) == 2 && LPR == 4 && RT >= 8), "MFMA form: fp16, 16 rows x 32 k per wave-load");
   constexpr int NR = (RT + WAVES - 1) / WAVES;   // LayerNorm rows per wave
   constexpr int TPR = NT / RT;           // PRO_PLAIN: threads staging one row
-  constexpr int CT = NT == 256 ? 10 : (NT == 512 ? 5 : 3);   // PRO_COMBINE fast path: tasks per thread
+  constexpr int CT = (RT * 20 * 16 + NT - 1) / NT;             // PRO_COMBINE fast path: tasks per thread (<= 20 heads)
   static_assert(!MULTI || (WAVES == 4 && GS == 1), "MULTI is the 4-wave streaming form");
   const int K = a.K;
   const int xld = MF ? K + 16 : K;       // MF: +32 B per row spreads the 8 x-rows of a B-fragment read over all banks
@@ -537,6 +537,25 @@ hipError_t launch_rt(const whk::GemvArgs& a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// More than 8 rows (beam search: rows = audios x beams, e.g. 8 x 5 = 40): the step is a skinny GEMM, not a matvec.
+// Row tiles of 16 on grid.y and the MFMA form of the kernel (one v_mfma_f32_16x16x32_f16 per wave-load, all 16
+// columns live): 3 passes over the weights for 40 rows instead of 5 passes of 64 v_dot2 per 16 bytes.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+hipError_t launch_rows16_mf(const whk::GemvArgs& a, hipStream_t stream) {
+  if constexpr (sizeof(T) == 2) {
+    const int ngroups16 = (a.N + 15) / 16;
+    if (ngroups16 > 1024) return launch_pro<T, 16, 4, true, 4, 1, true>(a, (ngroups16 + 1023) / 1024, stream);
+    if (a.pro == whk::PRO_LN && ngroups16 >= 300) return launch_pro<T, 16, 4, false, 16, 4, true>(a, 1, stream);
+    if (a.pro == whk::PRO_LN && ngroups16 >= 200) return launch_pro<T, 16, 4, false, 8, 2, true>(a, 1, stream);
+    if (a.pro != whk::PRO_PLAIN) return launch_pro<T, 16, 4, false, 8, 1, true>(a, 1, stream);
+    return launch_pro<T, 16, 4, false, 4, 1, true>(a, 1, stream);
+  } else {
+    return hipErrorInvalidValue;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Wave-private streaming form for the tied logits projection (V x D, 133 MB at large-v3): after the shared
 // LayerNorm prologue every wave owns whole 8-feature groups — it walks all of K itself, so there is no cross-wave
 // reduction, no barrier and no LDS traffic besides the broadcast x reads; waves of a workgroup drift apart freely
@@ -699,7 +718,10 @@ hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream) {
   if (a.R <= 0) return hipErrorInvalidValue;
   if (dtype == 1) {
     if (a.R <= 4) return launch_rt<half_t, 4>(a, stream);
-    return launch_rt<half_t, 8>(a, stream);           // R > 8: row tiles of 8 on grid.y
+    // beam-search row counts: row tiles of 16 through the matrix cores while x (16 rows) fits in LDS
+    if (a.R > 8 && a.variant == 0 && a.K % 32 == 0 && a.K <= 2048 && a.K / 32 <= 40)
+      return launch_rows16_mf<half_t>(a, stream);
+    return launch_rt<half_t, 8>(a, stream);           // R <= 8, or long K: row tiles of 8 on grid.y
   }
   // fp32 (strict-parity mode): x rows are twice as wide in LDS
   if (a.R <= 4 || (size_t)a.K * 8 * sizeof(float) > 128 * 1024) return launch_rt<float, 4>(a, stream);

@@ -56,6 +56,10 @@ hipError_t launch_gather_rows(const float* x, const int* sel, int n_sel, int D, 
 // dst rows <- src rows[src_idx[i]] : self-attention cache gather for beam search (rows of row_elems elements)
 hipError_t launch_gather_cache(const void* src, void* dst, const int* src_idx, int R, int64_t row_bytes,
                                int64_t used_bytes, hipStream_t stream);
+// in-place beam reorder of every layer's self-attention K and V cache in one launch; src_idx[i] must lie in the
+// beam group of row i (groups of G consecutive rows), G <= 8
+hipError_t launch_permute_groups(void* k_base, void* v_base, int n_layers, int64_t layer_bytes, int n_audio, int G,
+                                 int64_t row_bytes, int64_t used_bytes, const int* src_idx, hipStream_t stream);
 hipError_t launch_add_int(int* p, int v, hipStream_t stream);
 
 // ---- attention.hip -------------------------------------------------------------------------
