@@ -34,7 +34,7 @@ def _feats(dims, B, seed):
 
 
 @pytest.mark.parametrize("dt,tol", [(hip.WH_F32, 1e-3), (hip.WH_F16, 6e-2)])
-@pytest.mark.parametrize("B,G,T0", [(8, 1, 3), (2, 5, 4), (1, 1, 9)])
+@pytest.mark.parametrize("B,G,T0", [(8, 1, 3), (2, 5, 4), (1, 1, 9), (5, 1, 2), (8, 5, 3)])
 def test_wide_prefill_and_steps(wide, gpu_device, dt, tol, B, G, T0):
     """teacher-forced logits at every position: prefill (GEMM path) + 5 steps (GEMV path, hipGraph from the 2nd)
     vs the oracle's KV-cache decoder.  fp32: |dlogit| < 1e-3 (north_star bar); fp16 engine: 6e-2."""
