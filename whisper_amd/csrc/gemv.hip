@@ -75,7 +75,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
   constexpr int CT = (RT * 20 * 16 + NT - 1) / NT;             // PRO_COMBINE fast path: tasks per thread (<= 20 heads)
   static_assert(!MULTI || (WAVES == 4 && GS == 1), "MULTI is the 4-wave streaming form");
   const int K = a.K;
-  const int xld = MF ? K + 16 : K;       // MF: +32 B per row spreads the 8 x-rows of a B-fragment read over all banks
+  const int xld = K;
+  // MF: the B-fragment read touches 16 x-rows at the same column, and a row is a multiple of 256 B, so rows would
+  // collide on the LDS banks; 16-byte unit u of row r is therefore stored at unit u ^ (r & 15) (K is a multiple of
+  // 16 units for every Whisper width), which makes the read conflict-free without padding the rows — padding would
+  // push 16 rows x K = 5120 past the 160 KB of LDS.
+  auto xcol = [&](int r, int k) -> int { return MF ? ((((k >> 3) ^ (r & 15)) << 3) | (k & 7)) : k; };
   T* xs = (T*)smem;                                              // [RT][xld]
   // cross-wave partial sums [WAVES][NB][RT]; aliases xs when the workgroup makes a single pass
   float* red = red_alias ? (float*)smem : (float*)(smem + (size_t)RT * xld * sizeof(T));
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
 #pragma unroll
           for (int e = 0; e < UNIT; ++e) v[e] = 0;
         }
-        *(unit_t*)(xs + (size_t)r * xld + u * UNIT) = v;
+        *(unit_t*)(xs + (size_t)r * xld + xcol(r, u * UNIT)) = v;
       }
     }
   } else if (PRO == whk::PRO_LN) {
@@ -201,12 +206,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
           const int k = (j * 64 + lane) * 4;
           if (k < K) {
             if (r < R)
-              Pack4<T>::store(xr + k, (v[i][j][0] - mean) * rstd * w4[j][0] + b4[j][0],
+              Pack4<T>::store(xr + xcol(r, k), (v[i][j][0] - mean) * rstd * w4[j][0] + b4[j][0],
                               (v[i][j][1] - mean) * rstd * w4[j][1] + b4[j][1],
                               (v[i][j][2] - mean) * rstd * w4[j][2] + b4[j][2],
                               (v[i][j][3] - mean) * rstd * w4[j][3] + b4[j][3]);
             else
-              Pack4<T>::store(xr + k, 0.f, 0.f, 0.f, 0.f);
+              Pack4<T>::store(xr + xcol(r, k), 0.f, 0.f, 0.f, 0.f);
           }
         }
       }
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
             num[0] = __builtin_fmaf(w, o[j][s][0], num[0]); num[1] = __builtin_fmaf(w, o[j][s][1], num[1]);
             num[2] = __builtin_fmaf(w, o[j][s][2], num[2]); num[3] = __builtin_fmaf(w, o[j][s][3], num[3]);
           }
-          Pack4<T>::store(xs + (size_t)r * xld + h * 64 + d4 * 4, num[0], num[1], num[2], num[3]);
+          Pack4<T>::store(xs + (size_t)r * xld + xcol(r, h * 64 + d4 * 4), num[0], num[1], num[2], num[3]);
         }
       }
     } else {
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
           }
         }
         const float inv = 1.0f / den;
-        Pack4<T>::store(xs + (size_t)r * xld + h * 64 + d4 * 4, num[0] * inv, num[1] * inv, num[2] * inv, num[3] * inv);
+        Pack4<T>::store(xs + (size_t)r * xld + xcol(r, h * 64 + d4 * 4), num[0] * inv, num[1] * inv, num[2] * inv, num[3] * inv);
       }
       load_item(0, wa);
     }
@@ -309,12 +314,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
   auto compute_item = [&](int it, const unit_t* w) {
     const int b = MULTI ? it - (it / nbatch) * nbatch : 0;
     if constexpr (MF) {
-      const T* xrow = xs + (size_t)(fr % RT) * xld + sub * UNIT;      // B fragment: column = x row (duplicated)
+      const int xr_ = fr % RT;                                         // B fragment: column = x row (duplicated)
+      const T* xrow = xs + (size_t)xr_ * xld;
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         const int ub = kw + KS * (b * NU + u);
         if (ub < nblk) {
-          const unit_t xf = *(const unit_t*)(xrow + (size_t)ub * BLK);
+          const unit_t xf = *(const unit_t*)(xrow + xcol(xr_, ub * BLK + sub * UNIT));
           macc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u], xf, macc, 0, 0, 0);
         }
       }
@@ -424,7 +430,8 @@ hipError_t launch_cfg(const whk::GemvArgs& a, int gp, hipStream_t stream) {
   constexpr int NB = 64 / LPR;
   const int ngroups = (a.N + NB - 1) / NB;
   const int red_alias = (!MULTI || gp == 1) && PRO != whk::PRO_COMBINE ? 1 : 0;
-  size_t lds = (size_t)RT * (a.K + (MF ? 16 : 0)) * sizeof(T);
+  size_t lds = (size_t)RT * a.K * sizeof(T);
+  if (MF && a.K % 128 != 0) return hipErrorInvalidValue;          // the unit swizzle stays inside a row
   const size_t red_bytes = (size_t)WAVES * NB * RT * sizeof(float);
   if (!red_alias) lds += red_bytes;
   else if (lds < red_bytes) lds = red_bytes;
@@ -454,8 +461,8 @@ hipError_t launch_pro(const whk::GemvArgs& a, int gp, hipStream_t stream) {
       if (upr <= TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 1, MULTI, WAVES, GS, MF>(a, gp, stream);
       if (upr <= 3 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 3, MULTI, WAVES, GS, MF>(a, gp, stream);
       if (upr <= 6 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 6, MULTI, WAVES, GS, MF>(a, gp, stream);
+      if (upr <= 12 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 12, MULTI, WAVES, GS, MF>(a, gp, stream);
       if (WAVES == 4) {                              // narrow workgroups stage long rows with more units per thread
-        if (upr <= 12 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 12, MULTI, WAVES, GS, MF>(a, gp, stream);
         if (upr <= 24 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 24, MULTI, WAVES, GS, MF>(a, gp, stream);
       }
       return hipErrorInvalidValue;
@@ -545,6 +552,11 @@ template <typename T>
 hipError_t launch_rows16_mf(const whk::GemvArgs& a, hipStream_t stream) {
   if constexpr (sizeof(T) == 2) {
     const int ngroups16 = (a.N + 15) / 16;
+    const int nks = a.K / 32;
+    if (nks > 40) {                                    // D x 4D: K split 16 ways, x fills the LDS exactly at K = 5120
+      if ((nks + 15) / 16 <= 10) return launch_pro<T, 16, 4, false, 16, 1, true>(a, 1, stream);
+      return hipErrorInvalidValue;
+    }
     if (ngroups16 > 1024) return launch_pro<T, 16, 4, true, 4, 1, true>(a, (ngroups16 + 1023) / 1024, stream);
     if (a.pro == whk::PRO_LN && ngroups16 >= 300) return launch_pro<T, 16, 4, false, 16, 4, true>(a, 1, stream);
     if (a.pro == whk::PRO_LN && ngroups16 >= 200) return launch_pro<T, 16, 4, false, 8, 2, true>(a, 1, stream);
@@ -719,7 +731,7 @@ hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream) {
   if (dtype == 1) {
     if (a.R <= 4) return launch_rt<half_t, 4>(a, stream);
     // beam-search row counts: row tiles of 16 through the matrix cores while x (16 rows) fits in LDS
-    if (a.R > 8 && a.variant == 0 && a.K % 32 == 0 && a.K <= 2048 && a.K / 32 <= 40)
+    if (a.R > 8 && a.variant == 0 && a.K % 128 == 0 && a.K <= 5120 && (a.K / 32 <= 40 || a.pro == whk::PRO_PLAIN))
       return launch_rows16_mf<half_t>(a, stream);
     return launch_rt<half_t, 8>(a, stream);           // R <= 8, or long K: row tiles of 8 on grid.y
   }
