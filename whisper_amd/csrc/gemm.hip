@@ -23,9 +23,10 @@
 namespace {
 
 // Two tile shapes share the code: 128x128 (4 waves, 2x2 of 64x64) for small / skinny problems and 256x256
-// (8 waves, 2x4 of 128x64) for the encoder-sized ones.  At 128x128 the L2->LDS stream needs 64 B/clk/CU at MFMA
-// peak (64 FLOP/B = exactly the machine's ridge), which is what capped round 1's first GEMM at ~25 % of peak;
-// 256x256 doubles the FLOP per staged byte.  Either way a wave stages 4 + 4 rows-of-8 per K step.
+// (16 waves, 4x4 of 64x64) for the encoder-sized ones.  Measured with tools/probe_gemm (M = 12000): the 256x256
+// tile needs half the L2->LDS bytes per FLOP, but what moved the needle was WAVES — the same tile with 8 waves of
+// 128x64 gave 650 TFLOP/s on the QKV shape, with 16 waves of 64x64 it gives 760 (fc2, K = 5120: 1040); deeper LDS
+// rings (3-4 tiles in flight) at lower occupancy were slower.  One barrier per K step.
 
 __device__ __forceinline__ void mma16(half8v a, half8v b, float4v& c) {
   c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -55,7 +56,10 @@ template <> struct Out4<half_t> {
 };
 
 // WGM x WGN waves, each computing FM x FN MFMA 16x16 tiles
-template <typename T, typename OutT, int WGM, int WGN, int FM, int FN>
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NS: LDS ring depth (tiles in flight = NS - 1)
+template <typename T, typename OutT, int WGM, int WGN, int FM, int FN, int NS>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(whk::GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename ET<T>::unit_t unit_t;
@@ -118,19 +122,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(whk::GemmArgs p
     for (int i = 0; i < IW; ++i) glds16(gw[i] + ko, sW + i * 1024);
   };
 
-  stage(0, 0);
+  // Ring of NS tile buffers, ONE barrier per K step: wait for my loads of tile kt (tiles kt+1 .. kt+NS-2 stay in
+  // flight), barrier (=> every wave sees tile kt AND has finished reading tile kt-1), refill tile kt-1's buffer
+  // with tile kt+NS-1, then the MFMAs of tile kt run while those loads travel.
+  constexpr int LPS = IA + IW;
+  static_assert(NS >= 2 && NS <= 4 && LPS * (NS - 2) <= 63, "vmcnt immediates");
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (i < nk) stage(i, i);
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      stage(cur ^ 1, kt + 1);
-      static_assert(IA + IW == 8, "the counted wait below assumes 8 wave-loads per stage");
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile kt landed; tile kt+1 stays in flight
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    const int ahead = nk - 1 - kt;                 // tiles issued after tile kt that may still be in flight
+    if (NS >= 4 && ahead >= 2) wait_vmcnt<LPS * 2>();
+    else if (NS >= 3 && ahead >= 1) wait_vmcnt<(NS >= 3 ? LPS : 0)>();
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    if (kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
 
-    const char* sA = smem + cur * STAGE_BYTES;
+    const char* sA = smem + (kt % NS) * STAGE_BYTES;
     const char* sW = sA + A_BYTES;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -145,8 +153,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(whk::GemmArgs p
 #pragma unroll
         for (int tm = 0; tm < FM; ++tm) mma16(wf[tn], af[tm], acc[tn][tm]);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // everyone finished reading buf[cur] before it is refilled
   }
 
   // ---- epilogue: lane holds C[m][n..n+3] for m = m0+wm*FM*16+tm*16+(lane&15), n = n0+wn*FN*16+tn*16+(lane>>4)*4
@@ -195,22 +201,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(whk::GemmArgs p
   }
 }
 
-template <typename T, typename OutT, int WGM, int WGN, int FM, int FN>
+template <typename T, typename OutT, int WGM, int WGN, int FM, int FN, int NS>
 hipError_t launch_shape(const whk::GemmArgs& a, int batch, hipStream_t stream) {
   constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
-  constexpr int LDS = 2 * (BM + BN) * 128;
+  constexpr int LDS = NS * (BM + BN) * 128;
+  static_assert(LDS <= 160 * 1024, "LDS ring does not fit");
   whk::GemmArgs p = a;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, WGM, WGN, FM, FN>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, WGM, WGN, FM, FN, NS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, WGM, WGN, FM, FN>), grid, dim3(WGM * WGN * 64), LDS, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, WGM, WGN, FM, FN, NS>), grid, dim3(WGM * WGN * 64), LDS, stream, p);
   return hipGetLastError();
 }
 
@@ -221,8 +228,16 @@ hipError_t launch_t(const whk::GemmArgs& a, int batch, hipStream_t stream) {
   // 648 vs 548 TFLOP/s; N=1280 K=5120: 949 vs 809).  The K loop itself runs at ~1.2 PFLOP/s; at K = 1280 half of a
   // launch is fixed cost (first-tile latency, fp32 residual read-modify-write epilogue, exact-erf GELU +13 %).
   const bool big = force ? force == 256 : (a.M >= 1024 && a.N >= 1024);
-  if (big) return launch_shape<T, OutT, 2, 4, 8, 4>(a, batch, stream);
-  return launch_shape<T, OutT, 2, 2, 4, 4>(a, batch, stream);
+  if (force == 2563) return launch_shape<T, OutT, 4, 2, 4, 4, 3>(a, batch, stream);   // 256x128, 3-deep ring (experiment)
+  if (force == 1284) return launch_shape<T, OutT, 2, 2, 4, 4, 4>(a, batch, stream);   // 128x128, 4-deep ring (experiment)
+  if (force == 1283) return launch_shape<T, OutT, 2, 2, 4, 4, 3>(a, batch, stream);
+  if (force == 25616) return launch_shape<T, OutT, 4, 4, 4, 4, 2>(a, batch, stream);  // 256x256, 16 waves of 64x64
+  if (force == 25612) return launch_shape<T, OutT, 2, 4, 8, 2, 2>(a, batch, stream);  // 256x128, 8 waves of 128x32
+  if (force == 1288) return launch_shape<T, OutT, 4, 2, 2, 4, 2>(a, batch, stream);   // 128x128, 8 waves of 32x64
+  if (force == 12816) return launch_shape<T, OutT, 4, 4, 2, 2, 2>(a, batch, stream);  // 128x128, 16 waves of 32x32
+  if (force == 2568) return launch_shape<T, OutT, 2, 4, 8, 4, 2>(a, batch, stream);   // 256x256, 8 waves of 128x64
+  if (big) return launch_shape<T, OutT, 4, 4, 4, 4, 2>(a, batch, stream);
+  return launch_shape<T, OutT, 2, 2, 4, 4, 2>(a, batch, stream);
 }
 
 }  // namespace
