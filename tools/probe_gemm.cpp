@@ -6,6 +6,7 @@
 #include <string.h>
 #include <vector>
 #include "../whisper_amd/csrc/gemm.hip"
+#include "../whisper_amd/csrc/attention.hip"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 int main() {
@@ -45,6 +46,21 @@ int main() {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / 10, tf = 2.0 * M * c.N * c.K / us * 1e-6;
     printf("%s %8.1f us  %7.1f TFLOP/s  (%.1f %% of 2500)\n", c.name, us, tf, tf / 25.0);
+  }
+  {  // encoder flash attention: B = 8, H = 20, T = 1500 (q,k row-major [T][2D], V^T [D][1536])
+    const int B = 8, H = 20, T = 1500;
+    half_t* qk = A; half_t* vt = W; half_t* o = C16;
+    for (int rep = 0; rep < 2; ++rep) {
+      if (rep == 1) CK(hipEventRecord(e0, st));
+      for (int i = 0; i < 10; ++i)
+        CK(whk::launch_attn_flash_f16(qk, 2 * D, (int64_t)T * 2 * D, qk + D, 2 * D, (int64_t)T * 2 * D, vt, 1536, (int64_t)D * 1536,
+                                      o, D, (int64_t)T * D, B, H, T, st));
+      if (rep == 1) CK(hipEventRecord(e1, st));
+      CK(hipStreamSynchronize(st));
+    }
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / 10, tf = 4.0 * T * T * 64 * H * B / us * 1e-6;
+    printf("flash attention B=8 H=20 T=1500 %8.1f us  %7.1f TFLOP/s  (%.1f %% of 2500)\n", us, tf, tf / 25.0);
   }
   return 0;
 }

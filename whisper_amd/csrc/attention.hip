@@ -130,7 +130,10 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(whk::AttnArgs a) {
 // =============================================================================================
 constexpr int FQ = 128;   // queries per workgroup (4 waves x 32)
 
-__global__ __launch_bounds__(256, 2) void attn_flash_f16_kernel(
+#ifndef WH_FLASH_WAVES_PER_SIMD
+#define WH_FLASH_WAVES_PER_SIMD 2
+#endif
+__global__ __launch_bounds__(256, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f16_kernel(
     const half_t* __restrict__ q, int64_t q_ld, int64_t q_bs, const half_t* __restrict__ k, int64_t k_ld,
     int64_t k_bs, const half_t* __restrict__ vt, int64_t vt_ld, int64_t vt_bs, half_t* __restrict__ out,
     int64_t o_ld, int64_t o_bs, int T) {
@@ -222,9 +225,9 @@ __global__ __launch_bounds__(256, 2) void attn_flash_f16_kernel(
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    { float pa, pb; lane_swap32(mx, pa, pb); mx = fmaxf(pa, pb); }   // partner half (lane ^ 32) without LDS
     const float m_new = fmaxf(m_run, mx);          // finite: key 0 of every tile is valid
-    const float alpha = exp2f((m_run - m_new) * SCALE_LOG2E);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * SCALE_LOG2E);
     const float mc = m_new * SCALE_LOG2E;
     float psum = 0.f;
     half8v pf[2][2];
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_f16_kernel(
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(__builtin_fmaf(sacc[kb][r], SCALE_LOG2E, -mc));
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][r], SCALE_LOG2E, -mc));   // v_exp_f32
         psum += p;
         pf[kb][r >> 3][r & 7] = (half_t)p;
       }
@@ -261,7 +264,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_f16_kernel(
     __syncthreads();
   }
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_a, l_b; lane_swap32(l_run, l_a, l_b);
+  const float l_tot = l_a + l_b;
   const float inv = 1.0f / l_tot;
   if (qrow < T) {
     half_t* op = out + (int64_t)b * o_bs + (int64_t)qrow * o_ld + h * 64;
