@@ -128,12 +128,16 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(whk::AttnArgs a) {
 // =============================================================================================
 // encoder flash attention, fp16 MFMA
 // =============================================================================================
-constexpr int FQ = 128;   // queries per workgroup (4 waves x 32)
+#ifndef WH_FLASH_WAVES
+#define WH_FLASH_WAVES 4
+#endif
+constexpr int FW = WH_FLASH_WAVES;   // waves per workgroup
+constexpr int FQ = FW * 32;          // queries per workgroup (32 per wave)
 
 #ifndef WH_FLASH_WAVES_PER_SIMD
 #define WH_FLASH_WAVES_PER_SIMD 2
 #endif
-__global__ __launch_bounds__(256, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f16_kernel(
+__global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f16_kernel(
     const half_t* __restrict__ q, int64_t q_ld, int64_t q_bs, const half_t* __restrict__ k, int64_t k_ld,
     int64_t k_bs, const half_t* __restrict__ vt, int64_t vt_ld, int64_t vt_bs, half_t* __restrict__ out,
     int64_t o_ld, int64_t o_bs, int T) {
@@ -162,12 +166,13 @@ __global__ __launch_bounds__(256, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f16_k
   float m_run = WH_NEG_INF, l_run = 0.f;
 
   const int nkt = (T + 63) / 64;
-  // staging: thread handles units u = tid and tid+256 of each 512-unit tile
-  uint4v kreg[2], vreg[2];
+  // staging: thread handles units u = tid, tid + threads, ... of each 512-unit tile
+  constexpr int SJ = 512 / (FW * 64);
+  uint4v kreg[SJ], vreg[SJ];
   auto gload = [&](int kt) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int u = tid + 256 * j;
+    for (int j = 0; j < SJ; ++j) {
+      const int u = tid + FW * 64 * j;
       const int row = u >> 3, cu = u & 7;
       int key = kt * 64 + row; if (key > T - 1) key = T - 1;
       kreg[j] = *(const uint4v*)(kp + (int64_t)key * k_ld + cu * 8);
@@ -178,8 +183,8 @@ __global__ __launch_bounds__(256, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f16_k
     char* sK = smem + buf * 16384;
     char* sV = sK + 8192;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int u = tid + 256 * j;
+    for (int j = 0; j < SJ; ++j) {
+      const int u = tid + FW * 64 * j;
       const int row = u >> 3, cu = u & 7;
       *(uint4v*)(sK + swz_byte(row, cu)) = kreg[j];
       *(uint4v*)(sV + swz_byte(row, cu)) = vreg[j];
@@ -591,7 +596,7 @@ hipError_t launch_attn_generic(const AttnArgs& a, int batch, int dtype, hipStrea
 hipError_t launch_attn_flash_f16(const void* q, int64_t q_ld, int64_t q_bs, const void* k, int64_t k_ld,
                                  int64_t k_bs, const void* vt, int64_t vt_ld, int64_t vt_bs, void* out,
                                  int64_t o_ld, int64_t o_bs, int B, int H, int T, hipStream_t stream) {
-  dim3 grid((T + FQ - 1) / FQ, H, B), block(256);
+  dim3 grid((T + FQ - 1) / FQ, H, B), block(FW * 64);
   hipLaunchKernelGGL(attn_flash_f16_kernel, grid, block, 0, stream, (const half_t*)q, q_ld, q_bs,
                      (const half_t*)k, k_ld, k_bs, (const half_t*)vt, vt_ld, vt_bs, (half_t*)out, o_ld, o_bs, T);
   return hipGetLastError();
