@@ -202,3 +202,35 @@ def test_dtw(gpu_device, N, M):
     got = hip.dtw_trace(torch.from_numpy(x).to(gpu_device)).cpu().numpy()
     assert np.array_equal(got[1:, 1:], want[1:, 1:])
     assert np.array_equal(oracle.backtrace(got), oracle.backtrace(want))
+
+
+@pytest.mark.parametrize("n_steps", [1, 2, 7, 8, 9, 17])
+def test_fused_greedy_step_count_edges(micro, gpu_device, n_steps):
+    """the device loop polls for completion every 8 tokens: step counts around that period and the degenerate
+    single-step call must give the oracle's ids and lengths (fp32 strict mode, EOT allowed)"""
+    dims, sd, om, models = micro["micro.en"]
+    model = models[hip.WH_F32]
+    B = 2
+    init = [50257]
+    rules = _rules(dims, 1, True)
+    feats = _feats(om, dims, B, seed=31)
+    want = oracle.greedy_decode(om, feats, init, n_steps, rules)
+    task = hip.HipTask(model, B, 1, 8)
+    try:
+        task.set_audio(feats.to(gpu_device).contiguous())
+        tokens = torch.zeros(B, 1 + n_steps + 1, dtype=torch.int64, device=gpu_device)
+        tokens[:, 0] = init[0]
+        mask = torch.zeros(dims.n_vocab, dtype=torch.uint8)
+        mask[rules.suppress_tokens] = 1
+        mask = mask.to(gpu_device)
+        p = hip.GreedyParams(sample_begin=1, max_steps=n_steps, n_ctx=dims.n_text_ctx, eot=rules.eot,
+                             timestamp_begin=rules.timestamp_begin, no_timestamps=rules.no_timestamps,
+                             max_initial_timestamp_index=50, suppress_blank=1, blank_token=220,
+                             suppress_mask=mask.data_ptr())
+        n, sum_lp, nsp = task.greedy(tokens, p, 0, rules.no_speech)
+        wt = want["tokens"]
+        assert n == wt.shape[1], (n, wt.shape)
+        assert torch.equal(tokens[:, :n].cpu(), wt)
+        assert np.allclose(sum_lp.cpu().numpy(), np.array(want["sum_logprobs"]), atol=2e-3)
+    finally:
+        task.close()
