@@ -185,6 +185,20 @@ def main():
             ms, nbytes = task.bench_kernel(kind, 64 if kind else 16)
             log(f"kernel {name}: {ms * 1e3:.1f} us, {nbytes / (ms * 1e-3) / 1e9:.0f} GB/s")
             kern[name] = {"avg_us": round(ms * 1e3, 2), "bytes": nbytes, "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1)}
+        # the MFMA-bound side of the pass, for orientation: AudioEncoder.forward on the batch (SURVEY.md §8d FLOP count)
+        mel = log_mel_spectrogram(audio, dims.n_mels)
+        model.encode(mel)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            model.encode(mel)
+        torch.cuda.synchronize(device)
+        enc_ms = (time.perf_counter() - t0) / 3 * 1e3
+        D_, L_, M_ = dims.n_audio_state, dims.n_audio_layer, dims.n_mels
+        enc_flop = B * (2 * 3000 * M_ * 3 * D_ + 2 * 1500 * D_ * 3 * D_ + L_ * (24 * 1500 * D_ * D_ + 4 * 1500 * 1500 * D_))
+        kern["encoder_forward"] = {"avg_us": round(enc_ms * 1e3, 1), "flop": enc_flop,
+                                   "TFLOPs": round(enc_flop / (enc_ms * 1e-3) / 1e12, 1), "mfma_peak_TFLOPs": 2500.0}
+        log(f"encoder forward: {enc_ms:.1f} ms, {enc_flop / (enc_ms * 1e-3) / 1e12:.0f} TFLOP/s")
         dom = kern["attn_decode_cross"]
         # HBM traffic per launch from the PMC counters: they cannot be read from inside this process, so the
         # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/, per round),

@@ -155,3 +155,41 @@ def test_large_v3_batch_invariance_and_determinism(gpu_device):
         assert tok1[0].tolist() == tok8[row].tolist(), row
         assert abs(float(lp1[0]) - float(lp8[row])) < 2e-2 * n_steps      # fp16 engine, different row tiling
     assert len({tuple(r) for r in tok8.tolist()}) > 1                        # rows are not all the same clip
+
+
+@pytest.mark.parametrize("name", ["w512", "w768", "w1024"])
+@pytest.mark.parametrize("dt,tol", [(hip.WH_F32, 1e-3), (hip.WH_F16, 6e-2)])
+def test_other_widths_encoder_and_steps(gpu_device, name, dt, tol):
+    """base / small / medium widths (D = 512, 768, 1024; 8, 12, 16 heads) at 2 + 2 layers: every width-dependent
+    kernel choice (GEMV shapes, LayerNorm register tiles, GEMM tiles, attention splits) against the oracle —
+    encoder output, prefill logits and 4 decode steps at 8 rows."""
+    dims = oracle.dims_for(name)
+    sd = oracle.synthetic_state_dict(dims, seed=7)
+    om = oracle.OracleModel(dims, sd)
+    model = hip.HipModel(dims, dt, hip.pack_weights(sd, dims, dt, gpu_device))
+    rng = np.random.default_rng(2)
+    t = np.arange(480000) / 16000.0
+    audio = (rng.standard_normal(480000) * 0.05 + 0.2 * np.sin(2 * np.pi * 500 * t)).astype(np.float32)[None]
+    filt = oracle.mel_filterbank(dims.n_mels)
+    mel = oracle.log_mel_spectrogram(audio, filt)
+    want_enc = om.encoder(mel)
+    got_enc = model.encode(mel.to(gpu_device)).float().cpu()
+    assert (got_enc - want_enc).abs().max().item() < (3e-4 if dt == hip.WH_F32 else 4e-2)
+    B, T0 = 8, 3
+    feats = _feats(dims, B, seed=13)
+    g = torch.Generator().manual_seed(6)
+    toks = torch.randint(0, dims.n_vocab, (B, T0 + 4), generator=g)
+    cache = om.new_cache()
+    want0 = om.decoder(toks[:, :T0], feats, cache)
+    task = hip.HipTask(model, B, 1, 8)
+    try:
+        task.set_audio(feats.to(gpu_device, model.torch_dtype).contiguous())
+        dtoks = toks.to(gpu_device)
+        got0 = task.prefill(dtoks[:, :T0].contiguous()).cpu()
+        assert (got0 - want0).abs().max().item() < tol
+        for i in range(4):
+            want = om.decoder(toks[:, T0 + i: T0 + i + 1], feats, cache)[:, -1]
+            got = task.step(dtoks[:, T0 + i]).cpu()
+            assert (got - want).abs().max().item() < tol, i
+    finally:
+        task.close()

@@ -735,8 +735,9 @@ hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream) {
       return launch_rows16_mf<half_t>(a, stream);
     return launch_rt<half_t, 8>(a, stream);           // R <= 8, or long K: row tiles of 8 on grid.y
   }
-  // fp32 (strict-parity mode): x rows are twice as wide in LDS
-  if (a.R <= 4 || (size_t)a.K * 8 * sizeof(float) > 128 * 1024) return launch_rt<float, 4>(a, stream);
+  // fp32 (strict-parity mode): x rows are twice as wide in LDS, and the 4-wave staging moves at most 24 units per
+  // thread per row (K <= 3072 at 8 rows, K <= 6144 at 4 rows)
+  if (a.R <= 4 || (size_t)a.K * 8 * sizeof(float) > 128 * 1024 || a.K > 3072) return launch_rt<float, 4>(a, stream);
   return launch_rt<float, 8>(a, stream);
 }
 

@@ -27,6 +27,8 @@ _DIMS = {
     "micro-v3": (128, 384, 6, 2, 2, 51866),
     # large-v3 widths at 2 + 2 layers: exercises the D = 1280 kernel shapes against the CPU oracle in seconds
     "wide-v3": (128, 1280, 20, 2, 2, 51866),
+    # the other released widths (base / small / medium) at 2 + 2 layers, for kernel-shape coverage
+    "w512": (80, 512, 8, 2, 2, 51865), "w768": (80, 768, 12, 2, 2, 51865), "w1024": (80, 1024, 16, 2, 2, 51865),
 }
 
 
