@@ -70,7 +70,7 @@ def _feats(om, dims, B, seed=0):
 
 @pytest.mark.parametrize("name", ["micro.en", "micro-v3"])
 @pytest.mark.parametrize("dt,tol", [(hip.WH_F32, 1e-3), (hip.WH_F16, 5e-2)])
-@pytest.mark.parametrize("B,G,T0", [(2, 1, 5), (1, 3, 17), (3, 1, 1)])
+@pytest.mark.parametrize("B,G,T0", [(2, 1, 5), (1, 3, 17), (3, 1, 1), (1, 1, 200), (16, 1, 2), (4, 10, 3)])
 def test_prefill_and_steps(micro, gpu_device, name, dt, tol, B, G, T0):
     """Teacher-forced logits at every position: prefill (GEMM path) then 6 single-token steps (GEMV path,
     the 2nd onwards replayed from the hipGraph) vs the oracle's KV-cache decoder.  fp32: |dlogit| < 1e-3."""
