@@ -233,3 +233,20 @@ def test_transcribe_batch_equals_sequential(setup, cond):
         assert np.allclose([s["avg_logprob"] for s in g["segments"]], [s["avg_logprob"] for s in w["segments"]], atol=1e-4)
         n_windows += len({s["seek"] for s in w["segments"]})
     assert n_windows >= 6
+
+
+def test_temperature_fallback_runs_sampling_path(setup):
+    """transcribe.py:184-224: a window whose greedy result trips the log-prob threshold is re-decoded at the next
+    temperature through the generic (host-driven, Categorical) loop; best_of > 1 exercises the grouped rows."""
+    key, dims, sd, model, mel = setup
+    torch.manual_seed(0)
+    r = model.transcribe(audio(41, 200000), temperature=(0.0, 0.5), logprob_threshold=0.0, fp16=False, language="en",
+                         sample_len=10, best_of=3, condition_on_previous_text=False)
+    assert len(r["segments"]) >= 1
+    assert all(s["temperature"] == 0.5 for s in r["segments"])          # the fallback result was kept
+    assert all(np.isfinite(s["avg_logprob"]) for s in r["segments"])
+    opts = whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=8, temperature=0.7, best_of=2)
+    res = whisper_amd.decode(model, mel, opts)
+    assert len(res.tokens) <= 8 and res.temperature == 0.7
+    with pytest.raises(ValueError):
+        whisper_amd.decode(model, mel, whisper_amd.DecodingOptions(language="en", beam_size=2, best_of=2))   # decoding.py:572-585
