@@ -400,6 +400,29 @@ static inline void* cross_layer(const wh_task* t, int l) {
   return (char*)t->cross_kv + (size_t)l * t->B * d.n_audio_ctx * 2 * d.n_text_state * t->m->esize;
 }
 
+// ---- skinny projections of the prefill -------------------------------------------------------------
+// The usual prefill is a handful of rows (batch x 3-4 initial tokens): a 128x128 MFMA tile would be > 80 % padding
+// and its launch fills 10-40 workgroups, so up to SKINNY_ROWS rows go through the decode-step projection kernels
+// (LayerNorm / residual fused, weights streamed once); long prompts keep the GEMM path.
+static const int SKINNY_ROWS = 48;
+
+static hipError_t proj_ln(const wh_model* m, const float* x, int rows, const float* ln_w, const float* ln_b, const void* W,
+                          const float* bias, int N, int K, void* y, int64_t y_ld, bool gelu, hipStream_t s) {
+  GemvArgs g; memset(&g, 0, sizeof(g));
+  g.pro = PRO_LN; g.xf = x; g.xf_ld = K; g.ln_w = ln_w; g.ln_b = ln_b;
+  g.W = W; g.bias = bias; g.N = N; g.K = K; g.R = rows;
+  g.epi = gelu ? EPI_GELU : EPI_STORE; g.y = y; g.y_ld = y_ld;
+  return launch_gemv(g, m->dtype, s);
+}
+static hipError_t proj_resid(const wh_model* m, const void* x, int64_t x_ld, int rows, const void* W, const float* bias,
+                             int N, int K, float* resid, hipStream_t s) {
+  GemvArgs g; memset(&g, 0, sizeof(g));
+  g.pro = PRO_PLAIN; g.x = x; g.x_ld = x_ld;
+  g.W = W; g.bias = bias; g.N = N; g.K = K; g.R = rows;
+  g.epi = EPI_RESID; g.resid = resid; g.resid_ld = N;
+  return launch_gemv(g, m->dtype, s);
+}
+
 // ---- prefill: T0 tokens per row through the GEMM path ------------------------------------------
 static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride, int T0, const int32_t* sel_pos,
                         int n_sel, float* logits_out, int64_t logits_row_ld, hipStream_t s) {
@@ -411,12 +434,17 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
   if (!t->audio_set) return WH_ERR_STATE;
   if (T0 <= 0 || T0 > t->Tmax || t->pos + T0 > C) return WH_ERR_ARG;
 
+  const bool skinny = M <= SKINNY_ROWS && D <= 2048;
   HIPCHK(launch_embed(tokens, token_stride, R, T0, m->w.tok_emb, m->w.dec_pos, t->d_pos, D, V, t->x, m->dtype, s));
   for (int l = 0; l < d.n_text_layer; ++l) {
     const wh_layer_weights& L = m->dec[l];
     // self attention (causal over cached + new positions)
-    HIPCHK(launch_layernorm(t->x, D, L.attn_ln_w, L.attn_ln_b, t->xn, D, M, D, m->dtype, s));
-    HIPCHK(gemm(m, t->xn, D, L.qkv_w, D, t->qkv, 3 * D, M, 3 * D, L.qkv_b, 0, nullptr, 0, false, s));
+    if (skinny) {
+      HIPCHK(proj_ln(m, t->x, M, L.attn_ln_w, L.attn_ln_b, L.qkv_w, L.qkv_b, 3 * D, D, t->qkv, 3 * D, false, s));
+    } else {
+      HIPCHK(launch_layernorm(t->x, D, L.attn_ln_w, L.attn_ln_b, t->xn, D, M, D, m->dtype, s));
+      HIPCHK(gemm(m, t->xn, D, L.qkv_w, D, t->qkv, 3 * D, M, 3 * D, L.qkv_b, 0, nullptr, 0, false, s));
+    }
     HIPCHK(launch_scatter_kv(t->qkv, R, T0, D, t->d_pos, C, self_k_layer(t, l), self_v_layer(t, l), m->dtype, s));
     {
       AttnArgs a; memset(&a, 0, sizeof(a));
@@ -427,10 +455,15 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
       a.H = H; a.Tq = T0; a.d_len = t->d_pos; a.causal = 1; a.kv_group = 1;
       HIPCHK(launch_attn_generic(a, R, m->dtype, s));
     }
-    HIPCHK(gemm(m, t->att, D, L.out_w, D, t->x, D, M, D, L.out_b, 0, t->x, D, true, s));
-    // cross attention over the cached audio K/V
-    HIPCHK(launch_layernorm(t->x, D, L.cross_ln_w, L.cross_ln_b, t->xn, D, M, D, m->dtype, s));
-    HIPCHK(gemm(m, t->xn, D, L.cq_w, D, t->qkv, D, M, D, L.cq_b, 0, nullptr, 0, false, s));
+    if (skinny) {
+      HIPCHK(proj_resid(m, t->att, D, M, L.out_w, L.out_b, D, D, t->x, s));
+      HIPCHK(proj_ln(m, t->x, M, L.cross_ln_w, L.cross_ln_b, L.cq_w, L.cq_b, D, D, t->qkv, D, false, s));
+    } else {
+      HIPCHK(gemm(m, t->att, D, L.out_w, D, t->x, D, M, D, L.out_b, 0, t->x, D, true, s));
+      // cross attention over the cached audio K/V
+      HIPCHK(launch_layernorm(t->x, D, L.cross_ln_w, L.cross_ln_b, t->xn, D, M, D, m->dtype, s));
+      HIPCHK(gemm(m, t->xn, D, L.cq_w, D, t->qkv, D, M, D, L.cq_b, 0, nullptr, 0, false, s));
+    }
     if (t->qcap) {   // keep q rows at their cache positions: [l][r][pos+t][D]
       for (int r = 0; r < R; ++r) {
         char* dst = (char*)t->qcap + (((size_t)l * R + r) * C + t->pos) * D * es;
@@ -447,11 +480,17 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
       a.H = H; a.Tq = T0; a.Tk = Ta; a.causal = 0; a.kv_group = t->G;
       HIPCHK(launch_attn_generic(a, R, m->dtype, s));
     }
-    HIPCHK(gemm(m, t->att, D, L.cout_w, D, t->x, D, M, D, L.cout_b, 0, t->x, D, true, s));
-    // MLP
-    HIPCHK(launch_layernorm(t->x, D, L.mlp_ln_w, L.mlp_ln_b, t->xn, D, M, D, m->dtype, s));
-    HIPCHK(gemm(m, t->xn, D, L.fc1_w, D, t->h, 4 * D, M, 4 * D, L.fc1_b, 1, nullptr, 0, false, s));
-    HIPCHK(gemm(m, t->h, 4 * D, L.fc2_w, 4 * D, t->x, D, M, D, L.fc2_b, 0, t->x, D, true, s));
+    if (skinny) {
+      HIPCHK(proj_resid(m, t->att, D, M, L.cout_w, L.cout_b, D, D, t->x, s));
+      HIPCHK(proj_ln(m, t->x, M, L.mlp_ln_w, L.mlp_ln_b, L.fc1_w, L.fc1_b, 4 * D, D, t->h, 4 * D, true, s));
+      HIPCHK(proj_resid(m, t->h, 4 * D, M, L.fc2_w, L.fc2_b, D, 4 * D, t->x, s));
+    } else {
+      HIPCHK(gemm(m, t->att, D, L.cout_w, D, t->x, D, M, D, L.cout_b, 0, t->x, D, true, s));
+      // MLP
+      HIPCHK(launch_layernorm(t->x, D, L.mlp_ln_w, L.mlp_ln_b, t->xn, D, M, D, m->dtype, s));
+      HIPCHK(gemm(m, t->xn, D, L.fc1_w, D, t->h, 4 * D, M, 4 * D, L.fc1_b, 1, nullptr, 0, false, s));
+      HIPCHK(gemm(m, t->h, 4 * D, L.fc2_w, 4 * D, t->x, D, M, D, L.fc2_b, 0, t->x, D, true, s));
+    }
   }
   // logits of the selected positions
   if (logits_out && n_sel > 0) {
@@ -466,12 +505,20 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
     HIPCHK(hipMemcpyAsync(t->d_sel, sel.data(), sel.size() * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));   // `sel` is host stack memory
     HIPCHK(launch_gather_rows(t->x, t->d_sel, Ms, D, t->xsel, s));
-    HIPCHK(launch_layernorm(t->xsel, D, m->w.dec_ln_w, m->w.dec_ln_b, t->xseln, D, Ms, D, m->dtype, s));
-    GemmArgs g; memset(&g, 0, sizeof(g));
-    g.A = t->xseln; g.lda = D; g.W = m->w.tok_emb; g.ldw = D;
-    g.C = logits_out; g.ldc = logits_row_ld;
-    g.M = Ms; g.N = V; g.K = D;
-    HIPCHK(launch_gemm(g, m->dtype, 1, 1, s));
+    if (Ms <= SKINNY_ROWS && D <= 2048) {          // LayerNorm + tied logits projection as one streaming launch
+      GemvArgs g; memset(&g, 0, sizeof(g));
+      g.pro = PRO_LN; g.xf = t->xsel; g.xf_ld = D; g.ln_w = m->w.dec_ln_w; g.ln_b = m->w.dec_ln_b;
+      g.W = m->w.tok_emb; g.N = V; g.K = D; g.R = Ms;
+      g.epi = EPI_F32; g.y = logits_out; g.y_ld = logits_row_ld;
+      HIPCHK(launch_gemv(g, m->dtype, s));
+    } else {
+      HIPCHK(launch_layernorm(t->xsel, D, m->w.dec_ln_w, m->w.dec_ln_b, t->xseln, D, Ms, D, m->dtype, s));
+      GemmArgs g; memset(&g, 0, sizeof(g));
+      g.A = t->xseln; g.lda = D; g.W = m->w.tok_emb; g.ldw = D;
+      g.C = logits_out; g.ldc = logits_row_ld;
+      g.M = Ms; g.N = V; g.K = D;
+      HIPCHK(launch_gemm(g, m->dtype, 1, 1, s));
+    }
   }
   HIPCHK(launch_add_int(t->d_pos, T0, s));
   t->pos += T0;
