@@ -310,8 +310,9 @@ static void task_carve(wh_task* t, void* base) {
   t->att = c.take(Mx * D * es);
   t->h = c.take(Mx * 4 * D * es);
   t->qbuf = c.take(R * D * es);
-  t->part_o = (float*)c.take(R * H * DEC_ATTN_MAX_SPLITS * 64 * 4);
-  t->part_ml = (float*)c.take(R * H * DEC_ATTN_MAX_SPLITS * 2 * 4);
+  const size_t Rp = R > 48 ? R : 48;          // the few-row prefill runs its cross attention through the decode kernel
+  t->part_o = (float*)c.take(Rp * H * DEC_ATTN_MAX_SPLITS * 64 * 4);
+  t->part_ml = (float*)c.take(Rp * H * DEC_ATTN_MAX_SPLITS * 2 * 4);
   t->logits = (float*)c.take(R * 2 * V * 4);
   t->xsel = (float*)c.take(Mx * D * 4);
   t->xseln = c.take(Mx * D * es);
@@ -471,7 +472,24 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
                               hipMemcpyDeviceToDevice, s));
       }
     }
-    {
+    if (skinny) {
+      // rows (r, t) are M independent single-query rows of the decode cross attention; the T0 * G rows of one
+      // audio share its K/V (one workgroup per (split, head, audio) when T0 * G <= 8)
+      const int ps = pick_splits(M, H, Ta, m->dtype);
+      DecAttnArgs a; memset(&a, 0, sizeof(a));
+      a.q = t->qkv; a.q_ld = D;
+      a.k = cross_layer(t, l); a.k_ld = 2 * D; a.k_bs = (int64_t)Ta * 2 * D;
+      a.v = (char*)cross_layer(t, l) + (size_t)D * es; a.v_ld = 2 * D; a.v_bs = a.k_bs;
+      a.H = H; a.R = M; a.kv_group = T0 * t->G; a.Tk = Ta; a.splits = ps;
+      a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
+      HIPCHK(launch_attn_decode(a, m->dtype, s));
+      GemvArgs g; memset(&g, 0, sizeof(g));
+      if (ps > 1) { g.pro = PRO_COMBINE; g.part_o = t->part_o; g.part_ml = t->part_ml; g.splits = ps; g.H = H; }
+      else { g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D; }
+      g.W = L.cout_w; g.bias = L.cout_b; g.N = D; g.K = D; g.R = M;
+      g.epi = EPI_RESID; g.resid = t->x; g.resid_ld = D;
+      HIPCHK(launch_gemv(g, m->dtype, s));
+    } else {
       AttnArgs a; memset(&a, 0, sizeof(a));
       a.q = t->qkv; a.q_ld = D; a.q_bs = (int64_t)T0 * D;
       a.k = cross_layer(t, l); a.k_ld = 2 * D; a.k_bs = (int64_t)Ta * 2 * D;
@@ -481,7 +499,6 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
       HIPCHK(launch_attn_generic(a, R, m->dtype, s));
     }
     if (skinny) {
-      HIPCHK(proj_resid(m, t->att, D, M, L.cout_w, L.cout_b, D, D, t->x, s));
       HIPCHK(proj_ln(m, t->x, M, L.mlp_ln_w, L.mlp_ln_b, L.fc1_w, L.fc1_b, 4 * D, D, t->h, 4 * D, true, s));
       HIPCHK(proj_resid(m, t->h, 4 * D, M, L.fc2_w, L.fc2_b, D, 4 * D, t->x, s));
     } else {
