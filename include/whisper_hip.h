@@ -145,7 +145,15 @@ int wh_task_step(wh_task *t, const int64_t *last_tokens, int64_t token_stride, f
 int wh_task_rearrange(wh_task *t, const int32_t *source_indices, void *stream);
 /* Inference.cleanup_caching (decoding.py:165-170): forget cached positions (keeps the audio). */
 int wh_task_reset(wh_task *t);
-/* number of cached self-attention positions (the `offset` of model.py:234) */
+/* Ragged prompts (no counterpart in the reference, whose DecodingTask shares one initial_tokens tuple between all
+ * rows, decoding.py:719).  Row r's token sequence is the longest row's shifted left by lag[r]
+ * (host array of n_rows ints, 0 <= lag[r] < max_prefill_tokens; NULL = all zero): it has a shorter leading prompt.
+ * Call before the prefill, with the position at 0.  The prefill still takes T0 tokens per row, of which the last
+ * lag[r] are padding (any valid id); sel_pos, sot_index and sample_begin are given for the longest row and apply
+ * lag[r] earlier in row r; each decode step appends row r at cache position (position - lag[r]) and
+ * wh_task_greedy writes row r's sampled tokens from column sample_begin - lag[r].  Cleared by wh_task_reset. */
+int wh_task_set_lag(wh_task *t, const int32_t *lag, void *stream);
+/* number of cached self-attention positions of the longest row (the `offset` of model.py:234) */
 int wh_task_position(const wh_task *t);
 
 /*

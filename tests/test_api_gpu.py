@@ -250,3 +250,75 @@ def test_temperature_fallback_runs_sampling_path(setup):
     assert len(res.tokens) <= 8 and res.temperature == 0.7
     with pytest.raises(ValueError):
         whisper_amd.decode(model, mel, whisper_amd.DecodingOptions(language="en", beam_size=2, best_of=2))   # decoding.py:572-585
+
+
+def _prompted_mels(dims, gpu_device, n):
+    return torch.stack([whisper_amd.pad_or_trim(whisper_amd.log_mel_spectrogram(audio(50 + i), dims.n_mels,
+                                                                                device=gpu_device), 3000) for i in range(n)])
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+def test_ragged_prompts_equal_single_row_decodes(setup, gpu_device, fp16):
+    """DecodingTask(prompts=...): rows of ONE fused greedy call conditioned on previous-text
+    prompts of different lengths (none, 1, 5, 17, 60 and 150 tokens; every row at its own cache positions on the
+    device) must return what each segment returns decoded alone with options.prompt — the reference's only way to
+    run it.  fp32: token ids exact and statistics to 1e-4; fp16: tokens exact on this seed, statistics to 2e-2.
+    One row is also checked against the CPU oracle."""
+    key, dims, sd, model, mel = setup
+    rng = np.random.default_rng(7)
+    prompts = [None, [1234], rng.integers(300, 40000, 5).tolist(), rng.integers(300, 40000, 17).tolist(),
+               rng.integers(300, 40000, 60).tolist(), rng.integers(300, 40000, 150).tolist()]
+    mels = _prompted_mels(dims, gpu_device, len(prompts))
+    opts = whisper_amd.DecodingOptions(language="en", fp16=fp16, sample_len=14)
+    got = whisper_amd.decode(model, mels, opts, prompts=prompts)
+    tol = 2e-2 if fp16 else 1e-4
+    for i, p in enumerate(prompts):
+        want = whisper_amd.decode(model, mels[i], opts, prompt=p)
+        assert got[i].tokens == want.tokens, i
+        assert abs(got[i].avg_logprob - want.avg_logprob) < tol
+        assert abs(got[i].no_speech_prob - want.no_speech_prob) < max(1e-6, tol * want.no_speech_prob)
+        assert got[i].text == want.text and got[i].compression_ratio == want.compression_ratio
+    if not fp16:
+        om = oracle.OracleModel(dims, sd)
+        multilingual = dims.n_vocab >= 51865
+        tok = get_tokenizer(multilingual, num_languages=dims.n_vocab - 51765 - int(multilingual), language="en", task="transcribe")
+        suppress = sorted(set(list(tok.non_speech_tokens) + [tok.transcribe, tok.translate, tok.sot, tok.sot_prev, tok.sot_lm, tok.no_speech]))
+        i = 3
+        init = [tok.sot_prev] + prompts[i] + list(tok.sot_sequence)
+        rules = oracle.SamplingRules(sample_begin=len(init), sot_index=init.index(tok.sot), eot=tok.eot,
+                                     timestamp_begin=tok.timestamp_begin, no_timestamps=tok.no_timestamps,
+                                     suppress_tokens=suppress, blank_token=tok.encode(" ")[0], no_speech=tok.no_speech)
+        omel = oracle.log_mel_spectrogram(audio(50 + i), oracle.mel_filterbank(dims.n_mels))
+        with torch.no_grad():
+            ref = oracle.greedy_decode(om, om.encoder(omel[None]), init, 14, rules)
+        body = ref["tokens"][0, len(init):].tolist()
+        body = body[: body.index(tok.eot)] if tok.eot in body else body
+        assert got[i].tokens == body
+
+
+def test_row_prompts_other_modes(setup, gpu_device):
+    """per-row prompts outside the fused greedy loop: equal-length prompts under beam search and under the generic
+    host loop equal the single-row decodes; language detection writes every row's own language slot; prompts of
+    different lengths are refused where rows cannot sit at different positions (beam search, long prompts)."""
+    key, dims, sd, model, mel = setup
+    rng = np.random.default_rng(8)
+    mels = _prompted_mels(dims, gpu_device, 3)
+    same_len = [rng.integers(300, 40000, 9).tolist() for _ in range(3)]
+    opts = whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=8, beam_size=2)
+    got = whisper_amd.decode(model, mels, opts, prompts=same_len)
+    for i in range(3):
+        assert got[i].tokens == whisper_amd.decode(model, mels[i], opts, prompt=same_len[i]).tokens, i
+    ragged = [same_len[0], same_len[1][:4], None]
+    with pytest.raises(ValueError):
+        whisper_amd.decode(model, mels, opts, prompts=ragged)
+    with pytest.raises(ValueError):      # 230 + 3 initial tokens + 224 steps do not fit n_text_ctx for the short rows' shared counter
+        whisper_amd.decode(model, mels, whisper_amd.DecodingOptions(language="en", fp16=False),
+                           prompts=[list(range(1000, 1230)), [5], None])
+    with pytest.raises(ValueError):
+        whisper_amd.decode(model, mels, whisper_amd.DecodingOptions(language="en", fp16=False, prompt=[7]), prompts=ragged)
+    if dims.n_vocab >= 51865:            # multilingual: detected language goes to sot_index + 1 of every row
+        opts = whisper_amd.DecodingOptions(fp16=False, sample_len=6)
+        got = whisper_amd.decode(model, mels, opts, prompts=ragged)
+        for i in range(3):
+            want = whisper_amd.decode(model, mels[i], opts, prompt=ragged[i])
+            assert got[i].language == want.language and got[i].tokens == want.tokens, i

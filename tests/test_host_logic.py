@@ -185,6 +185,39 @@ def test_task_setup_matches_reference(ref):
                 ref.decoding.DecodingTask(model, ref.DecodingOptions(**bad))
 
 
+def test_row_prompts_setup_matches_reference_per_row(ref):
+    """DecodingTask(prompts=[...]) (our addition): every row's initial tokens are exactly what
+    the reference's DecodingTask builds for that prompt alone (decoding.py:610-632); lags, the longest-row layout
+    and the batching classes of transcribe_batch follow from the lengths"""
+    from whisper_amd import decoding as mine
+    from whisper_amd.transcribe import _prompt_batches
+    model = _fake_model(True)
+    prompts = [None, [5], list(range(2000, 2006)), list(range(1000, 1300)), []]
+    for kw in (dict(), dict(without_timestamps=True), dict(prefix=[400, 500], sample_len=40)):
+        task = mine.DecodingTask(model, mine.DecodingOptions(language="en", **kw), prompts=prompts)
+        for p, row in zip(prompts, task.row_tokens):
+            b = ref.decoding.DecodingTask(model, ref.DecodingOptions(language="en", prompt=p, **kw))
+            assert row == b.initial_tokens
+        longest = max(task.row_tokens, key=len)
+        assert task.initial_tokens == longest and task.sample_begin == len(longest)
+        assert task.row_lag == [len(longest) - len(r) for r in task.row_tokens]
+        for r, lag in zip(task.row_tokens, task.row_lag):
+            assert r.index(task.tokenizer.sot) == task.sot_index - lag        # rows differ only in the leading prompt
+        assert task.ragged_limit() == 448 - task.sample_len
+    with pytest.raises(ValueError):
+        mine.DecodingTask(model, mine.DecodingOptions(language="en", prompt=[3]), prompts=prompts)
+    assert mine.DecodingTask(model, mine.DecodingOptions(language="en", beam_size=2), prompts=prompts).ragged_limit() is None
+    assert mine.DecodingTask(model, mine.DecodingOptions(language="en", temperature=0.4), prompts=prompts).ragged_limit() is None
+    by_index = dict(enumerate(prompts))
+    members = list(by_index)
+    # greedy: everything below the limit shares one ragged class; the saturated prompt (227 initial tokens) is alone
+    assert _prompt_batches(model, mine.DecodingOptions(language="en"), by_index, members, 16) == [[0, 1, 2, 4], [3]]
+    assert _prompt_batches(model, mine.DecodingOptions(language="en"), by_index, members, 3) == [[0, 1, 2], [4], [3]]
+    # beam search: only rows of equal length (no prompt == empty prompt) share a call
+    assert _prompt_batches(model, mine.DecodingOptions(language="en", beam_size=2), by_index, members, 16) == \
+        [[0, 4], [1], [2], [3]]
+
+
 class _ScriptedModel:
     """stands in for a Whisper model inside transcribe(): `decode` returns scripted DecodingResults"""
 

@@ -273,6 +273,9 @@ struct wh_task {
   float* logits;           // [R][V] step logits / [R][2][V] greedy prefill logits
   float* xsel; void* xseln;
   int* d_pos; int* d_alive; int* d_sel; int* d_src;
+  int* d_lag;              // [R] ragged prompts: row r is lag[r] tokens shorter than the longest row (zeros otherwise)
+  int* h_lag;              // host copy
+  bool lag_on;
   int64_t* step_tokens;
   float* samp_part;        // greedy sampler stage-1 partials
   void* qcap;              // [L][R*Tcap][D] captured cross-attention queries
@@ -320,6 +323,7 @@ static void task_carve(wh_task* t, void* base) {
   t->d_alive = (int*)c.take(256);
   t->d_sel = (int*)c.take(Mx * 4);
   t->d_src = (int*)c.take(R * 4);
+  t->d_lag = (int*)c.take(R * 4);
   t->step_tokens = (int64_t*)c.take(R * 8);
   t->samp_part = (float*)c.take(greedy_sample_scratch_bytes((int)R, (int)V));
   t->qcap = (t->flags & WH_TASK_CAPTURE_Q) ? c.take(L * R * C * D * es) : nullptr;
@@ -350,8 +354,11 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
     const int cap = attn_decode_capacity(m->dtype);
     t->self_splits = (m->d.n_text_ctx + cap - 1) / cap;
   }
+  t->h_lag = (int*)calloc((size_t)t->R, sizeof(int));
+  if (!t->h_lag) { delete t; return WH_ERR_ARG; }
   hipError_t e = hipMemset(t->d_pos, 0, 4);
-  if (e != hipSuccess) { g_last_hip = e; delete t; return WH_ERR_HIP; }
+  if (e == hipSuccess) e = hipMemset(t->d_lag, 0, (size_t)t->R * 4);
+  if (e != hipSuccess) { g_last_hip = e; free(t->h_lag); delete t; return WH_ERR_HIP; }
   *out = t;
   return WH_OK;
 }
@@ -360,6 +367,7 @@ extern "C" void wh_task_destroy(wh_task* t) {
   if (!t) return;
   if (t->graph_exec) (void)hipGraphExecDestroy(t->graph_exec);
   if (t->graph) (void)hipGraphDestroy(t->graph);
+  free(t->h_lag);
   delete t;
 }
 
@@ -369,6 +377,32 @@ extern "C" int wh_task_reset(wh_task* t) {
   if (!t) return WH_ERR_ARG;
   HIPCHK(hipMemset(t->d_pos, 0, 4));
   t->pos = 0;
+  if (t->lag_on) {
+    HIPCHK(hipMemset(t->d_lag, 0, (size_t)t->R * 4));
+    memset(t->h_lag, 0, (size_t)t->R * sizeof(int));
+    t->lag_on = false;
+  }
+  return WH_OK;
+}
+
+// Ragged prompts: row r's token sequence is the longest row's shifted left by lag[r] (a shorter leading prompt).
+// Set before the prefill; the prefill then reads T0 tokens per row of which the last lag[r] are padding (any valid
+// id; causality keeps them out of the real positions and the decode steps overwrite their cache slots), and every
+// later step appends row r at position - lag[r].  Cleared by wh_task_reset.
+extern "C" int wh_task_set_lag(wh_task* t, const int32_t* lag, void* stream) {
+  if (!t) return WH_ERR_ARG;
+  if (t->pos != 0) return WH_ERR_STATE;
+  if (t->flags & WH_TASK_CAPTURE_Q) return WH_ERR_STATE;      // captured queries are indexed by the common position
+  bool any = false;
+  for (int r = 0; r < t->R; ++r) {
+    const int v = lag ? lag[r] : 0;
+    if (v < 0 || v >= t->Tmax) return WH_ERR_ARG;
+    t->h_lag[r] = v;
+    any = any || v != 0;
+  }
+  HIPCHK(hipMemcpyAsync(t->d_lag, t->h_lag, (size_t)t->R * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  t->lag_on = any;
   return WH_OK;
 }
 
@@ -434,9 +468,13 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
   const size_t es = m->esize;
   if (!t->audio_set) return WH_ERR_STATE;
   if (T0 <= 0 || T0 > t->Tmax || t->pos + T0 > C) return WH_ERR_ARG;
+  if (t->lag_on) {
+    if (t->pos != 0) return WH_ERR_STATE;
+    for (int r = 0; r < R; ++r) if (t->h_lag[r] >= T0) return WH_ERR_ARG;
+  }
 
   const bool skinny = M <= SKINNY_ROWS && D <= 2048;
-  HIPCHK(launch_embed(tokens, token_stride, R, T0, m->w.tok_emb, m->w.dec_pos, t->d_pos, D, V, t->x, m->dtype, s));
+  HIPCHK(launch_embed(tokens, token_stride, R, T0, m->w.tok_emb, m->w.dec_pos, t->d_pos, nullptr, D, V, t->x, m->dtype, s));
   for (int l = 0; l < d.n_text_layer; ++l) {
     const wh_layer_weights& L = m->dec[l];
     // self attention (causal over cached + new positions)
@@ -514,7 +552,7 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
     std::vector<int> sel((size_t)R * n_sel);
     for (int r = 0; r < R; ++r)
       for (int i = 0; i < n_sel; ++i) {
-        const int p = sel_pos ? sel_pos[i] : i;
+        const int p = (sel_pos ? sel_pos[i] : i) - (sel_pos ? t->h_lag[r] : 0);   // selected positions shift with the row
         if (p < 0 || p >= T0) return WH_ERR_ARG;
         sel[(size_t)r * n_sel + i] = r * T0 + p;
       }
@@ -556,7 +594,7 @@ static int step_launch(wh_task* t, hipStream_t s) {
   const int D = d.n_text_state, H = d.n_text_head, C = d.n_text_ctx, Ta = d.n_audio_ctx, V = d.n_vocab;
   const int R = t->R;
   const size_t es = m->esize;
-  HIPCHK(launch_embed(t->step_tokens, 1, R, 1, m->w.tok_emb, m->w.dec_pos, t->d_pos, D, V, t->x, m->dtype, s));
+  HIPCHK(launch_embed(t->step_tokens, 1, R, 1, m->w.tok_emb, m->w.dec_pos, t->d_pos, t->d_lag, D, V, t->x, m->dtype, s));
   for (int l = 0; l < d.n_text_layer; ++l) {
     const wh_layer_weights& L = m->dec[l];
     GemvArgs g;
@@ -566,6 +604,7 @@ static int step_launch(wh_task* t, hipStream_t s) {
     g.W = L.qkv_w; g.bias = L.qkv_b; g.N = 3 * D; g.K = D; g.R = R;
     g.epi = EPI_QKV; g.y = t->qbuf; g.y_ld = D;
     g.kcache = self_k_layer(t, l); g.vcache = self_v_layer(t, l); g.cache_bs = (int64_t)C * D; g.d_pos = t->d_pos; g.D = D;
+    g.lag = t->d_lag;
     HIPCHK(launch_gemv(g, m->dtype, s));
     {
       DecAttnArgs a; memset(&a, 0, sizeof(a));
@@ -573,6 +612,7 @@ static int step_launch(wh_task* t, hipStream_t s) {
       a.k = self_k_layer(t, l); a.k_ld = D; a.k_bs = (int64_t)C * D;
       a.v = self_v_layer(t, l); a.v_ld = D; a.v_bs = (int64_t)C * D;
       a.H = H; a.R = R; a.kv_group = 1; a.d_len = t->d_pos; a.len_plus = 1; a.splits = t->self_splits;
+      a.lag = t->d_lag;
       a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
       HIPCHK(launch_attn_decode(a, m->dtype, s));
     }
@@ -718,6 +758,8 @@ extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* to
   const int V = d.n_vocab, R = t->R, T0 = p->sample_begin;
   if (t->pos != 0 || T0 <= 0 || T0 > t->Tmax || p->max_steps <= 0) return WH_ERR_ARG;
   if (token_stride < (int64_t)T0 + p->max_steps) return WH_ERR_ARG;
+  // ragged rows share one step counter: no row may reach the context limit before the step budget runs out
+  if (t->lag_on && (T0 + p->max_steps > p->n_ctx || T0 + p->max_steps > d.n_text_ctx)) return WH_ERR_ARG;
 
   int32_t sel[2]; int n_sel;
   const bool want_ns = no_speech_token >= 0 && no_speech_probs != nullptr;
@@ -732,7 +774,7 @@ extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* to
   HIPCHK(hipStreamSynchronize(s));
 
   SampleArgs sa; memset(&sa, 0, sizeof(sa));
-  sa.R = R; sa.V = V; sa.tokens = tokens; sa.token_stride = token_stride; sa.d_ntok = t->d_pos;
+  sa.R = R; sa.V = V; sa.tokens = tokens; sa.token_stride = token_stride; sa.d_ntok = t->d_pos; sa.lag = t->d_lag;
   sa.sample_begin = T0; sa.eot = p->eot; sa.timestamp_begin = p->timestamp_begin; sa.no_timestamps = p->no_timestamps;
   sa.max_initial_ts = p->max_initial_timestamp_index; sa.suppress_blank = p->suppress_blank;
   sa.blank_token = p->blank_token; sa.suppress_mask = p->suppress_mask; sa.sum_logprobs = sum_logprobs;

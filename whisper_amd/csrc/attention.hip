@@ -319,6 +319,7 @@ __device__ __forceinline__ float4v scale_q(float4v q) { return q * SCALE; }
 // cached length is only known on the device); without it every round is issued unconditionally.
 template <typename T, int NL, int WAVES, bool SKIP>
 __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArgs a) {
+  pin_kernargs(a);
   typedef typename ET<T>::unit_t unit_t;
   constexpr int UNIT = ET<T>::UNIT;
   constexpr int LPK = 64 / UNIT;     // lanes per key (8 fp16 / 16 fp32)
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int s = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
   const int S = a.splits;
-  const int Tk = a.d_len ? (*a.d_len + a.len_plus) : a.Tk;
+  const int Tk = a.d_len ? (*a.d_len + a.len_plus - (a.lag ? a.lag[r] : 0)) : a.Tk;
   int chunk = (Tk + S - 1) / S;
   chunk = (chunk + KPR - 1) / KPR * KPR;
   const int k0 = s * chunk;
@@ -451,6 +452,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArg
 // =============================================================================================
 template <typename T, int NL, int WAVES, int GQ>
 __global__ __launch_bounds__(WAVES * 64) void attn_decode_group_kernel(whk::DecAttnArgs a) {
+  pin_kernargs(a);
   typedef typename ET<T>::unit_t unit_t;
   constexpr int UNIT = ET<T>::UNIT;
   constexpr int LPK = 64 / UNIT, KPW = 64 / LPK, KPR = WAVES * KPW;

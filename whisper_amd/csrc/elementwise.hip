@@ -102,13 +102,14 @@ void layernorm_dispatch(const float* x, int64_t ldx, const float* w, const float
 template <typename T>
 __global__ void embed_kernel(const int64_t* __restrict__ tokens, int64_t stride, int T0,
                              const T* __restrict__ emb, const float* __restrict__ pos,
-                             const int* __restrict__ d_offset, int D, int n_vocab, float* __restrict__ x) {
+                             const int* __restrict__ d_offset, const int* __restrict__ lag, int D, int n_vocab,
+                             float* __restrict__ x) {
   const int row = blockIdx.x;           // r*T0 + t
   const int r = row / T0, t = row - r * T0;
   int64_t tok = tokens[(int64_t)r * stride + t];
   if (tok < 0) tok = 0;
   if (tok >= n_vocab) tok = n_vocab - 1;
-  const int p = *d_offset + t;
+  const int p = *d_offset - (lag ? lag[r] : 0) + t;
   const T* e = emb + tok * D;
   const float* pp = pos + (int64_t)p * D;
   float* xr = x + (int64_t)row * D;
@@ -215,13 +216,13 @@ hipError_t launch_layernorm(const float* x, int64_t ldx, const float* w, const f
 }
 
 hipError_t launch_embed(const int64_t* tokens, int64_t stride, int R, int T0, const void* tok_emb,
-                        const float* pos, const int* d_offset, int D, int n_vocab, float* x, int dtype,
-                        hipStream_t stream) {
+                        const float* pos, const int* d_offset, const int* lag, int D, int n_vocab, float* x,
+                        int dtype, hipStream_t stream) {
   dim3 grid(R * T0), block(256);
   if (dtype == 1)
-    hipLaunchKernelGGL((embed_kernel<half_t>), grid, block, 0, stream, tokens, stride, T0, (const half_t*)tok_emb, pos, d_offset, D, n_vocab, x);
+    hipLaunchKernelGGL((embed_kernel<half_t>), grid, block, 0, stream, tokens, stride, T0, (const half_t*)tok_emb, pos, d_offset, lag, D, n_vocab, x);
   else
-    hipLaunchKernelGGL((embed_kernel<float>), grid, block, 0, stream, tokens, stride, T0, (const float*)tok_emb, pos, d_offset, D, n_vocab, x);
+    hipLaunchKernelGGL((embed_kernel<float>), grid, block, 0, stream, tokens, stride, T0, (const float*)tok_emb, pos, d_offset, lag, D, n_vocab, x);
   return hipGetLastError();
 }
 

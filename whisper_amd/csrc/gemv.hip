@@ -62,6 +62,8 @@ template <> struct Pack4<half_t> {
 template <typename T, int RT, int LPR, int PRO, int J, bool MULTI, int WAVES, int GS, bool MF>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int gp, int red_alias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  pin_kernargs(a);
+  asm volatile("" ::"s"(gp), "s"(red_alias));
   typedef typename ET<T>::unit_t unit_t;
   constexpr int UNIT = ET<T>::UNIT;
   constexpr int NT = WAVES * 64;
@@ -122,6 +124,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
   const int es = tid / (NB * RT), er = (tid / NB) % RT, ej = tid % NB;
   const bool e_on = es < GS && er < R;
   float e_bias = 0.f, e_res = 0.f;
+  int e_lag = 0;                                   // EPI_QKV: this row's position lag (ragged prompts)
+  if (e_on && a.epi == whk::EPI_QKV && a.lag) e_lag = a.lag[r0 + er];
   if (e_on) {
     const int n = (g0 + es) * NB + ej;
     if (n < a.N) {
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
             const int D = a.D;
             if (n < D) ((T*)a.y)[rr * a.y_ld + n] = from_f32<T>(v);
             else {
-              const int64_t pos = *a.d_pos;
+              const int64_t pos = *a.d_pos - e_lag;
               if (n < 2 * D) ((T*)a.kcache)[rr * a.cache_bs + pos * D + (n - D)] = from_f32<T>(v);
               else ((T*)a.vcache)[rr * a.cache_bs + pos * D + (n - 2 * D)] = from_f32<T>(v);
             }
@@ -576,6 +580,8 @@ hipError_t launch_rows16_mf(const whk::GemvArgs& a, hipStream_t stream) {
 template <typename T, int RT, int J>
 __global__ __launch_bounds__(512) void gemv_stream_kernel(whk::GemvArgs a, int groups_per_wave) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  pin_kernargs(a);
+  asm volatile("" ::"s"(groups_per_wave));
   typedef typename ET<T>::unit_t unit_t;
   constexpr int UNIT = ET<T>::UNIT, WAVES = 8, LPR = 8, NB = 8, BLK = LPR * UNIT, NU = 10;
   constexpr int NR = (RT + WAVES - 1) / WAVES;

@@ -43,10 +43,10 @@ hipError_t launch_mel_transpose(const void* mel, int mel_is_f16, int B, int n_me
 // fp32 x [rows][D] (row stride ldx) -> element-type out [rows][D] (row stride ldo)
 hipError_t launch_layernorm(const float* x, int64_t ldx, const float* w, const float* b, void* out,
                             int64_t ldo, int64_t rows, int D, int dtype, hipStream_t stream);
-// x[r*T0+t][:] = tok_emb[tokens[r*stride+t]][:] + pos[(offset+t)][:]   (fp32 out)
+// x[r*T0+t][:] = tok_emb[tokens[r*stride+t]][:] + pos[(offset - lag[r] + t)][:]   (fp32 out; lag may be null)
 hipError_t launch_embed(const int64_t* tokens, int64_t stride, int R, int T0, const void* tok_emb,
-                        const float* pos, const int* d_offset, int D, int n_vocab, float* x, int dtype,
-                        hipStream_t stream);
+                        const float* pos, const int* d_offset, const int* lag, int D, int n_vocab, float* x,
+                        int dtype, hipStream_t stream);
 // qkv [R*T0][3D] -> q [R*T0][D] is left in place (ld 3D); k,v rows scattered to caches [R][n_ctx][D]
 hipError_t launch_scatter_kv(const void* qkv, int R, int T0, int D, const int* d_offset, int n_ctx,
                              void* kcache, void* vcache, int dtype, hipStream_t stream);
@@ -88,6 +88,7 @@ struct DecAttnArgs {
   int64_t kv_hs;                                  // head stride in elements: 0 means 64 (heads side by side in a row)
   int H; int R; int kv_group;
   int Tk; const int* d_len; int len_plus;         // Tk fixed, or *d_len + len_plus
+  const int* lag;                                 // with d_len: row r holds lag[r] fewer keys (ragged prompts); may be null
   int splits;                                     // key-range splits
   void* out; int64_t o_ld;                        // splits==1: normalized output, element type
   float* part_o; float* part_ml;                  // splits>1: [R][H][S][64], [R][H][S][2]
@@ -117,7 +118,8 @@ struct GemvArgs {
   int epi;
   void* y; int64_t y_ld;                          // EPI_STORE / EPI_GELU (element type), EPI_F32 (float)
   float* resid; int64_t resid_ld;                 // EPI_RESID: resid[r][n] += y
-  void* kcache; void* vcache; int64_t cache_bs; const int* d_pos; int D;  // EPI_QKV
+  void* kcache; void* vcache; int64_t cache_bs; const int* d_pos; int D;  // EPI_QKV: row r appends at *d_pos - lag[r]
+  const int* lag;                                 // EPI_QKV: per-row position lag (ragged prompts); may be null
   int* bump; int bump_by;                         // optional: *bump += bump_by once per launch (position counter)
   int variant;                                    // 0 = shape heuristic; > 0 forces a kernel shape (tools/probe_decode)
   WH_PROBE_FIELD
@@ -129,7 +131,8 @@ struct SampleArgs {
   const float* logits; int64_t logits_ld;   // row r at logits + r*logits_ld, V entries
   int R, V;
   int64_t* tokens; int64_t token_stride;          // [R][stride], current length *d_ntok
-  const int* d_ntok;          // device: number of tokens currently in each row (== cached positions)
+  const int* d_ntok;          // device: number of tokens currently in the longest row (== cached positions)
+  const int* lag;             // row r holds lag[r] fewer tokens, its sample_begin is lag[r] earlier; may be null
   int sample_begin, eot, timestamp_begin, no_timestamps, max_initial_ts, suppress_blank, blank_token;
   const uint8_t* suppress_mask;
   float* sum_logprobs;        // [R]

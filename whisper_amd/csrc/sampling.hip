@@ -47,6 +47,7 @@ constexpr int SCHUNK = 1024;    // vocabulary entries per stage-1 workgroup (256
 // to two partial statistics (text range, timestamp range): {max, sum exp(x - max), first arg-max}.
 // All four logits of a thread are requested before any is used (one L2 round trip per workgroup).
 __global__ __launch_bounds__(256) void greedy_partial_kernel(whk::SampleArgs a) {
+  pin_kernargs(a);
   __shared__ int sh_last_ts;
   __shared__ float sh_m[2][4], sh_s[2][4];
   __shared__ int sh_i[2][4];
@@ -59,9 +60,11 @@ __global__ __launch_bounds__(256) void greedy_partial_kernel(whk::SampleArgs a) 
     const int v = c * SCHUNK + j * 256 + tid;
     xv[j] = v < a.V ? x[v] : WH_NEG_INF;
   }
-  const int ntok = *a.d_ntok;
+  const int lag = a.lag ? a.lag[k] : 0;  // ragged prompts: this row's indices sit lag earlier than the longest row's
+  const int ntok = *a.d_ntok - lag;
+  const int sample_begin = a.sample_begin - lag;
   const int64_t* row = a.tokens + (int64_t)k * a.token_stride;
-  const int L = ntok - a.sample_begin;
+  const int L = ntok - sample_begin;
   const int TB = a.timestamp_begin;       // < 0: timestamp rules disabled (without_timestamps)
   const bool ts_rules = TB >= 0;
 
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void greedy_partial_kernel(whk::SampleArgs a) 
   __syncthreads();
   if (ts_rules) {
     for (int t = tid; t < L; t += 256)
-      if (row[a.sample_begin + t] >= TB) atomicMax(&sh_last_ts, t);
+      if (row[sample_begin + t] >= TB) atomicMax(&sh_last_ts, t);
   }
   __syncthreads();
 
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void greedy_partial_kernel(whk::SampleArgs a) 
     last_ts = (L >= 1) && (row[ntok - 1] >= TB);
     pen_ts = (L < 2) || (row[ntok - 2] >= TB);
     if (sh_last_ts >= 0) {
-      const int t = (int)row[a.sample_begin + sh_last_ts];
+      const int t = (int)row[sample_begin + sh_last_ts];
       ts_lo = TB;
       ts_hi = (last_ts && !pen_ts) ? t : t + 1;
     }
@@ -127,11 +130,14 @@ __global__ __launch_bounds__(256) void greedy_partial_kernel(whk::SampleArgs a) 
 // Stage 2: one workgroup per row merges the chunk partials, applies the "timestamp mass" rule and
 // GreedyDecoder.update, and appends the token.
 __global__ __launch_bounds__(256) void greedy_final_kernel(whk::SampleArgs a, int nchunk) {
+  pin_kernargs(a);
+  asm volatile("" ::"s"(nchunk));
   __shared__ float sh_m[2][4], sh_s[2][4];
   __shared__ int sh_i[2][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k = blockIdx.x;
-  const int ntok = *a.d_ntok;
+  const int lag = a.lag ? a.lag[k] : 0;
+  const int ntok = *a.d_ntok - lag;
   int64_t* row = a.tokens + (int64_t)k * a.token_stride;
   const bool ts_rules = a.timestamp_begin >= 0;
   Stat st[2];
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256) void greedy_final_kernel(whk::SampleArgs a, in
     else next = a.eot;
     row[ntok] = next;
     if (a.step_tokens) a.step_tokens[k] = next;
-    if (next != a.eot) *a.d_alive_step = ntok;       // benign race: every writer stores the same value
+    if (next != a.eot) *a.d_alive_step = ntok + lag;      // benign race: every writer stores the same value
   }
 }
 

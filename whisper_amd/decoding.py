@@ -387,13 +387,20 @@ class ApplyTimestampRules(LogitFilter):
 # ---------------------------------------------------------------------------------------------------------------
 # the task
 # ---------------------------------------------------------------------------------------------------------------
+_FROM_OPTIONS = object()
+
+
 class DecodingTask:
     inference: Inference
     sequence_ranker: SequenceRanker
     decoder: TokenDecoder
     logit_filters: List[LogitFilter]
 
-    def __init__(self, model: "Whisper", options: DecodingOptions):
+    def __init__(self, model: "Whisper", options: DecodingOptions, prompts: Optional[Sequence[Sequence[int]]] = None):
+        """`prompts` (no counterpart in the reference, whose task shares ONE initial_tokens tuple between all rows,
+        decoding.py:719): one previous-text token list per audio segment, each used exactly as
+        `options.prompt` would be for that segment alone.  Prompts of different lengths ("ragged") are decoded by the
+        fused greedy loop, every row at its own positions; `options.prompt` must then be unset."""
         self.model = model
         tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages,
                                   language=options.language or "en", task=options.task)
@@ -408,7 +415,18 @@ class DecodingTask:
         if self.options.without_timestamps:
             self.sot_sequence = tokenizer.sot_sequence_including_notimestamps
 
-        self.initial_tokens: Tuple[int] = self._get_initial_tokens()
+        # per-segment prompts: `initial_tokens`, `sample_begin` and `sot_index` describe the LONGEST row; row r is
+        # that layout shifted left by row_lag[r] tokens
+        self.row_tokens: Optional[List[Tuple[int]]] = None
+        self.row_lag: Optional[List[int]] = None
+        if prompts is not None:
+            if options.prompt:
+                raise ValueError("per-segment prompts and options.prompt can't be given together")
+            self.row_tokens = [self._get_initial_tokens(list(p) if p is not None else None) for p in prompts]
+            self.initial_tokens: Tuple[int] = max(self.row_tokens, key=len)
+            self.row_lag = [len(self.initial_tokens) - len(r) for r in self.row_tokens]
+        else:
+            self.initial_tokens: Tuple[int] = self._get_initial_tokens()
         self.sample_begin: int = len(self.initial_tokens)
         self.sot_index: int = self.initial_tokens.index(tokenizer.sot)
 
@@ -445,7 +463,7 @@ class DecodingTask:
             raise ValueError("length_penalty (alpha) should be a value between 0 and 1")
         return options
 
-    def _get_initial_tokens(self) -> Tuple[int]:
+    def _get_initial_tokens(self, prompt=_FROM_OPTIONS) -> Tuple[int]:
         tokens = list(self.sot_sequence)
         prefix = self.options.prefix
         if prefix:
@@ -453,7 +471,8 @@ class DecodingTask:
             if self.sample_len is not None:
                 prefix_tokens = prefix_tokens[-(self.n_ctx // 2 - self.sample_len):]
             tokens = tokens + prefix_tokens
-        prompt = self.options.prompt
+        if prompt is _FROM_OPTIONS:
+            prompt = self.options.prompt
         if prompt:
             prompt_tokens = self.tokenizer.encode(" " + prompt.strip()) if isinstance(prompt, str) else prompt
             tokens = [self.tokenizer.sot_prev] + prompt_tokens[-(self.n_ctx // 2 - 1):] + tokens
@@ -495,7 +514,12 @@ class DecodingTask:
             lang_tokens, lang_probs = self.model.detect_language(audio_features, self.tokenizer)
             languages = [max(probs, key=probs.get) for probs in lang_probs]
             if self.options.language is None:
-                tokens[:, self.sot_index + 1] = lang_tokens.to(tokens.device)
+                lang_tokens = lang_tokens.to(tokens.device)
+                if self.row_lag is None:
+                    tokens[:, self.sot_index + 1] = lang_tokens
+                else:
+                    for r, lag in enumerate(self.row_lag):
+                        tokens[r, self.sot_index - lag + 1] = lang_tokens[r]
         return languages, lang_probs
 
     # -- sampling loops -------------------------------------------------------------------------------------
@@ -527,13 +551,39 @@ class DecodingTask:
                 suppress_blank=int(bool(self.options.suppress_blank)), blank_token=tk.encode(" ")[0],
                 suppress_mask=mask.data_ptr())
             no_speech = tk.no_speech if tk.no_speech is not None else -1
+            ragged = self._ragged()
+            if ragged:
+                task.set_lag(self.row_lag)
             n, sum_logprobs, nsp = task.greedy(buf, params, self.sot_index, no_speech)
             no_speech_probs = nsp.tolist() if nsp is not None else [np.nan] * n_rows
-            return buf[:, :n], sum_logprobs, no_speech_probs
+            if not ragged:
+                return buf[:, :n], sum_logprobs, no_speech_probs
+            # row r holds n - lag tokens: right-align so that every row's sampled part starts at sample_begin
+            out = torch.full((n_rows, n), tk.sot, dtype=torch.int64, device=dev)
+            for r, lag in enumerate(self.row_lag):
+                out[r, lag:] = buf[r, : n - lag]
+            return out, sum_logprobs, no_speech_probs
         finally:
             self.inference.cleanup_caching()
 
+    def _ragged(self) -> bool:
+        return self.row_lag is not None and any(self.row_lag)
+
+    def ragged_limit(self) -> Optional[int]:
+        """longest initial sequence that rows of different lengths may have in one call (None: this task can only
+        take rows of equal length).  Rows share one step counter on the device, so none may reach the context
+        limit (reference decoding.py:705) before the `sample_len` budget runs out."""
+        return self.n_ctx - self.sample_len if self._fused_greedy_ok(None) else None
+
     def _main_loop(self, audio_features: Tensor, tokens: Tensor):
+        if self._ragged():
+            limit = self.ragged_limit()
+            if limit is None:
+                raise ValueError("prompts of different lengths need greedy decoding (temperature 0, no beams / "
+                                 "best_of) with the stock logit filters")
+            if self.sample_begin > limit:
+                raise ValueError(f"prompts of different lengths: the longest initial sequence ({self.sample_begin}) "
+                                 f"+ sample_len ({self.sample_len}) exceeds n_text_ctx ({self.n_ctx})")
         if self._fused_greedy_ok(tokens):
             return self._main_loop_fused(audio_features, tokens)
         n_batch = tokens.shape[0]
@@ -565,7 +615,13 @@ class DecodingTask:
         n_audio: int = mel.shape[0]
 
         audio_features: Tensor = self._get_audio_features(mel)
-        tokens: Tensor = torch.tensor([self.initial_tokens]).repeat(n_audio, 1)
+        if self.row_tokens is None:
+            tokens: Tensor = torch.tensor([self.initial_tokens]).repeat(n_audio, 1)
+        else:
+            if len(self.row_tokens) != n_audio:
+                raise ValueError(f"{len(self.row_tokens)} prompts for {n_audio} audio segments")
+            # shorter rows are padded on the right: causal attention keeps the padding out of the real positions
+            tokens = torch.tensor([list(r) + [tokenizer.eot] * lag for r, lag in zip(self.row_tokens, self.row_lag)])
 
         languages, language_probs = self._detect_language(audio_features, tokens)
         if self.options.task == "lang_id":
@@ -607,12 +663,13 @@ class DecodingTask:
 
 @torch.no_grad()
 def decode(model: "Whisper", mel: Tensor, options: DecodingOptions = DecodingOptions(),
-           **kwargs) -> Union[DecodingResult, List[DecodingResult]]:
-    """Decode 30-second segment(s) given as (n_mels, 3000) or (*, n_mels, 3000) log-mel spectrograms."""
+           prompts: Optional[Sequence[Sequence[int]]] = None, **kwargs) -> Union[DecodingResult, List[DecodingResult]]:
+    """Decode 30-second segment(s) given as (n_mels, 3000) or (*, n_mels, 3000) log-mel spectrograms.
+    `prompts`: optional previous-text token list per segment (see DecodingTask)."""
     single = mel.ndim == 2
     if single:
         mel = mel.unsqueeze(0)
     if kwargs:
         options = replace(options, **kwargs)
-    result = DecodingTask(model, options).run(mel)
+    result = DecodingTask(model, options, prompts).run(mel)
     return result[0] if single else result

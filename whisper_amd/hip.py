@@ -81,6 +81,7 @@ SIGNATURES = {
     "wh_task_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "wh_task_rearrange": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "wh_task_reset": (C.c_int, [C.c_void_p]),
+    "wh_task_set_lag": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "wh_task_position": (C.c_int, [C.c_void_p]),
     "wh_task_greedy": (C.c_int, [C.c_void_p, C.POINTER(GreedyParams), C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
@@ -406,6 +407,16 @@ class HipTask:
     def reset(self):
         torch.cuda.synchronize(self.model.device)
         check(lib().wh_task_reset(self.handle), "wh_task_reset")
+
+    def set_lag(self, lag: Optional[Sequence[int]]):
+        """ragged prompts: row r's sequence is the longest row's shifted left by lag[r] (include/whisper_hip.h)"""
+        arr = None
+        if lag is not None:
+            assert len(lag) == self.n_rows
+            arr = (C.c_int32 * len(lag))(*[int(v) for v in lag])
+        cur = self._enter()
+        check(lib().wh_task_set_lag(self.handle, arr, stream_ptr(self.stream)), "wh_task_set_lag")
+        cur.wait_stream(self.stream)
 
     @property
     def position(self) -> int:

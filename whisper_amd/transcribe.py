@@ -17,7 +17,9 @@ import torch
 import tqdm
 
 from .audio import FRAMES_PER_SECOND, HOP_LENGTH, N_FRAMES, N_SAMPLES, SAMPLE_RATE, log_mel_spectrogram, pad_or_trim
-from .decoding import DecodingOptions, DecodingResult
+from dataclasses import replace
+
+from .decoding import DecodingOptions, DecodingResult, DecodingTask
 from .timing import add_word_timestamps
 from .tokenizer import LANGUAGES, get_tokenizer
 from .utils import exact_div, format_timestamp, get_end, make_safe
@@ -372,27 +374,41 @@ def transcribe(
 
 
 def _options_key(opts: dict):
-    """hashable identity of a DecodingOptions kwargs dict: windows may share one batched decode only if every
-    option — including the prompt tokens — is the same (DecodingTask builds ONE initial token sequence per call,
-    reference decoding.py:719)"""
+    """hashable identity of a DecodingOptions kwargs dict without its prompt: windows may share one batched decode
+    only if every other option is the same (the prompts go to DecodingTask as one token list per row)"""
     def freeze(v):
         if isinstance(v, (list, tuple)):
             return tuple(freeze(x) for x in v)
         if isinstance(v, torch.Tensor):
             return tuple(v.flatten().tolist())
         return v
-    return tuple(sorted((k, freeze(v)) for k, v in opts.items()))
+    return tuple(sorted((k, freeze(v)) for k, v in opts.items() if k != "prompt"))
+
+
+def _prompt_batches(model: "Whisper", options: DecodingOptions, prompts: List[Optional[List[int]]], members: List[int],
+                    batch_size: int) -> List[List[int]]:
+    """split `members` (windows with the same options and the prompts `prompts[i]`) into batches one DecodingTask
+    can take: rows whose initial sequences have different lengths may share a call only in the fused greedy mode
+    and below its length limit (DecodingTask.ragged_limit); any rows of EQUAL length may always share one"""
+    probe = DecodingTask(model, options)
+    limit = probe.ragged_limit()
+    classes = {}
+    for i in members:
+        n = len(probe._get_initial_tokens(prompts[i]))
+        classes.setdefault("ragged" if limit is not None and n <= limit else n, []).append(i)
+    return [rows[at: at + batch_size] for rows in classes.values() for at in range(0, len(rows), batch_size)]
 
 
 def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, **kwargs) -> List[dict]:
     """Transcribe several files at once (no counterpart in the reference, which is strictly
     one file at a time).  Every file keeps its own seek / prompt / fallback state machine exactly as `transcribe`;
     the driver advances them in lock-step and decodes the windows that are pending at the same moment — and whose
-    decoding options, prompt included, are identical — as ONE batch of up to `batch_size` rows.  Results are the
-    same dicts `transcribe` returns, in input order.  Windows of one file stay sequential (seek and prompt depend on
-    the previous window); with `condition_on_previous_text=False` all files share their prompt and every round is
-    one batch.  A window whose batched result trips the temperature-fallback criteria is re-decoded on its own
-    from the next temperature, as the reference would."""
+    decoding options other than the prompt are identical — as batches of up to `batch_size` rows, each row
+    conditioned on its own file's previous text (`DecodingTask(..., prompts=...)`: rows of different prompt lengths
+    share a greedy call; beam search batches rows of equal prompt length).  Results are the same dicts `transcribe`
+    returns, in input order.  Windows of one file stay sequential (seek and prompt depend on the previous window).
+    A window whose batched result trips the temperature-fallback criteria is re-decoded on its own from the next
+    temperature, as the reference would."""
     names = ("verbose", "temperature", "compression_ratio_threshold", "logprob_threshold", "no_speech_threshold",
              "condition_on_previous_text", "initial_prompt", "carry_initial_prompt", "word_timestamps",
              "prepend_punctuations", "append_punctuations", "clip_timestamps", "hallucination_silence_threshold")
@@ -422,13 +438,15 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, **kwargs
             groups.setdefault(_options_key(workers[i].decode_options), []).append(i)
         answers = {}
         for members in groups.values():
-            for at in range(0, len(members), batch_size):
-                chunk = members[at: at + batch_size]
-                lead = workers[chunk[0]]
+            lead = workers[members[0]]
+            shared = replace(lead._options_for(lead.temperatures[0]), prompt=None)
+            prompts = {i: workers[i].decode_options.get("prompt") for i in members}
+            for chunk in _prompt_batches(model, shared, prompts, members, batch_size):
                 if len(chunk) == 1:
-                    answers[chunk[0]] = lead.decode_with_fallback(pending[chunk[0]])
+                    answers[chunk[0]] = workers[chunk[0]].decode_with_fallback(pending[chunk[0]])
                     continue
-                decoded = model.decode(torch.stack([pending[i] for i in chunk]), lead._options_for(lead.temperatures[0]))
+                decoded = model.decode(torch.stack([pending[i] for i in chunk]), shared,
+                                       prompts=[prompts[i] for i in chunk])
                 for i, result in zip(chunk, decoded):
                     if workers[i]._needs_retry(result) and len(workers[i].temperatures) > 1:
                         result = workers[i].decode_with_fallback(pending[i], first=1)
