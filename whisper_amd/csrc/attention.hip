@@ -332,7 +332,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int s = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
   const int S = a.splits;
-  const int Tk = a.d_len ? (*a.d_len + a.len_plus - (a.lag ? a.lag[r] : 0)) : a.Tk;
+  int Tk = a.Tk;
+  if (a.d_len) {                          // cached length and this row's lag: two independent scalar loads
+    const int n = load_uniform_int(a.d_len);
+    const int lg = load_uniform_int(a.lag ? a.lag + r : a.d_len);
+    Tk = n + a.len_plus - (a.lag ? lg : 0);
+  }
   int chunk = (Tk + S - 1) / S;
   chunk = (chunk + KPR - 1) / KPR * KPR;
   const int k0 = s * chunk;

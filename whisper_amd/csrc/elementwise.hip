@@ -109,7 +109,7 @@ __global__ void embed_kernel(const int64_t* __restrict__ tokens, int64_t stride,
   int64_t tok = tokens[(int64_t)r * stride + t];
   if (tok < 0) tok = 0;
   if (tok >= n_vocab) tok = n_vocab - 1;
-  const int p = *d_offset - (lag ? lag[r] : 0) + t;
+  const int p = load_uniform_int(d_offset) - (lag ? load_uniform_int(lag + r) : 0) + t;
   const T* e = emb + tok * D;
   const float* pp = pos + (int64_t)p * D;
   float* xr = x + (int64_t)row * D;

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
   const int es = tid / (NB * RT), er = (tid / NB) % RT, ej = tid % NB;
   const bool e_on = es < GS && er < R;
   float e_bias = 0.f, e_res = 0.f;
-  int e_lag = 0;                                   // EPI_QKV: this row's position lag (ragged prompts)
+  int e_lag = 0, e_pos = 0;                        // EPI_QKV: cache position and this row's lag (ragged prompts)
+  if (a.epi == whk::EPI_QKV) e_pos = load_uniform_int(a.d_pos);
   if (e_on && a.epi == whk::EPI_QKV && a.lag) e_lag = a.lag[r0 + er];
   if (e_on) {
     const int n = (g0 + es) * NB + ej;
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
             const int D = a.D;
             if (n < D) ((T*)a.y)[rr * a.y_ld + n] = from_f32<T>(v);
             else {
-              const int64_t pos = *a.d_pos - e_lag;
+              const int64_t pos = e_pos - e_lag;
               if (n < 2 * D) ((T*)a.kcache)[rr * a.cache_bs + pos * D + (n - D)] = from_f32<T>(v);
               else ((T*)a.vcache)[rr * a.cache_bs + pos * D + (n - 2 * D)] = from_f32<T>(v);
             }
