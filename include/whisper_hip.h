@@ -183,6 +183,27 @@ int wh_task_greedy(wh_task *t, const wh_greedy_params *p, int64_t *tokens, int64
                    int sot_index, int no_speech_token, float *sum_logprobs, float *no_speech_probs,
                    int32_t *n_tokens_out, void *stream);
 
+/*
+ * Fused beam search loop == DecodingTask._main_loop with BeamSearchDecoder (decoding.py:301-404) and the stock logit
+ * filters, run on the device without a per-step host sync: filters + log_softmax + top-(beam+1) per row, the candidate
+ * bookkeeping of every audio segment (stable descending order, first `beam` non-EOT sequences survive, EOT ones go
+ * to the segment's finished list up to max_candidates), the KV-cache permutation (rearrange_kv_cache, :172-176).
+ * The task must have been created with n_group == beam_size (2..8).
+ * tokens: int64 [2][n_rows][token_stride] device (token_stride >= sample_begin + max_steps + 1); [0] holds the initial
+ * tokens in columns [0, sample_begin) of every row and receives the live beams.  sum_logprobs: fp32 [n_rows] out.
+ * Finished sequences of segment b, in the order the reference's dict holds them: fin_tokens [n_audio][max_candidates]
+ * [token_stride], fin_len / fin_scores [n_audio][max_candidates], fin_count [n_audio] (all device).
+ * n_tokens_out (host): length of the live beams' rows.  BeamSearchDecoder.finalize (:384-404) stays with the caller.
+ */
+typedef struct wh_beam_params {
+  wh_greedy_params rules;        /* as for wh_task_greedy */
+  int32_t beam_size;             /* decoding.py:303 */
+  int32_t max_candidates;        /* round(beam_size * patience), decoding.py:313 */
+} wh_beam_params;
+int wh_task_beam(wh_task *t, const wh_beam_params *p, int64_t *tokens, int64_t token_stride, int sot_index,
+                 int no_speech_token, float *sum_logprobs, float *no_speech_probs, int64_t *fin_tokens,
+                 int32_t *fin_len, float *fin_scores, int32_t *fin_count, int32_t *n_tokens_out, void *stream);
+
 /* cross-attention QK of chosen heads for the cached positions — the `qk` captured by the hooks of
  * find_alignment (whisper/timing.py:186-197; model.py:130-137 manual path): for every pair
  * (layers[i], heads[i]) writes fp32 [n_tok][n_audio_ctx] = (q*scale)·(k*scale)ᵀ of row `row`.

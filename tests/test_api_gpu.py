@@ -322,3 +322,37 @@ def test_row_prompts_other_modes(setup, gpu_device):
         for i in range(3):
             want = whisper_amd.decode(model, mels[i], opts, prompt=ragged[i])
             assert got[i].language == want.language and got[i].tokens == want.tokens, i
+
+
+@pytest.mark.parametrize("kw", [dict(beam_size=4), dict(beam_size=2, patience=2.0), dict(beam_size=4, patience=0.5),
+                                dict(beam_size=5, without_timestamps=True), dict(beam_size=8)])
+def test_device_beam_search_equals_host_loop(setup, gpu_device, kw):
+    """wh_task_beam (filters + log_softmax + top-(beam+1) + BeamSearchDecoder.update + cache permutation on the device,
+    SURVEY.md §8f rank 2) against the host-driven loop (per-step wh_task_step, torch filters, the Python
+    BeamSearchDecoder checked against the reference in tests/test_host_logic.py), forced by a no-op user filter:
+    same tokens, same finished lists in the same order, same scores — for 3 segments decoded together, with patience
+    above and below 1 (max_candidates != beam_size) and runs that end by completion as well as by the step budget."""
+    from whisper_amd.decoding import DecodingTask, LogitFilter
+
+    class Noop(LogitFilter):
+        def apply(self, logits, tokens):
+            return None
+
+    key, dims, sd, model, mel = setup
+    mels = _prompted_mels(dims, gpu_device, 3)
+    for sample_len in (5, 24):
+        opts = whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=sample_len, **kw)
+        fused_task = DecodingTask(model, opts)
+        assert fused_task._fused_beam_ok()
+        fused = fused_task.run(mels)
+        host_task = DecodingTask(model, opts)
+        host_task.logit_filters.append(Noop())
+        assert not host_task._fused_beam_ok()
+        host = host_task.run(mels)
+        for a, (f, h) in enumerate(zip(fused, host)):
+            assert f.tokens == h.tokens, (sample_len, a)
+            assert abs(f.avg_logprob - h.avg_logprob) < 1e-5
+            assert abs(f.no_speech_prob - h.no_speech_prob) < 1e-6
+        ff, hf = fused_task.decoder.finished_sequences, host_task.decoder.finished_sequences
+        assert [list(d.keys()) for d in ff] == [list(d.keys()) for d in hf]
+        assert np.allclose([v for d in ff for v in d.values()], [v for d in hf for v in d.values()], atol=1e-4)

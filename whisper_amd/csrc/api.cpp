@@ -278,6 +278,8 @@ struct wh_task {
   bool lag_on;
   int64_t* step_tokens;
   float* samp_part;        // greedy sampler stage-1 partials
+  void* beam_scratch;      // beam search partials / candidates (G > 1)
+  int* beam_flags;         // [2][B] completion flags + [1] applied-update counter
   void* qcap;              // [L][R*Tcap][D] captured cross-attention queries
   int cross_splits, self_splits;
   size_t total;
@@ -326,6 +328,8 @@ static void task_carve(wh_task* t, void* base) {
   t->d_lag = (int*)c.take(R * 4);
   t->step_tokens = (int64_t*)c.take(R * 8);
   t->samp_part = (float*)c.take(greedy_sample_scratch_bytes((int)R, (int)V));
+  t->beam_scratch = t->G > 1 ? c.take(beam_scratch_bytes((int)R, (int)V)) : nullptr;
+  t->beam_flags = t->G > 1 ? (int*)c.take((2 * (size_t)t->B + 1) * 4) : nullptr;
   t->qcap = (t->flags & WH_TASK_CAPTURE_Q) ? c.take(L * R * C * D * es) : nullptr;
   t->total = align_up(c.off, 256);
 }
@@ -804,6 +808,91 @@ extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* to
   int final_len = alive + 2;
   if (final_len > ntok) final_len = ntok;
   *n_tokens_out = final_len;
+  return WH_OK;
+}
+
+// ---- fused beam search loop --------------------------------------------------------------------------
+extern "C" int wh_task_beam(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int64_t token_stride, int sot_index,
+                            int no_speech_token, float* sum_logprobs, float* no_speech_probs, int64_t* fin_tokens,
+                            int32_t* fin_len, float* fin_scores, int32_t* fin_count, int32_t* n_tokens_out,
+                            void* stream_) {
+  if (!t || !bp || !tokens || !sum_logprobs || !fin_tokens || !fin_len || !fin_scores || !fin_count || !n_tokens_out)
+    return WH_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream_;
+  const wh_greedy_params* p = &bp->rules;
+  const wh_dims& d = t->m->d;
+  const int V = d.n_vocab, R = t->R, B = t->B, G = t->G, T0 = p->sample_begin;
+  if (G < 2 || G > 8 || bp->beam_size != G || bp->max_candidates < 1 || !t->beam_scratch) return WH_ERR_ARG;
+  if (t->pos != 0 || T0 <= 0 || T0 > t->Tmax || p->max_steps <= 0 || t->lag_on) return WH_ERR_ARG;
+  if (token_stride < (int64_t)T0 + p->max_steps + 1) return WH_ERR_ARG;
+
+  int32_t sel[2]; int n_sel;
+  const bool want_ns = no_speech_token >= 0 && no_speech_probs != nullptr;
+  if (want_ns && sot_index != T0 - 1) { sel[0] = sot_index; sel[1] = T0 - 1; n_sel = 2; }
+  else { sel[0] = T0 - 1; n_sel = 1; }
+  int rc = prefill_impl(t, tokens, token_stride, T0, sel, n_sel, t->logits, V, s);
+  if (rc != WH_OK) return rc;
+  if (want_ns) HIPCHK(launch_no_speech(t->logits, (int64_t)n_sel * V, R, V, no_speech_token, no_speech_probs, s));
+  HIPCHK(hipMemsetAsync(sum_logprobs, 0, (size_t)R * 4, s));
+  HIPCHK(hipMemsetAsync(fin_count, 0, (size_t)B * 4, s));
+  HIPCHK(hipMemsetAsync(t->beam_flags, 0, (2 * (size_t)B + 1) * 4, s));
+
+  int64_t* buf[2] = {tokens, tokens + (int64_t)R * token_stride};
+  int* done[2] = {t->beam_flags, t->beam_flags + B};
+  int* d_applied = t->beam_flags + 2 * B;
+  BeamArgs a; memset(&a, 0, sizeof(a));
+  a.R = R; a.V = V; a.G = G; a.K = G + 1; a.token_stride = token_stride; a.d_ntok = t->d_pos;
+  a.sample_begin = T0; a.eot = p->eot; a.timestamp_begin = p->timestamp_begin; a.no_timestamps = p->no_timestamps;
+  a.max_initial_ts = p->max_initial_timestamp_index; a.suppress_blank = p->suppress_blank;
+  a.blank_token = p->blank_token; a.suppress_mask = p->suppress_mask; a.sum_logprobs = sum_logprobs;
+  beam_scratch_carve(a, t->beam_scratch, R, V);
+  a.fin_tok = fin_tokens; a.fin_len = fin_len; a.fin_score = fin_scores; a.fin_count = fin_count;
+  a.max_candidates = bp->max_candidates;
+  a.src = t->d_src; a.step_tokens = t->step_tokens; a.d_applied = d_applied;
+
+  const size_t es = t->m->esize;
+  const int64_t row_bytes = (int64_t)d.n_text_ctx * d.n_text_state * es;
+  int cur = 0;
+  auto update = [&](const float* logits, int64_t logits_ld, int first) -> int {
+    a.logits = logits; a.logits_ld = logits_ld; a.first = first;
+    a.tokens_in = buf[cur]; a.tokens_out = buf[cur ^ 1];
+    a.done_prev = done[cur]; a.done_next = done[cur ^ 1];
+    HIPCHK(launch_beam_step(a, B, s));
+    cur ^= 1;
+    // rearrange_kv_cache (decoding.py:172-176): new beam i continues the cache of row src[i]
+    HIPCHK(launch_permute_groups(t->self_k, t->self_v, d.n_text_layer, (int64_t)R * row_bytes, B, G, row_bytes,
+                                 (int64_t)t->pos * d.n_text_state * es, t->d_src, s));
+    return WH_OK;
+  };
+
+  rc = update(t->logits + (size_t)(n_sel - 1) * V, (int64_t)n_sel * V, 1);
+  if (rc != WH_OK) return rc;
+  int ntok = T0 + 1, steps = 1;
+  std::vector<int> flags((size_t)B);
+  auto all_done = [&]() -> int {       // 1 / 0, or -1 after a HIP error
+    hipError_t e = hipMemcpyAsync(flags.data(), done[cur], (size_t)B * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { g_last_hip = e; return -1; }
+    for (int b = 0; b < B; ++b) if (!flags[b]) return 0;
+    return 1;
+  };
+  while (steps < p->max_steps && ntok <= p->n_ctx && ntok <= d.n_text_ctx) {
+    rc = step_run(t, s);
+    if (rc != WH_OK) return rc;
+    rc = update(t->logits, V, 0);
+    if (rc != WH_OK) return rc;
+    ++ntok; ++steps;
+    if ((steps & 7) == 0) {
+      const int fin = all_done();
+      if (fin < 0) return WH_ERR_HIP;
+      if (fin) break;
+    }
+  }
+  int applied = 0;
+  HIPCHK(hipMemcpyAsync(&applied, d_applied, 4, hipMemcpyDeviceToHost, s));
+  if (cur == 1) HIPCHK(hipMemcpyAsync(buf[0], buf[1], (size_t)R * token_stride * 8, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  *n_tokens_out = T0 + applied;
   return WH_OK;
 }
 

@@ -334,9 +334,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArg
   const int S = a.splits;
   int Tk = a.Tk;
   if (a.d_len) {                          // cached length and this row's lag: two independent scalar loads
-    const int n = load_uniform_int(a.d_len);
-    const int lg = load_uniform_int(a.lag ? a.lag + r : a.d_len);
-    Tk = n + a.len_plus - (a.lag ? lg : 0);
+    const int vn = load_agent_int(a.d_len);
+    const int vl = load_agent_int(a.lag ? a.lag + r : a.d_len);
+    Tk = uniform(vn) + a.len_plus - (a.lag ? uniform(vl) : 0);
   }
   int chunk = (Tk + S - 1) / S;
   chunk = (chunk + KPR - 1) / KPR * KPR;

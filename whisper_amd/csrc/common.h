@@ -152,12 +152,16 @@ __device__ __forceinline__ float ordered_to_float(int i) {
 // into the block that first uses it, and every such block costs one more serialized round trip to the (cold)
 // kernarg segment — ~0.2-0.5 us each on a launch chain of 5-12 us kernels.  Naming every dword as an SGPR input of
 // an empty asm in the entry block keeps all the loads there, behind a single s_waitcnt.
-// A workgroup-uniform int written by an EARLIER kernel (the position counter, a row's lag): read through the
-// constant address space so that it is one s_load on the scalar cache — independent loads issue back to back —
-// instead of a vector global_load + readfirstlane per value.  Never use it on memory this kernel writes.
-__device__ __forceinline__ int load_uniform_int(const int* p) {
-  return *(const __attribute__((address_space(4))) int*)(p);
+// A workgroup-uniform int written by an EARLIER kernel (the position counter, a row's lag).  Read at agent scope, i.e.
+// from L2: a scalar load through the constant address space is faster, but the scalar cache is not invalidated between
+// back-to-back launches of one stream — a kernel that s_loaded the counter before it was bumped leaves a stale line
+// behind (seen on the GPU: the first beam-search update read position 0 after the prefill's add).  Independent loads
+// still issue back to back; the value lands in an SGPR.
+__device__ __forceinline__ int load_agent_int(const int* p) {       // per-lane value; issue several, then uniform()
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int load_uniform_int(const int* p) { return uniform(load_agent_int(p)); }
 
 template <typename A>
 __device__ __forceinline__ void pin_kernargs(const A& a) {

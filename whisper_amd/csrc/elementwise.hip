@@ -109,7 +109,8 @@ __global__ void embed_kernel(const int64_t* __restrict__ tokens, int64_t stride,
   int64_t tok = tokens[(int64_t)r * stride + t];
   if (tok < 0) tok = 0;
   if (tok >= n_vocab) tok = n_vocab - 1;
-  const int p = load_uniform_int(d_offset) - (lag ? load_uniform_int(lag + r) : 0) + t;
+  const int vo = load_agent_int(d_offset), vl = load_agent_int(lag ? lag + r : d_offset);
+  const int p = uniform(vo) - (lag ? uniform(vl) : 0) + t;
   const T* e = emb + tok * D;
   const float* pp = pos + (int64_t)p * D;
   float* xr = x + (int64_t)row * D;
@@ -166,6 +167,10 @@ __global__ __launch_bounds__(256) void permute_group_kernel(uint4v* __restrict__
   int src[GMAX];
 #pragma unroll
   for (int g = 0; g < GMAX; ++g) src[g] = g < G ? src_idx[audio * G + g] - audio * G : 0;
+  bool identity = true;
+#pragma unroll
+  for (int g = 0; g < GMAX; ++g) identity = identity && (g >= G || src[g] == g);
+  if (identity) return;                     // nothing moves in this segment (uniform: decided from src_idx alone)
   for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < used_units; u += (int64_t)gridDim.x * 256) {
     uint4v val[GMAX];
 #pragma unroll

@@ -147,6 +147,31 @@ hipError_t launch_no_speech(const float* logits_row0, int64_t row_stride, int R,
 // dst[r] = src[r*stride]
 hipError_t launch_gather_tokens(const int64_t* src, int64_t stride, int R, int64_t* dst, hipStream_t stream);
 
+// ---- beam.hip -------------------------------------------------------------------------------
+constexpr int BEAM_KMAX = 9;   // candidates per row = beam + 1, beam <= 8
+struct BeamArgs {
+  const float* logits; int64_t logits_ld;   // row r at logits + r*logits_ld, V entries
+  int R, V, G, K;                           // rows = segments x G beams; K = G + 1
+  const int64_t* tokens_in; int64_t* tokens_out; int64_t token_stride;   // [R][stride] each; rows hold *d_ntok tokens
+  const int* d_ntok;
+  int sample_begin, eot, timestamp_begin, no_timestamps, max_initial_ts, suppress_blank, blank_token;
+  const uint8_t* suppress_mask;
+  float* sum_logprobs;                      // [R] in/out
+  float* part_stat; float* part_val; int* part_idx;   // scratch (beam_scratch_carve)
+  float* cand_lp; int* cand_tok;            // [R][BEAM_KMAX] top-K log-probabilities / tokens of every row
+  int64_t* fin_tok; int* fin_len; float* fin_score; int* fin_count;   // [B][max_candidates][stride], [B][mc], [B][mc], [B]
+  int max_candidates;
+  int* src;                                 // [R] out: row whose KV cache the new beam continues
+  int64_t* step_tokens;                     // [R] out: next step's input tokens
+  const int* done_prev; int* done_next;     // [B] completion flags written by the previous / this update
+  int* d_applied;                           // number of updates applied (not frozen)
+  int first;                                // 1: first update — all beams of a segment hold the same prefix
+};
+size_t beam_scratch_bytes(int R, int V);
+void beam_scratch_carve(BeamArgs& a, void* base, int R, int V);
+// filters + log_softmax + top-(G+1) of every row, then the candidate bookkeeping of every segment (3 launches)
+hipError_t launch_beam_step(const BeamArgs& a, int B, hipStream_t stream);
+
 // ---- timing.hip ----------------------------------------------------------------------------
 hipError_t launch_median_filter(const float* x, float* out, int64_t rows, int n, int width,
                                 hipStream_t stream);

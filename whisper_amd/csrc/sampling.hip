@@ -60,8 +60,9 @@ __global__ __launch_bounds__(256) void greedy_partial_kernel(whk::SampleArgs a) 
     const int v = c * SCHUNK + j * 256 + tid;
     xv[j] = v < a.V ? x[v] : WH_NEG_INF;
   }
-  const int lag = a.lag ? load_uniform_int(a.lag + k) : 0;  // ragged prompts: this row's indices sit lag earlier than the longest row's
-  const int ntok = load_uniform_int(a.d_ntok) - lag;
+  const int vl = load_agent_int(a.lag ? a.lag + k : a.d_ntok), vn = load_agent_int(a.d_ntok);
+  const int lag = a.lag ? uniform(vl) : 0;   // ragged prompts: this row's indices sit lag earlier than the longest row's
+  const int ntok = uniform(vn) - lag;
   const int sample_begin = a.sample_begin - lag;
   const int64_t* row = a.tokens + (int64_t)k * a.token_stride;
   const int L = ntok - sample_begin;
@@ -136,8 +137,9 @@ __global__ __launch_bounds__(256) void greedy_final_kernel(whk::SampleArgs a, in
   __shared__ int sh_i[2][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k = blockIdx.x;
-  const int lag = a.lag ? load_uniform_int(a.lag + k) : 0;
-  const int ntok = load_uniform_int(a.d_ntok) - lag;
+  const int vl = load_agent_int(a.lag ? a.lag + k : a.d_ntok), vn = load_agent_int(a.d_ntok);
+  const int lag = a.lag ? uniform(vl) : 0;
+  const int ntok = uniform(vn) - lag;
   int64_t* row = a.tokens + (int64_t)k * a.token_stride;
   const bool ts_rules = a.timestamp_begin >= 0;
   Stat st[2];

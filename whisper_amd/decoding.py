@@ -530,6 +530,54 @@ class DecodingTask:
                 and all(type(f) in (SuppressBlank, SuppressTokens, ApplyTimestampRules) for f in self.logit_filters)
                 and self.sample_begin + self.sample_len <= 2 * self.n_ctx)
 
+    def _fused_beam_ok(self) -> bool:
+        """device-side beam search (wh_task_beam): stock decoder / filters / inference, 2..8 beams, rows of equal length"""
+        return (type(self.decoder) is BeamSearchDecoder and self.options.beam_size == self.n_group
+                and 2 <= self.n_group <= 8 and type(self.inference) is HipInference
+                and self.logit_filters == self._stock_filters
+                and all(type(f) in (SuppressBlank, SuppressTokens, ApplyTimestampRules) for f in self.logit_filters)
+                and not self._ragged())
+
+    def _sampling_rules(self, T0: int, dev) -> Tuple["hip.GreedyParams", Tensor]:
+        """the stock logit filters as the parameter block of the device-side loops (the mask tensor must stay alive)"""
+        tk = self.tokenizer
+        mask = torch.zeros(self.model.dims.n_vocab, dtype=torch.uint8)
+        if self._suppress:
+            mask[list(self._suppress)] = 1
+        mask = mask.to(dev)
+        with_ts = not self.options.without_timestamps
+        params = hip.GreedyParams(
+            sample_begin=T0, max_steps=self.sample_len, n_ctx=self.n_ctx, eot=tk.eot,
+            timestamp_begin=tk.timestamp_begin if with_ts else -1,
+            no_timestamps=tk.no_timestamps if tk.no_timestamps is not None else -1,
+            max_initial_timestamp_index=self._max_initial_ts if self._max_initial_ts is not None else -1,
+            suppress_blank=int(bool(self.options.suppress_blank)), blank_token=tk.encode(" ")[0],
+            suppress_mask=mask.data_ptr())
+        return params, mask
+
+    def _main_loop_beam_fused(self, audio_features: Tensor, tokens: Tensor):
+        """BeamSearchDecoder.update for every step on the device; leaves the decoder's finished_sequences as the
+        host loop would (same dict order) for finalize()"""
+        tk = self.tokenizer
+        dev = audio_features.device
+        n_rows, T0 = tokens.shape
+        try:
+            task = self.inference._ensure_task(tokens, audio_features)
+            buf = torch.zeros(2, n_rows, T0 + self.sample_len + 1, dtype=torch.int64, device=dev)
+            buf[0, :, :T0] = tokens
+            rules, mask = self._sampling_rules(T0, dev)
+            params = hip.BeamParams(rules=rules, beam_size=self.n_group, max_candidates=self.decoder.max_candidates)
+            no_speech = tk.no_speech if tk.no_speech is not None else -1
+            n, sum_logprobs, nsp, (fin_tok, fin_len, fin_score, fin_count) = task.beam(buf, params, self.sot_index, no_speech)
+            no_speech_probs = nsp.tolist() if nsp is not None else [np.nan] * n_rows
+            fin_tok, fin_len, fin_score, fin_count = fin_tok.cpu(), fin_len.tolist(), fin_score.tolist(), fin_count.tolist()
+            self.decoder.finished_sequences = [
+                {tuple(fin_tok[a, i, : fin_len[a][i]].tolist()): fin_score[a][i] for i in range(fin_count[a])}
+                for a in range(n_rows // self.n_group)]
+            return buf[0, :, :n], sum_logprobs, no_speech_probs
+        finally:
+            self.inference.cleanup_caching()
+
     def _main_loop_fused(self, audio_features: Tensor, tokens: Tensor):
         tk = self.tokenizer
         dev = audio_features.device
@@ -538,18 +586,7 @@ class DecodingTask:
             task = self.inference._ensure_task(tokens, audio_features)
             buf = torch.zeros(n_rows, T0 + self.sample_len + 1, dtype=torch.int64, device=dev)
             buf[:, :T0] = tokens
-            mask = torch.zeros(self.model.dims.n_vocab, dtype=torch.uint8)
-            if self._suppress:
-                mask[list(self._suppress)] = 1
-            mask = mask.to(dev)
-            with_ts = not self.options.without_timestamps
-            params = hip.GreedyParams(
-                sample_begin=T0, max_steps=self.sample_len, n_ctx=self.n_ctx, eot=tk.eot,
-                timestamp_begin=tk.timestamp_begin if with_ts else -1,
-                no_timestamps=tk.no_timestamps if tk.no_timestamps is not None else -1,
-                max_initial_timestamp_index=self._max_initial_ts if self._max_initial_ts is not None else -1,
-                suppress_blank=int(bool(self.options.suppress_blank)), blank_token=tk.encode(" ")[0],
-                suppress_mask=mask.data_ptr())
+            params, mask = self._sampling_rules(T0, dev)
             no_speech = tk.no_speech if tk.no_speech is not None else -1
             ragged = self._ragged()
             if ragged:
@@ -586,6 +623,8 @@ class DecodingTask:
                                  f"+ sample_len ({self.sample_len}) exceeds n_text_ctx ({self.n_ctx})")
         if self._fused_greedy_ok(tokens):
             return self._main_loop_fused(audio_features, tokens)
+        if self._fused_beam_ok():
+            return self._main_loop_beam_fused(audio_features, tokens)
         n_batch = tokens.shape[0]
         sum_logprobs: Tensor = torch.zeros(n_batch, device=audio_features.device)
         no_speech_probs = [np.nan] * n_batch

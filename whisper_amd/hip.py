@@ -62,6 +62,10 @@ class GreedyParams(C.Structure):
     ]
 
 
+class BeamParams(C.Structure):
+    _fields_ = [("rules", GreedyParams), ("beam_size", C.c_int32), ("max_candidates", C.c_int32)]
+
+
 # name -> (restype, argtypes); also the list the CPU-only symbol test walks
 SIGNATURES = {
     "wh_abi_version": (C.c_int, []),
@@ -85,6 +89,9 @@ SIGNATURES = {
     "wh_task_position": (C.c_int, [C.c_void_p]),
     "wh_task_greedy": (C.c_int, [C.c_void_p, C.POINTER(GreedyParams), C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "wh_task_beam": (C.c_int, [C.c_void_p, C.POINTER(BeamParams), C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(C.c_int32), C.c_void_p]),
     "wh_task_cross_qk": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "wh_task_bench_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
@@ -436,6 +443,29 @@ class HipTask:
                                    stream_ptr(self.stream)), "wh_task_greedy")
         cur.wait_stream(self.stream)
         return n_out.value, sum_lp, nsp
+
+    def beam(self, tokens: torch.Tensor, params: BeamParams, sot_index: int, no_speech_token: int):
+        """tokens: int64 [2][n_rows][>= sample_begin + max_steps + 1], initial tokens in the first columns of [0].
+        Returns (n_tokens, sum_logprobs[n_rows], no_speech_probs[n_rows] | None, finished) where finished =
+        (tokens [n_audio][max_candidates][stride], lengths, scores [n_audio][max_candidates], counts [n_audio])."""
+        assert tokens.is_cuda and tokens.dtype == torch.int64 and tokens.dim() == 3 and tokens.is_contiguous()
+        assert tokens.shape[0] == 2 and tokens.shape[1] == self.n_rows
+        dev = tokens.device
+        n_audio, mc, stride = self.n_rows // params.beam_size, params.max_candidates, tokens.shape[2]
+        sum_lp = torch.empty(self.n_rows, dtype=torch.float32, device=dev)
+        nsp = torch.empty(self.n_rows, dtype=torch.float32, device=dev) if no_speech_token >= 0 else None
+        fin_tok = torch.zeros(n_audio, mc, stride, dtype=torch.int64, device=dev)
+        fin_len = torch.zeros(n_audio, mc, dtype=torch.int32, device=dev)
+        fin_score = torch.zeros(n_audio, mc, dtype=torch.float32, device=dev)
+        fin_count = torch.zeros(n_audio, dtype=torch.int32, device=dev)
+        n_out = C.c_int32(0)
+        cur = self._enter()
+        check(lib().wh_task_beam(self.handle, C.byref(params), tokens.data_ptr(), stride, sot_index, no_speech_token,
+                                 sum_lp.data_ptr(), _ptr(nsp), fin_tok.data_ptr(), fin_len.data_ptr(),
+                                 fin_score.data_ptr(), fin_count.data_ptr(), C.byref(n_out),
+                                 stream_ptr(self.stream)), "wh_task_beam")
+        cur.wait_stream(self.stream)
+        return n_out.value, sum_lp, nsp, (fin_tok, fin_len, fin_score, fin_count)
 
     def bench_kernel(self, kind: int, iters: int) -> Tuple[float, float]:
         """(average ms per launch measured with HIP events on the launch stream, algorithmic bytes per launch)"""
