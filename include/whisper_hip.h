@@ -157,9 +157,10 @@ int wh_task_set_lag(wh_task *t, const int32_t *lag, void *stream);
 int wh_task_position(const wh_task *t);
 
 /*
- * Fused greedy sampling loop == DecodingTask._main_loop with GreedyDecoder(temperature=0) and the
- * SuppressBlank / SuppressTokens / ApplyTimestampRules filters (decoding.py:272-298, 423-505, 680-710),
- * run entirely on the device (no per-step host sync).
+ * Fused sampling loop == DecodingTask._main_loop with GreedyDecoder (arg-max at temperature 0, otherwise one
+ * categorical draw per row and step) and the SuppressBlank / SuppressTokens / ApplyTimestampRules filters
+ * (decoding.py:272-298, 423-505, 680-710), run entirely on the device (no per-step host sync).  Rows are independent:
+ * a task created with n_group = best_of decodes best_of samples per audio segment.
  */
 typedef struct wh_greedy_params {
   int32_t sample_begin;          /* len(initial_tokens), decoding.py:536 */
@@ -172,6 +173,11 @@ typedef struct wh_greedy_params {
   int32_t suppress_blank;        /* 0/1, decoding.py:555-556 */
   int32_t blank_token;           /* tokenizer.encode(" ")[0] */
   const uint8_t *suppress_mask;  /* device [n_vocab] bytes: 1 = token in SuppressTokens list */
+  float temperature;             /* 0: arg-max (decoding.py:278-279); > 0: Categorical(logits / temperature).sample()
+                                    (:281-283) drawn on the device by Gumbel-max with counter-based noise — the same
+                                    distribution, not torch's random stream; wh_task_greedy only */
+  uint32_t reserved;
+  uint64_t seed;                 /* noise key of this call (temperature > 0) */
 } wh_greedy_params;
 /*
  * tokens: int64 [n_rows][token_stride] device, columns [0,sample_begin) hold the initial tokens; the

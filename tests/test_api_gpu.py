@@ -237,7 +237,7 @@ def test_transcribe_batch_equals_sequential(setup, cond):
 
 def test_temperature_fallback_runs_sampling_path(setup):
     """transcribe.py:184-224: a window whose greedy result trips the log-prob threshold is re-decoded at the next
-    temperature through the generic (host-driven, Categorical) loop; best_of > 1 exercises the grouped rows."""
+    temperature (sampling, drawn on the device); best_of > 1 exercises the grouped rows."""
     key, dims, sd, model, mel = setup
     torch.manual_seed(0)
     r = model.transcribe(audio(41, 200000), temperature=(0.0, 0.5), logprob_threshold=0.0, fp16=False, language="en",
@@ -356,3 +356,57 @@ def test_device_beam_search_equals_host_loop(setup, gpu_device, kw):
         ff, hf = fused_task.decoder.finished_sequences, host_task.decoder.finished_sequences
         assert [list(d.keys()) for d in ff] == [list(d.keys()) for d in hf]
         assert np.allclose([v for d in ff for v in d.values()], [v for d in hf for v in d.values()], atol=1e-4)
+
+
+def test_device_sampling(setup, gpu_device):
+    """Temperature sampling inside the fused loop (GreedyDecoder.update at T > 0, decoding.py:281-293; SURVEY.md §8f
+    rank 2).  The reference draws from torch's generator, so parity is distributional:
+    (a) T -> 0 reproduces the arg-max decode exactly, with the same log-probabilities;
+    (b) same torch seed -> same tokens, other seed -> other tokens;
+    (c) the accumulated log-probability of a drawn token is log_softmax(filtered logits)[token], UNSCALED by T;
+    (d) over 384 draws of the first token, the mean of log p_T(token) sits within 5 standard errors of its
+        expectation under p_T = softmax(filtered logits / T) computed on the host with the torch filters."""
+    import torch.nn.functional as F
+    from whisper_amd.decoding import DecodingTask
+    key, dims, sd, model, mel = setup
+    greedy = whisper_amd.decode(model, mel, whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=16))
+    cold = whisper_amd.decode(model, mel, whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=16, temperature=1e-6))
+    assert cold.tokens == greedy.tokens and abs(cold.avg_logprob - greedy.avg_logprob) < 1e-4
+
+    opts = whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=12, temperature=0.9, best_of=4)
+    torch.manual_seed(11); a = whisper_amd.decode(model, mel, opts)
+    torch.manual_seed(11); b = whisper_amd.decode(model, mel, opts)
+    torch.manual_seed(12); c = whisper_amd.decode(model, mel, opts)
+    assert a.tokens == b.tokens and a.avg_logprob == b.avg_logprob
+    assert a.tokens != c.tokens
+    assert np.isfinite(a.avg_logprob) and a.temperature == 0.9
+
+    for T in (1.0, 0.5):
+        opts = whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=1, temperature=T, best_of=8)
+        probe = DecodingTask(model, opts)
+        assert probe._fused_greedy_ok(None)
+        feats = probe._get_audio_features(mel[None])
+        rows = torch.tensor([probe.initial_tokens]).repeat(8, 1).to(gpu_device)
+        logits = probe.inference.logits(rows, feats)[:, -1].clone()
+        probe.inference.cleanup_caching()
+        for f in probe.logit_filters:
+            f.apply(logits, rows)
+        lp1 = F.log_softmax(logits[0].float(), -1).cpu()            # unscaled: what sum_logprobs accumulates
+        lpT = F.log_softmax(logits[0].float() / T, -1).cpu()        # the distribution that is sampled
+        pT = lpT.exp()
+        finite = torch.isfinite(lpT)
+        mean = float((pT[finite] * lpT[finite]).sum())
+        var = float((pT[finite] * (lpT[finite] - mean) ** 2).sum())
+        draws = []
+        torch.manual_seed(100 + int(T * 10))
+        for _ in range(48):
+            task = DecodingTask(model, opts)
+            toks, sums, _ = task._main_loop(feats, rows.clone())
+            assert toks.shape == (8, rows.shape[1] + 1)
+            for tkn, s in zip(toks[:, -1].tolist(), sums.tolist()):
+                assert torch.isfinite(lpT[tkn]), tkn                  # never a filtered token
+                assert abs(s - float(lp1[tkn])) < 2e-4                # (c)
+                draws.append(float(lpT[tkn]))
+        n = len(draws)
+        assert n == 384 and len(set(draws)) > 8
+        assert abs(np.mean(draws) - mean) < 5.0 * np.sqrt(var / n) + 1e-3, (T, np.mean(draws), mean, var)

@@ -207,7 +207,8 @@ def test_row_prompts_setup_matches_reference_per_row(ref):
     with pytest.raises(ValueError):
         mine.DecodingTask(model, mine.DecodingOptions(language="en", prompt=[3]), prompts=prompts)
     assert mine.DecodingTask(model, mine.DecodingOptions(language="en", beam_size=2), prompts=prompts).ragged_limit() is None
-    assert mine.DecodingTask(model, mine.DecodingOptions(language="en", temperature=0.4), prompts=prompts).ragged_limit() is None
+    assert mine.DecodingTask(model, mine.DecodingOptions(language="en", temperature=0.4, best_of=3),
+                             prompts=prompts).ragged_limit() == 448 - 224       # sampling runs on the device too
     by_index = dict(enumerate(prompts))
     members = list(by_index)
     # greedy: everything below the limit shares one ragged class; the saturated prompt (227 initial tokens) is alone

@@ -783,6 +783,10 @@ extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* to
   sa.max_initial_ts = p->max_initial_timestamp_index; sa.suppress_blank = p->suppress_blank;
   sa.blank_token = p->blank_token; sa.suppress_mask = p->suppress_mask; sa.sum_logprobs = sum_logprobs;
   sa.step_tokens = t->step_tokens; sa.d_alive_step = t->d_alive; sa.partials = t->samp_part;
+  if (p->temperature > 0.f) {
+    sa.inv_temperature = 1.0f / p->temperature;
+    sa.seed_lo = (uint32_t)(p->seed & 0xffffffffu); sa.seed_hi = (uint32_t)(p->seed >> 32);
+  }
 
   sa.logits = t->logits + (size_t)(n_sel - 1) * V; sa.logits_ld = (int64_t)n_sel * V;
   HIPCHK(launch_greedy_sample(sa, s));

@@ -139,6 +139,8 @@ struct SampleArgs {
   int64_t* step_tokens;       // [R] next-step input tokens (may be null)
   int* d_alive_step;          // device: set to ntok by every row whose sampled token is not EOT
   float* partials;            // scratch: greedy_sample_scratch_bytes(R, V)
+  float inv_temperature;      // 0: arg-max; > 0: sample from softmax(logits / T) (Gumbel-max, counter-based noise)
+  uint32_t seed_lo, seed_hi;
 };
 size_t greedy_sample_scratch_bytes(int R, int V);
 hipError_t launch_greedy_sample(const SampleArgs& a, hipStream_t stream);

@@ -43,14 +43,50 @@ __device__ __forceinline__ void stat_wave_reduce(Stat& a) {
 
 constexpr int SCHUNK = 1024;    // vocabulary entries per stage-1 workgroup (256 threads x 4)
 
+// Temperature sampling (GreedyDecoder.update at temperature > 0, decoding.py:281-283: Categorical(logits / T).sample())
+// as a Gumbel-max draw: argmax over the filtered entries of x / T + g, g = -log(-log(u)), u from a counter-based hash of
+// (seed, step, row, token) — one uniform per entry, no state, the same partial / final kernel structure as the arg-max.
+// The log-probability that is accumulated is the one of the UNSCALED filtered logits (decoding.py:285-287).
+struct Pick {           // best perturbed key of a range: key, the entry's logit, its index
+  float key, x; int idx;
+};
+__device__ __forceinline__ void pick_merge(Pick& a, float key, float x, int idx) {
+  if (idx == 0x7fffffff) return;
+  if (a.idx == 0x7fffffff || key > a.key || (key == a.key && idx < a.idx)) { a.key = key; a.x = x; a.idx = idx; }
+}
+__device__ __forceinline__ void pick_wave_reduce(Pick& a) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float key = __shfl_xor(a.key, o, 64);
+    const float x = __shfl_xor(a.x, o, 64);
+    const int idx = __shfl_xor(a.idx, o, 64);
+    pick_merge(a, key, x, idx);
+  }
+}
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+// standard Gumbel noise for (seed, step, row, token); 24-bit uniform strictly inside (0, 1)
+__device__ __forceinline__ float gumbel(uint32_t seed_lo, uint32_t seed_hi, int step, int row, int v) {
+  uint32_t h = fmix32((uint32_t)row * 0x9E3779B1u + (uint32_t)step) ^ seed_lo;
+  h = fmix32(h ^ (uint32_t)v * 0x85EBCA77u);
+  h = fmix32(h + seed_hi);
+  const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  return -logf(-logf(u));
+}
+constexpr int PSTRIDE = 8;      // floats per (row, chunk, range) partial: m, s, idx | key, x (sampling)
+
 // Stage 1: grid (chunks, rows).  Applies the filters to one 1024-entry slice of the row and reduces it
 // to two partial statistics (text range, timestamp range): {max, sum exp(x - max), first arg-max}.
 // All four logits of a thread are requested before any is used (one L2 round trip per workgroup).
+template <bool SAMPLE>
 __global__ __launch_bounds__(256) void greedy_partial_kernel(whk::SampleArgs a) {
   pin_kernargs(a);
   __shared__ int sh_last_ts;
   __shared__ float sh_m[2][4], sh_s[2][4];
   __shared__ int sh_i[2][4];
+  __shared__ float sh_k[2][4], sh_x[2][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = blockIdx.x, k = blockIdx.y;
   const float* x = a.logits + (int64_t)k * a.logits_ld;
@@ -93,6 +129,10 @@ __global__ __launch_bounds__(256) void greedy_partial_kernel(whk::SampleArgs a) 
   Stat st[2];
   st[0] = Stat{WH_NEG_INF, 0.f, 0x7fffffff};
   st[1] = Stat{WH_NEG_INF, 0.f, 0x7fffffff};
+  Pick pk[2];
+  pk[0] = Pick{WH_NEG_INF, WH_NEG_INF, 0x7fffffff};
+  pk[1] = pk[0];
+  const int step = ntok + lag;             // the common position counter: the same for every row of a step
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int v = c * SCHUNK + j * 256 + tid;
@@ -113,28 +153,49 @@ __global__ __launch_bounds__(256) void greedy_partial_kernel(whk::SampleArgs a) 
     }
     if (masked) continue;
     if (v < split) stat_add(st[0], xv[j], v); else stat_add(st[1], xv[j], v);
+    if constexpr (SAMPLE) {
+      if (xv[j] != WH_NEG_INF) {
+        const float key = xv[j] * a.inv_temperature + gumbel(a.seed_lo, a.seed_hi, step, k, v);
+        pick_merge(pk[v < split ? 0 : 1], key, xv[j], v);
+      }
+    }
   }
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     stat_wave_reduce(st[g]);
-    if (lane == 0) { sh_m[g][wave] = st[g].m; sh_s[g][wave] = st[g].s; sh_i[g][wave] = st[g].idx; }
+    if constexpr (SAMPLE) pick_wave_reduce(pk[g]);
+    if (lane == 0) {
+      sh_m[g][wave] = st[g].m; sh_s[g][wave] = st[g].s; sh_i[g][wave] = SAMPLE ? pk[g].idx : st[g].idx;
+      if constexpr (SAMPLE) { sh_k[g][wave] = pk[g].key; sh_x[g][wave] = pk[g].x; }
+    }
   }
   __syncthreads();
   if (tid < 2) {
     Stat t = Stat{WH_NEG_INF, 0.f, 0x7fffffff};
-    for (int w = 0; w < 4; ++w) stat_merge(t, sh_m[tid][w], sh_s[tid][w], sh_i[tid][w]);
-    float* o = a.partials + (((int64_t)k * gridDim.x + c) * 2 + tid) * 4;
-    o[0] = t.m; o[1] = t.s; o[2] = __int_as_float(t.idx);
+    float* o = a.partials + (((int64_t)k * gridDim.x + c) * 2 + tid) * PSTRIDE;
+    if constexpr (SAMPLE) {
+      Pick p = Pick{WH_NEG_INF, WH_NEG_INF, 0x7fffffff};
+      for (int w = 0; w < 4; ++w) {
+        stat_merge(t, sh_m[tid][w], sh_s[tid][w], 0);
+        pick_merge(p, sh_k[tid][w], sh_x[tid][w], sh_i[tid][w]);
+      }
+      o[0] = t.m; o[1] = t.s; o[2] = __int_as_float(p.idx); o[3] = p.key; o[4] = p.x;
+    } else {
+      for (int w = 0; w < 4; ++w) stat_merge(t, sh_m[tid][w], sh_s[tid][w], sh_i[tid][w]);
+      o[0] = t.m; o[1] = t.s; o[2] = __int_as_float(t.idx);
+    }
   }
 }
 
 // Stage 2: one workgroup per row merges the chunk partials, applies the "timestamp mass" rule and
 // GreedyDecoder.update, and appends the token.
+template <bool SAMPLE>
 __global__ __launch_bounds__(256) void greedy_final_kernel(whk::SampleArgs a, int nchunk) {
   pin_kernargs(a);
   asm volatile("" ::"s"(nchunk));
   __shared__ float sh_m[2][4], sh_s[2][4];
   __shared__ int sh_i[2][4];
+  __shared__ float sh_k[2][4], sh_x[2][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k = blockIdx.x;
   const int vl = load_agent_int(a.lag ? a.lag + k : a.d_ntok), vn = load_agent_int(a.d_ntok);
@@ -145,25 +206,42 @@ __global__ __launch_bounds__(256) void greedy_final_kernel(whk::SampleArgs a, in
   Stat st[2];
   st[0] = Stat{WH_NEG_INF, 0.f, 0x7fffffff};
   st[1] = Stat{WH_NEG_INF, 0.f, 0x7fffffff};
+  Pick pk[2];
+  pk[0] = Pick{WH_NEG_INF, WH_NEG_INF, 0x7fffffff};
+  pk[1] = pk[0];
   for (int c = tid; c < nchunk; c += 256) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      const float* o = a.partials + (((int64_t)k * nchunk + c) * 2 + g) * 4;
-      stat_merge(st[g], o[0], o[1], __float_as_int(o[2]));
+      const float* o = a.partials + (((int64_t)k * nchunk + c) * 2 + g) * PSTRIDE;
+      if constexpr (SAMPLE) {
+        stat_merge(st[g], o[0], o[1], 0);
+        pick_merge(pk[g], o[3], o[4], __float_as_int(o[2]));
+      } else {
+        stat_merge(st[g], o[0], o[1], __float_as_int(o[2]));
+      }
     }
   }
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     stat_wave_reduce(st[g]);
-    if (lane == 0) { sh_m[g][wave] = st[g].m; sh_s[g][wave] = st[g].s; sh_i[g][wave] = st[g].idx; }
+    if constexpr (SAMPLE) pick_wave_reduce(pk[g]);
+    if (lane == 0) {
+      sh_m[g][wave] = st[g].m; sh_s[g][wave] = st[g].s; sh_i[g][wave] = SAMPLE ? pk[g].idx : st[g].idx;
+      if constexpr (SAMPLE) { sh_k[g][wave] = pk[g].key; sh_x[g][wave] = pk[g].x; }
+    }
   }
   __syncthreads();
   if (tid == 0) {
     const int64_t last_tok = row[ntok - 1];
     Stat tx = Stat{WH_NEG_INF, 0.f, 0x7fffffff}, ts = tx;
+    Pick ptx = Pick{WH_NEG_INF, WH_NEG_INF, 0x7fffffff}, pts = ptx;
     for (int w = 0; w < 4; ++w) {
-      stat_merge(tx, sh_m[0][w], sh_s[0][w], sh_i[0][w]);
-      stat_merge(ts, sh_m[1][w], sh_s[1][w], sh_i[1][w]);
+      stat_merge(tx, sh_m[0][w], sh_s[0][w], SAMPLE ? 0 : sh_i[0][w]);
+      stat_merge(ts, sh_m[1][w], sh_s[1][w], SAMPLE ? 0 : sh_i[1][w]);
+      if constexpr (SAMPLE) {
+        pick_merge(ptx, sh_k[0][w], sh_x[0][w], sh_i[0][w]);
+        pick_merge(pts, sh_k[1][w], sh_x[1][w], sh_i[1][w]);
+      }
     }
     bool text_masked = false;
     if (ts_rules) {
@@ -183,6 +261,12 @@ __global__ __launch_bounds__(256) void greedy_final_kernel(whk::SampleArgs a, in
     int next = fin.idx;
     // log_softmax(filtered)[next] = x - max - log(sum exp(x - max)); x[next] == max
     float lp = -logf(fin.s);
+    if constexpr (SAMPLE) {                  // the Gumbel-max draw among the allowed entries; unscaled log-probability
+      Pick p = pts;
+      if (!text_masked) pick_merge(p, ptx.key, ptx.x, ptx.idx);
+      next = p.idx;
+      lp = (p.x - fin.m) - logf(fin.s);
+    }
     if (fin.m == WH_NEG_INF) { next = 0; lp = __builtin_nanf(""); }   // every logit filtered: argmax of all -inf
     if (last_tok != a.eot) a.sum_logprobs[k] += lp;
     else next = a.eot;
@@ -229,13 +313,18 @@ __global__ void gather_tokens_kernel(const int64_t* __restrict__ src, int64_t st
 
 namespace whk {
 
-size_t greedy_sample_scratch_bytes(int R, int V) { return (size_t)R * ((V + SCHUNK - 1) / SCHUNK) * 2 * 4 * sizeof(float); }
+size_t greedy_sample_scratch_bytes(int R, int V) { return (size_t)R * ((V + SCHUNK - 1) / SCHUNK) * 2 * PSTRIDE * sizeof(float); }
 
 hipError_t launch_greedy_sample(const SampleArgs& a, hipStream_t stream) {
   const int nchunk = (a.V + SCHUNK - 1) / SCHUNK;
   if (!a.partials) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(greedy_partial_kernel, dim3(nchunk, a.R), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(greedy_final_kernel, dim3(a.R), dim3(256), 0, stream, a, nchunk);
+  if (a.inv_temperature > 0.f) {
+    hipLaunchKernelGGL(greedy_partial_kernel<true>, dim3(nchunk, a.R), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(greedy_final_kernel<true>, dim3(a.R), dim3(256), 0, stream, a, nchunk);
+  } else {
+    hipLaunchKernelGGL(greedy_partial_kernel<false>, dim3(nchunk, a.R), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(greedy_final_kernel<false>, dim3(a.R), dim3(256), 0, stream, a, nchunk);
+  }
   return hipGetLastError();
 }
 

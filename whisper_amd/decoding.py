@@ -524,8 +524,11 @@ class DecodingTask:
 
     # -- sampling loops -------------------------------------------------------------------------------------
     def _fused_greedy_ok(self, tokens: Tensor) -> bool:
-        """device-side loop is exact for: temperature 0, no beams / best_of, stock filters and components"""
-        return (type(self.decoder) is GreedyDecoder and self.options.temperature == 0 and self.n_group == 1
+        """device-side loop (wh_task_greedy): stock decoder / filters / inference.  Temperature 0 is the exact arg-max
+        path; temperature > 0 (any best_of) draws every token on the device from the same categorical distribution
+        the reference samples with torch's generator."""
+        return (type(self.decoder) is GreedyDecoder and self.options.temperature >= 0
+                and (self.n_group == 1 or self.options.temperature > 0)
                 and type(self.inference) is HipInference and self.logit_filters == self._stock_filters
                 and all(type(f) in (SuppressBlank, SuppressTokens, ApplyTimestampRules) for f in self.logit_filters)
                 and self.sample_begin + self.sample_len <= 2 * self.n_ctx)
@@ -553,6 +556,9 @@ class DecodingTask:
             max_initial_timestamp_index=self._max_initial_ts if self._max_initial_ts is not None else -1,
             suppress_blank=int(bool(self.options.suppress_blank)), blank_token=tk.encode(" ")[0],
             suppress_mask=mask.data_ptr())
+        if type(self.decoder) is GreedyDecoder and self.options.temperature > 0:
+            params.temperature = float(self.options.temperature)
+            params.seed = int(torch.randint(0, 2 ** 62, (1,)).item())     # torch.manual_seed makes runs repeatable
         return params, mask
 
     def _main_loop_beam_fused(self, audio_features: Tensor, tokens: Tensor):
@@ -589,15 +595,16 @@ class DecodingTask:
             params, mask = self._sampling_rules(T0, dev)
             no_speech = tk.no_speech if tk.no_speech is not None else -1
             ragged = self._ragged()
+            row_lag = [lag for lag in self.row_lag for _ in range(self.n_group)] if ragged else None
             if ragged:
-                task.set_lag(self.row_lag)
+                task.set_lag(row_lag)
             n, sum_logprobs, nsp = task.greedy(buf, params, self.sot_index, no_speech)
             no_speech_probs = nsp.tolist() if nsp is not None else [np.nan] * n_rows
             if not ragged:
                 return buf[:, :n], sum_logprobs, no_speech_probs
             # row r holds n - lag tokens: right-align so that every row's sampled part starts at sample_begin
             out = torch.full((n_rows, n), tk.sot, dtype=torch.int64, device=dev)
-            for r, lag in enumerate(self.row_lag):
+            for r, lag in enumerate(row_lag):
                 out[r, lag:] = buf[r, : n - lag]
             return out, sum_logprobs, no_speech_probs
         finally:
@@ -616,8 +623,8 @@ class DecodingTask:
         if self._ragged():
             limit = self.ragged_limit()
             if limit is None:
-                raise ValueError("prompts of different lengths need greedy decoding (temperature 0, no beams / "
-                                 "best_of) with the stock logit filters")
+                raise ValueError("prompts of different lengths need the device-side greedy / sampling loop (no beam "
+                                 "search, stock logit filters)")
             if self.sample_begin > limit:
                 raise ValueError(f"prompts of different lengths: the longest initial sequence ({self.sample_begin}) "
                                  f"+ sample_len ({self.sample_len}) exceeds n_text_ctx ({self.n_ctx})")

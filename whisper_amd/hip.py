@@ -59,6 +59,7 @@ class GreedyParams(C.Structure):
         ("timestamp_begin", C.c_int32), ("no_timestamps", C.c_int32),
         ("max_initial_timestamp_index", C.c_int32), ("suppress_blank", C.c_int32),
         ("blank_token", C.c_int32), ("suppress_mask", C.c_void_p),
+        ("temperature", C.c_float), ("reserved", C.c_uint32), ("seed", C.c_uint64),
     ]
 
 
