@@ -245,6 +245,13 @@ def test_temperature_fallback_runs_sampling_path(setup):
     assert len(r["segments"]) >= 1
     assert all(s["temperature"] == 0.5 for s in r["segments"])          # the fallback result was kept
     assert all(np.isfinite(s["avg_logprob"]) for s in r["segments"])
+    # the same ladder climbed by several files together: retries are decoded as batches (best_of rows per window,
+    # per-row prompts of different lengths once the files have produced text)
+    files = [audio(42, 200000), np.concatenate([audio(43), audio(44, 150000)]), audio(45, 480000)]
+    got = model.transcribe_batch(files, temperature=(0.0, 0.5), logprob_threshold=0.0, fp16=False, language="en",
+                                 sample_len=10, best_of=3, condition_on_previous_text=True, no_speech_threshold=None)
+    assert len(got) == 3 and all(len(g["segments"]) >= 1 for g in got)
+    assert all(s["temperature"] == 0.5 and np.isfinite(s["avg_logprob"]) for g in got for s in g["segments"])
     opts = whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=8, temperature=0.7, best_of=2)
     res = whisper_amd.decode(model, mel, opts)
     assert len(res.tokens) <= 8 and res.temperature == 0.7

@@ -275,3 +275,65 @@ def test_transcribe_seek_logic_matches_reference(ref, monkeypatch):
         assert ma.calls == mb.calls
         assert ra["text"] == rb["text"] and ra["language"] == rb["language"]
         assert ra["segments"] == rb["segments"]
+
+
+class _FunctionalModel:
+    """decode() is a deterministic function of (window content, temperature, prompt): batched or one at a time, a
+    window must come out the same.  A window "fails" (compression ratio 3.0 -> fallback) below a per-window
+    temperature threshold, so windows climb the ladder to different rungs."""
+
+    def __init__(self, result_cls, tokenizer):
+        fm = _fake_model(True)
+        self.dims, self.is_multilingual, self.num_languages, self.device = fm.dims, fm.is_multilingual, fm.num_languages, fm.device
+        self.decoder = fm.decoder
+        self.result_cls, self.tk, self.calls = result_cls, tokenizer, []
+
+    def _one(self, mel, options, prompt):
+        key = int(abs(float(mel.double().sum())) * 1000) % 9973
+        TB = self.tk.timestamp_begin
+        words = self.tk.encode(" " + " ".join(["alpha", "bravo", "charlie", "delta", "echo"][: 1 + key % 5]))
+        need = (0.0, 0.0, 0.2, 0.4, 0.2)[key % 5]                    # lowest temperature at which this window is fine
+        ok = options.temperature >= need - 1e-9
+        toks = [TB, *words, TB + 100 + key % 400, TB + 100 + key % 400, *words[: 1 + (len(prompt or ()) % 2)], TB + 700]
+        return self.result_cls(audio_features=torch.zeros(1), language="en", tokens=toks,
+                               text=self.tk.decode(toks).strip(), avg_logprob=-0.3 - 0.01 * options.temperature,
+                               no_speech_prob=0.01, temperature=options.temperature,
+                               compression_ratio=1.2 if ok else 3.0)
+
+    def decode(self, segment, options, prompts=None):
+        if segment.ndim == 2:
+            self.calls.append((1, options.temperature))
+            return self._one(segment, options, options.prompt)
+        self.calls.append((segment.shape[0], options.temperature))
+        assert options.prompt is None and prompts is not None and len(prompts) == segment.shape[0]
+        return [self._one(m, options, p) for m, p in zip(segment, prompts)]
+
+
+def test_transcribe_batch_ladder_equals_file_by_file(monkeypatch):
+    """transcribe_batch: windows of several files are decoded in batches with per-row prompts and climb the
+    temperature ladder together (transcribe.py:184-224), and still every file comes out exactly as from transcribe()"""
+    import oracle
+    import whisper_amd  # noqa: F401
+    mine_tr = sys.modules["whisper_amd.transcribe"]
+    from whisper_amd import decoding as mine
+    from whisper_amd.tokenizer import get_tokenizer
+    tk = get_tokenizer(True, num_languages=99, language="en", task="transcribe")
+    filt = oracle.mel_filterbank(80)
+
+    def cpu_mel(a, n_mels=80, padding=0, device=None):
+        return oracle.log_mel_spectrogram(a, filt, padding=padding)
+    monkeypatch.setattr(mine_tr, "log_mel_spectrogram", cpu_mel)
+    rng = np.random.default_rng(1)
+    files = [(rng.standard_normal(16000 * n) * 0.01).astype(np.float32) for n in (95, 40, 130, 61, 20)]
+    for kw in (dict(temperature=(0.0, 0.2, 0.4, 0.6)), dict(temperature=(0.0, 0.2), condition_on_previous_text=False),
+               dict(temperature=(0.0, 0.2, 0.4), beam_size=3, best_of=2)):
+        ma, mb = _FunctionalModel(mine.DecodingResult, tk), _FunctionalModel(mine.DecodingResult, tk)
+        want = [mine_tr.transcribe(ma, a, language="en", fp16=False, **kw) for a in files]
+        got = mine_tr.transcribe_batch(mb, files, language="en", fp16=False, batch_size=4, **kw)
+        assert [g["segments"] for g in got] == [w["segments"] for w in want]
+        assert [g["text"] for g in got] == [w["text"] for w in want]
+        assert {s["temperature"] for w in want for s in w["segments"]} >= {0.0, 0.2}          # the ladder was climbed
+        assert sum(n for n, _ in mb.calls) == sum(n for n, _ in ma.calls)                      # same decodes in total
+        assert len(mb.calls) < len(ma.calls)                                                   # ... in fewer calls
+        assert any(n > 1 and t > 0 for n, t in mb.calls)                                       # retries were batched
+        assert all(n <= 4 for n, _ in mb.calls)

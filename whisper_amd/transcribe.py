@@ -407,8 +407,8 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, **kwargs
     conditioned on its own file's previous text (`DecodingTask(..., prompts=...)`: rows of different prompt lengths
     share a greedy call; beam search batches rows of equal prompt length).  Results are the same dicts `transcribe`
     returns, in input order.  Windows of one file stay sequential (seek and prompt depend on the previous window).
-    A window whose batched result trips the temperature-fallback criteria is re-decoded on its own from the next
-    temperature, as the reference would."""
+    Windows whose result trips the temperature-fallback criteria climb the temperature ladder together: the next
+    rung decodes them as a batch again (sampling runs on the device, `best_of` rows per window)."""
     names = ("verbose", "temperature", "compression_ratio_threshold", "logprob_threshold", "no_speech_threshold",
              "condition_on_previous_text", "initial_prompt", "carry_initial_prompt", "word_timestamps",
              "prepend_punctuations", "append_punctuations", "clip_timestamps", "hallucination_silence_threshold")
@@ -433,24 +433,33 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, **kwargs
     for i in range(len(walks)):
         advance(i, None)
     while pending:
-        groups = {}
-        for i in sorted(pending):
-            groups.setdefault(_options_key(workers[i].decode_options), []).append(i)
+        # one round = the windows pending right now, taken up the temperature ladder together: every rung decodes,
+        # in batches, the windows that still fail the fallback criteria of transcribe.py:202-222 at the rung below
+        rung = {i: 0 for i in pending}
+        todo = sorted(pending)
         answers = {}
-        for members in groups.values():
-            lead = workers[members[0]]
-            shared = replace(lead._options_for(lead.temperatures[0]), prompt=None)
-            prompts = {i: workers[i].decode_options.get("prompt") for i in members}
-            for chunk in _prompt_batches(model, shared, prompts, members, batch_size):
-                if len(chunk) == 1:
-                    answers[chunk[0]] = workers[chunk[0]].decode_with_fallback(pending[chunk[0]])
-                    continue
-                decoded = model.decode(torch.stack([pending[i] for i in chunk]), shared,
-                                       prompts=[prompts[i] for i in chunk])
-                for i, result in zip(chunk, decoded):
-                    if workers[i]._needs_retry(result) and len(workers[i].temperatures) > 1:
-                        result = workers[i].decode_with_fallback(pending[i], first=1)
-                    answers[i] = result
-        for i, result in answers.items():
+        while todo:
+            groups = {}
+            for i in todo:
+                t = workers[i].temperatures[rung[i]]
+                groups.setdefault((_options_key(workers[i].decode_options), t), []).append(i)
+            todo = []
+            for (_, t), members in groups.items():
+                shared = replace(workers[members[0]]._options_for(t), prompt=None)
+                prompts = {i: workers[i].decode_options.get("prompt") for i in members}
+                for chunk in _prompt_batches(model, shared, prompts, members, batch_size):
+                    if len(chunk) == 1:        # alone: exactly the call `transcribe` makes
+                        decoded = [model.decode(pending[chunk[0]], workers[chunk[0]]._options_for(t))]
+                    else:
+                        decoded = model.decode(torch.stack([pending[i] for i in chunk]), shared,
+                                               prompts=[prompts[i] for i in chunk])
+                    for i, result in zip(chunk, decoded):
+                        if workers[i]._needs_retry(result) and rung[i] + 1 < len(workers[i].temperatures):
+                            rung[i] += 1
+                            todo.append(i)
+                        else:
+                            answers[i] = result
+            todo.sort()
+        for i, result in sorted(answers.items()):
             advance(i, result)
     return results
