@@ -41,7 +41,23 @@ def _worker(rank, world, port, q):
         checksum = int(got.to(torch.int64).sum())
         items = list(range(11))
         res = launcher.run_sharded(items, lambda xs: [(rank, x * x) for x in xs], dist)
-        q.put((rank, checksum, res))
+        costs = [10, 1, 1, 1, 9, 2, 2, 8, 3, 3, 1]
+        bal = launcher.run_balanced(items, costs, lambda xs: [(rank, x * x) for x in xs], dist)
+
+        class _Model:                                  # transcribe_sharded only hands the model through
+            pass
+        import whisper_amd.transcribe as tr_mod        # noqa: F401  (module object lives in sys.modules)
+        import sys
+        mod = sys.modules["whisper_amd.transcribe"]
+        real = mod.transcribe_batch
+        mod.transcribe_batch = lambda model, part, batch_size=16, **kw: [
+            {"text": f"{int(a.shape[-1])}", "rank": rank, "bs": batch_size, "kw": sorted(kw)} for a in part]
+        try:
+            files = [torch.zeros(n) for n in (160000, 16000, 480000, 32000, 320000)]
+            tr = launcher.transcribe_sharded(_Model(), files, dist, batch_size=4, language="en")
+        finally:
+            mod.transcribe_batch = real
+        q.put((rank, checksum, res, bal, tr))
     finally:
         dist.destroy_process_group()
 
@@ -57,8 +73,29 @@ def test_broadcast_and_gather_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, c0, res0), (r1, c1, res1) = out
+    (r0, c0, res0, bal0, tr0), (r1, c1, res1, bal1, tr1) = out
     assert c0 == c1 != 0                       # both ranks hold the same blob bytes
     assert res1 is None                        # only rank 0 gets the gathered results
     assert [v for _, v in res0] == [x * x for x in range(11)]          # original order
     assert [r for r, _ in res0] == [0] * 6 + [1] * 5                    # contiguous shards: ceil(11/2) = 6
+    # cost-balanced shards (longest first onto the least loaded rank), results back in input order
+    assert bal1 is None and [v for _, v in bal0] == [x * x for x in range(11)]
+    costs = [10, 1, 1, 1, 9, 2, 2, 8, 3, 3, 1]
+    load = [sum(c for (r, _), c in zip(bal0, costs) if r == k) for k in range(2)]
+    assert sorted(load) == [20, 21]
+    # transcribe_sharded: files balanced by length, every file transcribed once, input order kept on rank 0
+    assert tr1 is None and [d["text"] for d in tr0] == ["160000", "16000", "480000", "32000", "320000"]
+    assert {d["rank"] for d in tr0} == {0, 1} and all(d["bs"] == 4 and d["kw"] == ["language"] for d in tr0)
+    assert [d["rank"] for d in tr0] == [1, 1, 0, 0, 1]       # 480000 + 32000 | 320000 + 160000 + 16000
+
+
+def test_balanced_shards():
+    assert launcher.balanced_shards([10, 1, 1, 1, 9, 2, 2, 8], 3) == [[0, 1, 3], [4, 6], [2, 5, 7]]
+    assert launcher.balanced_shards([], 2) == [[], []]
+    assert launcher.balanced_shards([5.0], 4) == [[0], [], [], []]
+    for n, w in [(17, 4), (5, 8), (64, 8)]:
+        costs = [(i * 37) % 11 + 1 for i in range(n)]
+        shards = launcher.balanced_shards(costs, w)
+        assert sorted(i for s in shards for i in s) == list(range(n))
+        loads = [sum(costs[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(costs)

@@ -52,3 +52,60 @@ def run_sharded(items: Sequence[Any], fn: Callable[[Sequence[Any]], List[Any]], 
     for part in gathered:
         out.extend(part or [])
     return out
+
+
+def balanced_shards(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Item indices per rank, longest-processing-time first: items are taken in descending cost and given to the
+    rank with the least work so far (ties: lowest rank).  Files of very different lengths would otherwise leave the
+    ranks with contiguous shards idle while the longest shard finishes (load imbalance is the only
+    limit on scaling — nothing is exchanged in the step).  Each rank's list is returned in ascending index order."""
+    loads = [0.0] * world
+    shards: List[List[int]] = [[] for _ in range(world)]
+    for i in sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i)):
+        r = min(range(world), key=lambda r: (loads[r], r))
+        shards[r].append(i)
+        loads[r] += float(costs[i])
+    return [sorted(s) for s in shards]
+
+
+def run_balanced(items: Sequence[Any], costs: Sequence[float], fn: Callable[[Sequence[Any]], List[Any]],
+                 dist=None) -> Optional[List[Any]]:
+    """`run_sharded` with cost-balanced instead of contiguous shards; rank 0 returns all results in input order."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return list(fn(items))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    shards = balanced_shards(costs, world)
+    mine = list(fn([items[i] for i in shards[rank]])) if shards[rank] else []
+    if len(mine) != len(shards[rank]):
+        raise RuntimeError(f"rank {rank}: {len(mine)} results for {len(shards[rank])} items")
+    gathered: List[Optional[List[Any]]] = [None] * world if rank == 0 else None
+    dist.gather_object(mine, gathered, dst=0)
+    if rank != 0:
+        return None
+    out: List[Any] = [None] * len(items)
+    for idx, part in zip(shards, gathered):
+        for i, res in zip(idx, part or []):
+            out[i] = res
+    return out
+
+
+def _audio_cost(audio) -> float:
+    """work estimate of one input of transcribe(): samples of an array, bytes of a file"""
+    import os
+    if isinstance(audio, (str, bytes, os.PathLike)):
+        try:
+            return float(os.path.getsize(audio))
+        except OSError:
+            return 1.0
+    return float(getattr(audio, "shape", [1])[-1])
+
+
+def transcribe_sharded(model, audios: Sequence[Any], dist=None, *, batch_size: int = 16, **kwargs) -> Optional[List[dict]]:
+    """Many files over many GPUs: every rank transcribes its cost-balanced share with `transcribe_batch` (windows of
+    one file never leave their rank: seek and prompt depend on the previous window, transcribe.py:288-293,371-399);
+    rank 0 returns the result dicts in input order, other ranks None.  All inputs must be of one kind (arrays or
+    paths) for the costs to be comparable."""
+    from .transcribe import transcribe_batch
+    costs = [_audio_cost(a) for a in audios]
+    return run_balanced(list(audios), costs, lambda part: transcribe_batch(model, part, batch_size=batch_size, **kwargs),
+                        dist)
