@@ -85,3 +85,29 @@ def test_audio_library_exports_header():
     lib = audio._audio_lib()
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in whisper_audio.h but not exported"
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """every struct that crosses the boundary has the same size and field offsets in the ctypes binding as a C
+    compiler gives the declarations in include/whisper_hip.h (gcc, plain C99 — the header must stay a C header)"""
+    import ctypes as C
+    import subprocess
+    structs = {"wh_dims": hip.Dims, "wh_layer_weights": hip.LayerWeights, "wh_model_weights": hip.ModelWeights,
+               "wh_greedy_params": hip.GreedyParams, "wh_beam_params": hip.BeamParams}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "whisper_hip.h"', '#include "whisper_audio.h"',
+             'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
