@@ -25,6 +25,7 @@ from .model import ModelDimensions, Whisper
 from .registry import ALIGNMENT_HEADS as _ALIGNMENT_HEADS
 from .registry import MODEL_URLS as _MODELS
 from .transcribe import transcribe, transcribe_batch
+from . import launcher  # noqa: E402,F401  (multi-GPU layer: broadcast_weights, transcribe_sharded)
 
 __version__ = "0.1.0"
 
