@@ -124,8 +124,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
   const int es = tid / (NB * RT), er = (tid / NB) % RT, ej = tid % NB;
   const bool e_on = es < GS && er < R;
   float e_bias = 0.f, e_res = 0.f;
-  int e_lag = 0, e_pos = 0;                        // EPI_QKV: cache position and this row's lag (ragged prompts)
-  if (a.epi == whk::EPI_QKV) e_pos = load_uniform_int(a.d_pos);
+  // EPI_QKV: cache position and this row's lag (ragged prompts).  The position is requested here and first USED in the
+  // epilogue (every lane reads the same word; no readfirstlane, which would wait for the load on the spot)
+  int e_lag = 0, e_pos = 0;
+  if (a.epi == whk::EPI_QKV) e_pos = load_agent_int(a.d_pos);
   if (e_on && a.epi == whk::EPI_QKV && a.lag) e_lag = a.lag[r0 + er];
   if (e_on) {
     const int n = (g0 + es) * NB + ej;
