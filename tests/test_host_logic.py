@@ -337,3 +337,89 @@ def test_transcribe_batch_ladder_equals_file_by_file(monkeypatch):
         assert len(mb.calls) < len(ma.calls)                                                   # ... in fewer calls
         assert any(n > 1 and t > 0 for n, t in mb.calls)                                       # retries were batched
         assert all(n <= 4 for n, _ in mb.calls)
+
+
+def _beam_update_model(state, cand_lp, cand_tok, first, G, K, eot, max_candidates):
+    """Line-by-line Python model of beam_update_kernel (whisper_amd/csrc/beam.hip): one segment per workgroup, fp32
+    scores, rank = stable descending order, walk until G sequences are kept.  `state`: tokens [R][len], sums [R] fp32,
+    fin (list of (sequence, score) per segment, in insertion order), done (flags of the previous update)."""
+    tokens, sums, fin, done_prev = state["tokens"], state["sums"], state["fin"], state["done"]
+    B = len(fin)
+    if all(done_prev):                                   # completed: later updates leave everything untouched
+        return dict(tokens=[list(r) for r in tokens], sums=sums.copy(), fin=fin, done=[1] * B), list(range(len(tokens)))
+    new_tokens, new_sums, src, done_next = [None] * len(tokens), sums.copy(), [None] * len(tokens), [0] * B
+    for au in range(B):
+        r0, N = au * G, G * K
+        score = np.full(N, np.nan, np.float32)
+        ctok, csrc = np.zeros(N, int), np.zeros(N, int)
+        for c in range(N):
+            j, kk = divmod(c, K)
+            if (j == G - 1) if first else True:          # first update: every beam holds the same prefix
+                score[c] = np.float32(sums[r0 + j]) + np.float32(cand_lp[r0 + j][kk])
+            ctok[c], csrc[c] = cand_tok[r0 + j][kk], r0 + j
+        order = {}
+        for c in range(N):
+            if score[c] != score[c]:
+                continue
+            rank = sum(1 for o in range(N) if score[o] == score[o] and (score[o] > score[c] or (score[o] == score[c] and o < c)))
+            order[rank] = c
+        kept, newly = [], []
+        for i in range(K if first else N):
+            if len(kept) >= G:
+                break
+            c = order[i]
+            (newly if ctok[c] == eot else kept).append(c)
+        for c in newly:
+            if len(fin[au]) >= max_candidates:
+                break
+            fin[au].append((tuple(tokens[csrc[c]]) + (eot,), float(score[c])))
+        for b, c in enumerate(kept):
+            new_tokens[r0 + b] = list(tokens[csrc[c]]) + [int(ctok[c])]
+            src[r0 + b], new_sums[r0 + b] = int(csrc[c]), score[c]
+        done_next[au] = 1 if len(fin[au]) >= max_candidates else 0
+    return dict(tokens=new_tokens, sums=new_sums, fin=fin, done=done_next), src
+
+
+def test_device_beam_bookkeeping_model_equals_beam_search_decoder():
+    """the algorithm beam_update_kernel implements (modelled above, candidate lists = log_softmax(...).topk(G + 1) as the
+    row kernel produces them) against BeamSearchDecoder.update — itself checked against the reference in
+    test_token_decoders_match_reference — over random multi-step runs: live beams, sums (bit-equal fp32), finished
+    lists in dict order, KV source rows, completion flag; patience above and below 1; EOT made likely so that lists
+    fill up and runs complete."""
+    import torch.nn.functional as F
+    from whisper_amd.decoding import BeamSearchDecoder
+
+    class Inf:
+        def rearrange_kv_cache(self, src):
+            self.src = list(src)
+
+    rng = np.random.default_rng(0)
+    for trial in range(120):
+        G, B, V = int(rng.integers(2, 6)), int(rng.integers(1, 4)), int(rng.integers(12, 40))
+        eot, patience = V - 3, float(rng.choice([1.0, 1.0, 2.0, 0.5]))
+        inf = Inf()
+        dec = BeamSearchDecoder(G, eot, inf, patience)
+        K = G + 1
+        tokens, sums = torch.tensor([[1, 2, 3]] * (B * G)), torch.zeros(B * G)
+        st = dict(tokens=[[1, 2, 3] for _ in range(B * G)], sums=np.zeros(B * G, np.float32), fin=[[] for _ in range(B)], done=[0] * B)
+        completed = False
+        for step in range(12):
+            lg = torch.tensor(rng.standard_normal((B, V)).astype(np.float32)).repeat_interleave(G, 0) if step == 0 \
+                else torch.tensor(rng.standard_normal((B * G, V)).astype(np.float32))
+            lg[:, eot] += float(rng.choice([0, 1.5, 3.0]))
+            lp = F.log_softmax(lg.float(), -1).numpy()
+            order = np.lexsort((np.arange(V)[None, :].repeat(B * G, 0), -lp), axis=-1)[:, :K]   # value desc, index asc
+            if not completed:
+                tokens, completed = dec.update(tokens, lg.clone(), sums)
+            st, src = _beam_update_model(st, np.take_along_axis(lp, order, 1), order, step == 0, G, K, eot, dec.max_candidates)
+            assert [list(r) for r in st["tokens"]] == tokens.tolist(), (trial, step)
+            assert np.array_equal(st["sums"], sums.numpy()), (trial, step)
+            for a in range(B):
+                assert [k for k, _ in st["fin"][a]] == list(dec.finished_sequences[a].keys()), (trial, step, a)
+                assert [v for _, v in st["fin"][a]] == list(dec.finished_sequences[a].values()), (trial, step, a)
+            assert bool(all(st["done"])) == bool(completed)
+            if not all(st["done"]) and step > 0:
+                # same caches: a new beam continues the row the decoder names (prefixes are distinct after step 0)
+                assert src == inf.src, (trial, step)
+            if completed and step > 8:
+                break
