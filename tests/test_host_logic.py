@@ -423,3 +423,59 @@ def test_device_beam_bookkeeping_model_equals_beam_search_decoder():
                 assert src == inf.src, (trial, step)
             if completed and step > 8:
                 break
+
+
+def test_word_timing_host_logic_matches_reference(ref, monkeypatch):
+    """the host half of word timestamps (timing.py:57-80 backtrace, :245-276 merge_punctuations, :279-388
+    add_word_timestamps with its duration-clipping heuristics): same inputs -> same words / boundaries as the live
+    reference; the alignment itself (the device half) is stubbed with the same scripted WordTimings on both sides"""
+    import copy
+    import whisper_amd  # noqa: F401
+    from whisper_amd import timing as mine
+    rt = ref.timing
+    rng = np.random.default_rng(5)
+
+    # backtrace: random valid trace matrices (first row = 2, first column = 1, as dtw leaves them)
+    for n, m in ((5, 9), (17, 40), (60, 33), (1, 7)):
+        trace = rng.integers(0, 3, (n + 1, m + 1)).astype(np.float32)
+        trace[0, :], trace[:, 0] = 2, 1
+        assert np.array_equal(mine.backtrace(trace.copy()), rt.backtrace(trace.copy()))
+
+    # merge_punctuations on random word lists with plenty of punctuation
+    vocab = [" hello", " world", ",", ".", " \"", "\"", " (", ")", " -", "!", " there", "?", " ¿", " que", ":"]
+    pre, app = "\"'“¿([{-", "\"'.。,，!！?？:：”)]}、"
+    for _ in range(200):
+        words = [vocab[i] for i in rng.integers(0, len(vocab), int(rng.integers(1, 12)))]
+        a = [mine.WordTiming(w, [i], 0.1 * i, 0.1 * i + 0.05, 0.9) for i, w in enumerate(words)]
+        b = [rt.WordTiming(w, [i], 0.1 * i, 0.1 * i + 0.05, 0.9) for i, w in enumerate(words)]
+        mine.merge_punctuations(a, pre, app)
+        rt.merge_punctuations(b, pre, app)
+        assert [(x.word, x.tokens) for x in a] == [(x.word, x.tokens) for x in b]
+
+    # add_word_timestamps: scripted alignment with pauses, over-long words and sentence marks
+    tk, rtk = _tok(ref)
+    for trial in range(60):
+        n_seg = int(rng.integers(1, 4))
+        segments, all_words, t = [], [], float(rng.uniform(0, 3))
+        for s in range(n_seg):
+            n_w = int(rng.integers(1, 7))
+            toks, seg_start = [], t
+            for w in range(n_w):
+                word = [" alpha", " beta", ".", " gamma", "!", " delta", ","][int(rng.integers(0, 7))]
+                wt = tk.encode(word)
+                dur = float(rng.choice([0.1, 0.2, 0.3, 0.5, 1.5, 3.0]))
+                gap = float(rng.choice([0.0, 0.0, 0.1, 2.5]))
+                all_words.append((word, wt, round(t + gap, 2), round(t + gap + dur, 2), float(rng.uniform(0.3, 1.0))))
+                toks += wt
+                t += gap + dur
+            segments.append(dict(seek=int(rng.choice([0, 3000])), start=round(seg_start + float(rng.uniform(-0.8, 0.8)), 2),
+                                 end=round(t + float(rng.uniform(-0.8, 0.8)), 2), tokens=[tk.timestamp_begin] + toks + [tk.timestamp_begin + 50]))
+        for s in segments:
+            s["seek"] = segments[0]["seek"]
+        monkeypatch.setattr(mine, "find_alignment", lambda *a, **k: [mine.WordTiming(*w) for w in all_words])
+        monkeypatch.setattr(rt, "find_alignment", lambda *a, **k: [rt.WordTiming(*w) for w in all_words])
+        sa, sb = copy.deepcopy(segments), copy.deepcopy(segments)
+        last = float(rng.choice([0.0, 1.0, 4.0]))
+        mine.add_word_timestamps(segments=sa, model=None, tokenizer=tk, mel=None, num_frames=3000, last_speech_timestamp=last)
+        rt.add_word_timestamps(segments=sb, model=None, tokenizer=rtk, mel=None, num_frames=3000, last_speech_timestamp=last)
+        assert sa == sb, trial
