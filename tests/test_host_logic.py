@@ -479,3 +479,60 @@ def test_word_timing_host_logic_matches_reference(ref, monkeypatch):
         mine.add_word_timestamps(segments=sa, model=None, tokenizer=tk, mel=None, num_frames=3000, last_speech_timestamp=last)
         rt.add_word_timestamps(segments=sb, model=None, tokenizer=rtk, mel=None, num_frames=3000, last_speech_timestamp=last)
         assert sa == sb, trial
+
+
+def test_transcribe_word_timestamp_seeking_matches_reference(ref, monkeypatch):
+    """transcribe.py:401-470 — word_timestamps=True changes how windows advance (seek to the last word's end) and
+    enables hallucination_silence_threshold (anomaly scores, skipping silence before / after suspicious segments).
+    The word aligner is stubbed identically on both sides (deterministic words with a few very long and very
+    improbable ones), the decoder is scripted: same segments, words and seek sequence as the live reference."""
+    import oracle
+    import whisper_amd  # noqa: F401
+    mine_tr = sys.modules["whisper_amd.transcribe"]
+    ref_tr = sys.modules["whisper.transcribe"]
+    from whisper_amd import decoding as mine
+    tk, rtk = _tok(ref)
+    TB = tk.timestamp_begin
+    hello, world = tk.encode(" hello there"), tk.encode(" general kenobi you are bold")
+    scripts = [
+        {"tokens": [TB, *hello, TB + 200, TB + 200, *world, TB + 450, TB + 450, *hello]},
+        {"tokens": [TB + 20, *world, TB + 300]},
+        {"tokens": [TB + 600, *hello, TB + 700, TB + 700, *world, TB + 1400, TB + 1400]},
+        {"tokens": [TB, *hello, TB + 100, TB + 100, *hello, TB + 220, TB + 400, *world, TB + 1000, TB + 1000]},
+        {"tokens": [*hello, *world]},
+        {"tokens": [TB + 50, *world, TB + 1200, TB + 1200, *hello, TB + 1490]},
+    ]
+
+    def fake_words(*, segments, model, tokenizer, mel, num_frames, prepend_punctuations="", append_punctuations="",
+                   last_speech_timestamp, **kw):
+        # words spread over the segment; every 5th word over-long, every 7th improbable -> anomaly scores vary
+        counter = 0
+        for seg in segments:
+            toks = [t for t in seg["tokens"] if t < tokenizer.eot]
+            n = max(1, len(toks) // 2)
+            span = max(seg["end"] - seg["start"], 0.2)
+            words, t0 = [], seg["start"]
+            for i in range(n):
+                counter += 1
+                dur = span / n * (3.5 if counter % 5 == 0 else 0.6)
+                words.append(dict(word=f" w{counter}", start=round(t0, 2), end=round(t0 + dur, 2),
+                                  probability=0.05 if counter % 7 == 0 else 0.9))
+                t0 += span / n
+            seg["words"] = words
+    monkeypatch.setattr(mine_tr, "add_word_timestamps", fake_words)
+    monkeypatch.setattr(ref_tr, "add_word_timestamps", fake_words)
+    filt = oracle.mel_filterbank(80)
+    monkeypatch.setattr(mine_tr, "log_mel_spectrogram", lambda a, n_mels=80, padding=0, device=None: oracle.log_mel_spectrogram(a, filt, padding=padding))
+    rng = np.random.default_rng(2)
+    audio = (rng.standard_normal(16000 * 140) * 0.01).astype(np.float32)
+    for kw in (dict(word_timestamps=True), dict(word_timestamps=True, hallucination_silence_threshold=1.0),
+               dict(word_timestamps=True, hallucination_silence_threshold=0.2, condition_on_previous_text=False),
+               dict(word_timestamps=True, clip_timestamps="10,70,80,130", hallucination_silence_threshold=2.0)):
+        ma = _ScriptedModel(mine.DecodingResult, tk, scripts)
+        mb = _ScriptedModel(ref.DecodingResult, rtk, scripts)
+        ra = mine_tr.transcribe(ma, audio, language="en", fp16=False, temperature=0.0, **kw)
+        rb = ref.transcribe(mb, audio, language="en", fp16=False, temperature=0.0, **kw)
+        assert ma.calls == mb.calls, kw
+        assert ra["text"] == rb["text"]
+        assert ra["segments"] == rb["segments"], kw
+        assert len(ma.calls) >= 4 and any("words" in s for s in ra["segments"])
