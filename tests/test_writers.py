@@ -100,3 +100,36 @@ def test_writers_known_output():
     assert json.loads(out.getvalue()) == res
     with pytest.raises(KeyError):
         U.get_writer("docx", ".")
+
+
+@pytest.mark.reference
+def test_small_helpers_match_reference(ref_utils):
+    """exact_div, compression_ratio, format_timestamp, get_start / get_end (utils.py:24-82) on random inputs"""
+    RU = ref_utils
+    rnd = random.Random(9)
+    for _ in range(200):
+        y, k = rnd.randint(1, 50), rnd.randint(0, 99)
+        assert U.exact_div(y * k, y) == RU.exact_div(y * k, y) == k
+    for x, y in ((480000, 160), (3000, 2), (0, 7)):
+        assert U.exact_div(x, y) == RU.exact_div(x, y)
+    for bad in ((10, 3), (7, 2)):
+        with pytest.raises(AssertionError):
+            U.exact_div(*bad)
+        with pytest.raises(AssertionError):
+            RU.exact_div(*bad)
+    words = ["the", "quick", "über", "naïve", "日本語", "a", " ", "\n", "and and and and"]
+    for _ in range(100):
+        text = " ".join(rnd.choice(words) for _ in range(rnd.randint(1, 60)))
+        assert U.compression_ratio(text) == RU.compression_ratio(text)
+    for _ in range(300):
+        s = rnd.choice([0.0, rnd.uniform(0, 70), rnd.uniform(3500, 3700), rnd.uniform(0, 1e5), 59.9996, 3599.9999])
+        for hours, mark in ((False, "."), (True, ","), (False, ","), (True, ".")):
+            assert U.format_timestamp(s, hours, mark) == RU.format_timestamp(s, hours, mark)
+    with pytest.raises(AssertionError):
+        U.format_timestamp(-1.0)
+    for seed in range(40):
+        segs = _result(seed)["segments"]                  # both index s["words"]: word-timed segments only
+        assert U.get_start(segs) == RU.get_start(segs) and U.get_end(segs) == RU.get_end(segs)
+        empty = [dict(s, words=[]) for s in segs]
+        assert U.get_start(empty) == RU.get_start(empty) and U.get_end(empty) == RU.get_end(empty)
+    assert U.get_start([]) == RU.get_start([]) and U.get_end([]) == RU.get_end([])
