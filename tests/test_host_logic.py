@@ -536,3 +536,40 @@ def test_transcribe_word_timestamp_seeking_matches_reference(ref, monkeypatch):
         assert ra["text"] == rb["text"]
         assert ra["segments"] == rb["segments"], kw
         assert len(ma.calls) >= 4 and any("words" in s for s in ra["segments"])
+
+
+def test_detect_language_host_logic_matches_reference(ref):
+    """decoding.py:18-77: given the same logits at the <|startoftranscript|> position, the language mask, arg-max and
+    probability dictionaries equal the reference's (v2 = 99 and v3 = 100 languages; single and batched inputs;
+    English-only models refuse)"""
+    from whisper_amd import decoding as mine
+    from whisper_amd.tokenizer import get_tokenizer
+    rng = np.random.default_rng(4)
+    for n_vocab in (51865, 51866):
+        fm = _fake_model(True)
+        dims = SimpleNamespace(**{**fm.dims.__dict__, "n_vocab": n_vocab})
+        table = torch.tensor(rng.standard_normal((3, n_vocab)).astype(np.float32) * 3)
+
+        class M:
+            is_multilingual, num_languages = True, n_vocab - 51765 - 1
+
+            def __init__(self):
+                self.dims = dims
+
+            def logits(self, x, feats):
+                assert x.shape == (feats.shape[0], 1)
+                return table[: feats.shape[0], None, :].clone()
+
+        feats = torch.zeros(3, dims.n_audio_ctx, dims.n_audio_state)
+        tk = get_tokenizer(True, num_languages=M.num_languages)
+        rtk = ref.tokenizer.get_tokenizer(True, num_languages=M.num_languages)
+        ta, pa = mine.detect_language(M(), feats, tk)
+        tb, pb = ref.decoding.detect_language(M(), feats, rtk)
+        assert ta.tolist() == tb.tolist() and pa == pb and len(pa[0]) == M.num_languages
+        ta, pa = mine.detect_language(M(), feats[0], tk)
+        tb, pb = ref.decoding.detect_language(M(), feats[0], rtk)
+        assert int(ta) == int(tb) and pa == pb
+    with pytest.raises(ValueError):
+        mine.detect_language(_fake_model(False), torch.zeros(1500, 384), get_tokenizer(False))
+    with pytest.raises(ValueError):
+        ref.decoding.detect_language(_fake_model(False), torch.zeros(1500, 384), ref.tokenizer.get_tokenizer(False))
