@@ -124,6 +124,14 @@ def test_wide_fused_greedy_vs_oracle(wide, gpu_device):
     assert torch.equal(got, want["tokens"])
     assert np.allclose(sum_lp.numpy(), np.asarray(want["sum_logprobs"]), atol=2e-3)
     assert np.allclose(nsp.numpy(), np.asarray(want["no_speech_probs"]), rtol=1e-3, atol=1e-7)
+    # the same inputs through the LIVE reference (tests/golden/make_golden_wide.py): rows cut at EOT, exact
+    import os
+    W = np.load(os.path.join(os.path.dirname(__file__), "golden", "wide_v3.npz"))
+    for i in range(8):
+        row = got[i, len(init):].tolist()
+        row = row[: row.index(tok.eot)] if tok.eot in row else row
+        assert row == [t for t in W["greedy_tokens"][i].tolist() if t >= 0], i
+        assert abs(float(sum_lp[i]) / (len(row) + 1) - W["greedy_stats"][i, 0]) < 1e-3
 
 
 def test_large_v3_batch_invariance_and_determinism(gpu_device):
