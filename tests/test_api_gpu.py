@@ -286,6 +286,13 @@ def test_ragged_prompts_equal_single_row_decodes(setup, gpu_device, fp16):
         assert abs(got[i].no_speech_prob - want.no_speech_prob) < max(1e-6, tol * want.no_speech_prob)
         assert got[i].text == want.text and got[i].compression_ratio == want.compression_ratio
     if not fp16:
+        # every row against the LIVE reference decoding that segment alone with options.prompt
+        # (tests/golden/make_golden_prompts.py): ids exact, statistics to 1e-3
+        P = np.load(os.path.join(os.path.dirname(__file__), "golden", "prompts_micro.npz"))
+        for i in range(len(prompts)):
+            assert got[i].tokens == [t for t in P[f"{key}_tokens"][i].tolist() if t >= 0], i
+            assert abs(got[i].avg_logprob - P[f"{key}_stats"][i, 0]) < 1e-3
+            assert abs(got[i].no_speech_prob - P[f"{key}_stats"][i, 1]) < max(1e-7, 2e-3 * P[f"{key}_stats"][i, 1])
         om = oracle.OracleModel(dims, sd)
         multilingual = dims.n_vocab >= 51865
         tok = get_tokenizer(multilingual, num_languages=dims.n_vocab - 51765 - int(multilingual), language="en", task="transcribe")
