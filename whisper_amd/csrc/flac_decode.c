@@ -184,13 +184,14 @@ static int read_subframe(BR* b, int64_t* s, int blocksize, int bps) {
     for (int i = 0; i < order; ++i) s[i] = br_s64(b, bps);
     int rc = read_residual(b, s, blocksize, order);
     if (rc) return rc;
+    uint64_t* u = (uint64_t*)s;                /* wrapping arithmetic, as in the LPC branch below */
     for (int i = order; i < blocksize; ++i) {
       switch (order) {
         case 0: break;
-        case 1: s[i] += s[i-1]; break;
-        case 2: s[i] += 2 * s[i-1] - s[i-2]; break;
-        case 3: s[i] += 3 * s[i-1] - 3 * s[i-2] + s[i-3]; break;
-        case 4: s[i] += 4 * s[i-1] - 6 * s[i-2] + 4 * s[i-3] - s[i-4]; break;
+        case 1: u[i] += u[i-1]; break;
+        case 2: u[i] += 2 * u[i-1] - u[i-2]; break;
+        case 3: u[i] += 3 * u[i-1] - 3 * u[i-2] + u[i-3]; break;
+        case 4: u[i] += 4 * u[i-1] - 6 * u[i-2] + 4 * u[i-3] - u[i-4]; break;
       }
     }
   } else if (type >= 32) {
@@ -206,14 +207,16 @@ static int read_subframe(BR* b, int64_t* s, int blocksize, int bps) {
     int rc = read_residual(b, s, blocksize, order);
     if (rc) return rc;
     for (int i = order; i < blocksize; ++i) {
-      int64_t sum = 0;
-      for (int j = 0; j < order; ++j) sum += (int64_t)coef[j] * s[i - 1 - j];
-      s[i] += sum >> shift;
+      /* wrapping arithmetic: a valid stream never overflows 64 bits here, a corrupt one must not be undefined
+         behaviour (its frame CRC / the MD5 reject it afterwards) */
+      uint64_t sum = 0;
+      for (int j = 0; j < order; ++j) sum += (uint64_t)(int64_t)coef[j] * (uint64_t)s[i - 1 - j];
+      s[i] = (int64_t)((uint64_t)s[i] + (uint64_t)((int64_t)sum >> shift));
     }
   } else {
     return FLAC_E_UNSUP;      /* reserved subframe types */
   }
-  if (wasted) for (int i = 0; i < blocksize; ++i) s[i] <<= wasted;
+  if (wasted) for (int i = 0; i < blocksize; ++i) s[i] = (int64_t)((uint64_t)s[i] << wasted);
   return b->eof ? FLAC_E_TRUNC : FLAC_OK;
 }
 
@@ -254,7 +257,10 @@ int wh_flac_decode(const uint8_t* data, size_t size, int32_t** samples_out, int6
   }
   if (!have_info || sr == 0 || max_block < 16 || bps < 4 || bps > 32) return FLAC_E_HEADER;
 
-  size_t cap = total ? (size_t)total : (size_t)1 << 20;
+  /* STREAMINFO's sample count sizes the output only as far as the file could possibly hold that much: a frame of
+     constant subframes packs 65535 samples per channel into ~16 bytes, nothing packs more; the buffer grows anyway */
+  size_t cap = (size_t)1 << 20;
+  if (total && total / 4096 <= (uint64_t)size) cap = (size_t)total;
   int32_t* out = (int32_t*)malloc(cap * ch * sizeof(int32_t));
   int64_t* work = (int64_t*)malloc((size_t)65536 * 8 * sizeof(int64_t));
   if (!out || !work) { free(out); free(work); return FLAC_E_MEM; }
@@ -321,7 +327,7 @@ int wh_flac_decode(const uint8_t* data, size_t size, int32_t** samples_out, int6
       if (ch_code == 8) w1[i] = w0[i] - w1[i];                       /* left, side  -> right = left - side */
       else if (ch_code == 9) w0[i] = w0[i] + w1[i];                  /* side, right -> left = right + side */
       else if (ch_code == 10) {                                      /* mid, side */
-        int64_t side = w1[i], mid = (w0[i] << 1) | (side & 1);
+        int64_t side = w1[i], mid = (int64_t)((uint64_t)w0[i] << 1) | (side & 1);
         w0[i] = (mid + side) >> 1; w1[i] = (mid - side) >> 1;
       }
     }
