@@ -573,3 +573,39 @@ def test_detect_language_host_logic_matches_reference(ref):
         mine.detect_language(_fake_model(False), torch.zeros(1500, 384), get_tokenizer(False))
     with pytest.raises(ValueError):
         ref.decoding.detect_language(_fake_model(False), torch.zeros(1500, 384), ref.tokenizer.get_tokenizer(False))
+
+
+def test_transcribe_batch_loads_files_concurrently(monkeypatch, tmp_path):
+    """paths given to transcribe_batch are decoded by a thread pool up front (same results as arrays, input order kept,
+    a failing file raises the loader's error)"""
+    import threading
+    import oracle
+    import whisper_amd  # noqa: F401
+    mine_tr = sys.modules["whisper_amd.transcribe"]
+    from whisper_amd import decoding as mine
+    from whisper_amd.tokenizer import get_tokenizer
+    tk = get_tokenizer(True, num_languages=99, language="en", task="transcribe")
+    filt = oracle.mel_filterbank(80)
+    monkeypatch.setattr(mine_tr, "log_mel_spectrogram",
+                        lambda a, n_mels=80, padding=0, device=None: oracle.log_mel_spectrogram(a, filt, padding=padding))
+    rng = np.random.default_rng(3)
+    arrays = {str(tmp_path / f"f{i}.wav"): (rng.standard_normal(16000 * n) * 0.01).astype(np.float32)
+              for i, n in enumerate((35, 50, 20, 64))}
+    seen = []
+
+    def fake_load(path, sr=16000):
+        seen.append((path, threading.get_ident()))
+        if path.endswith("missing.wav"):
+            raise RuntimeError(f"Failed to load audio: {path}")
+        return arrays[path]
+    monkeypatch.setattr(mine_tr, "load_audio", fake_load)
+    kw = dict(language="en", fp16=False, temperature=(0.0, 0.2, 0.4))
+    want = mine_tr.transcribe_batch(_FunctionalModel(mine.DecodingResult, tk), list(arrays.values()), **kw)
+    got = mine_tr.transcribe_batch(_FunctionalModel(mine.DecodingResult, tk), list(arrays), **kw)
+    assert [g["segments"] for g in got] == [w["segments"] for w in want]
+    assert sorted(p for p, _ in seen) == sorted(arrays) and threading.get_ident() not in {t for _, t in seen}
+    mixed = [list(arrays)[0], arrays[list(arrays)[1]], list(arrays)[2]]
+    got = mine_tr.transcribe_batch(_FunctionalModel(mine.DecodingResult, tk), mixed, **kw)
+    assert [g["text"] for g in got] == [w["text"] for w in want[:3]]
+    with pytest.raises(RuntimeError, match="Failed to load audio"):
+        mine_tr.transcribe_batch(_FunctionalModel(mine.DecodingResult, tk), list(arrays) + [str(tmp_path / "missing.wav")], **kw)

@@ -16,7 +16,8 @@ import numpy as np
 import torch
 import tqdm
 
-from .audio import FRAMES_PER_SECOND, HOP_LENGTH, N_FRAMES, N_SAMPLES, SAMPLE_RATE, log_mel_spectrogram, pad_or_trim
+from .audio import (FRAMES_PER_SECOND, HOP_LENGTH, N_FRAMES, N_SAMPLES, SAMPLE_RATE, load_audio, log_mel_spectrogram,
+                    pad_or_trim)
 from dataclasses import replace
 
 from .decoding import DecodingOptions, DecodingResult, DecodingTask
@@ -399,6 +400,21 @@ def _prompt_batches(model: "Whisper", options: DecodingOptions, prompts: List[Op
     return [rows[at: at + batch_size] for rows in classes.values() for at in range(0, len(rows), batch_size)]
 
 
+def _load_all(audios) -> list:
+    """decode the inputs that are file paths concurrently (ffmpeg subprocesses / the native FLAC decoder release the
+    GIL) instead of one after the other at the start of every file's state machine; arrays pass through untouched"""
+    paths = [i for i, a in enumerate(audios) if isinstance(a, str)]
+    out = list(audios)
+    if len(paths) < 2:
+        return out
+    from concurrent.futures import ThreadPoolExecutor
+    from .utils import usable_cores
+    with ThreadPoolExecutor(max(1, min(len(paths), usable_cores(), 16))) as pool:
+        for i, samples in zip(paths, pool.map(lambda i: load_audio(out[i]), paths)):
+            out[i] = samples
+    return out
+
+
 def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, **kwargs) -> List[dict]:
     """Transcribe several files at once (no counterpart in the reference, which is strictly
     one file at a time).  Every file keeps its own seek / prompt / fallback state machine exactly as `transcribe`;
@@ -418,6 +434,7 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, **kwargs
                     prepend_punctuations="\"'“¿([{-", append_punctuations="\"'.。,，!！?？:：”)]}、",
                     clip_timestamps="0", hallucination_silence_threshold=None)
     fixed = {k: kwargs.pop(k, defaults[k]) for k in names}
+    audios = _load_all(audios)
     workers = [_Transcriber(model, *[fixed[k] for k in names], dict(kwargs)) for _ in audios]
     walks = [w._walk(a) for w, a in zip(workers, audios)]
     results: List[Optional[dict]] = [None] * len(walks)
