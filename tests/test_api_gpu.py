@@ -133,6 +133,10 @@ def test_batched_beam_vs_oracle(setup, gpu_device):
             out = oracle.beam_decode(om, om.encoder(omel[None]), init, 8, rules, 3)
         body, lp = oracle.decoding.rank_candidates(out["candidates"][0], len(init), tok.eot)
         assert res.tokens == body, i
+    # ... and the live reference decoding each clip alone (tests/golden/make_golden_beam.py)
+    Bm = np.load(os.path.join(os.path.dirname(__file__), "golden", "beam_micro.npz"))
+    for i, res in enumerate(results):
+        assert res.tokens == [t for t in Bm[f"{key}_tokens"][i].tolist() if t >= 0], i
 
 
 def test_batch_invariance_fp16(setup, gpu_device):
