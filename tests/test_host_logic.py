@@ -609,3 +609,43 @@ def test_transcribe_batch_loads_files_concurrently(monkeypatch, tmp_path):
     assert [g["text"] for g in got] == [w["text"] for w in want[:3]]
     with pytest.raises(RuntimeError, match="Failed to load audio"):
         mine_tr.transcribe_batch(_FunctionalModel(mine.DecodingResult, tk), list(arrays) + [str(tmp_path / "missing.wav")], **kw)
+
+
+def test_loader_and_filter_error_conventions(ref, tmp_path):
+    """the error behaviour of the entry points a caller can hit without a GPU: unknown model name and
+    checksum mismatch -> RuntimeError (whisper/__init__.py:143-145, 66-93), unsupported n_mels -> AssertionError
+    (audio.py:103), with the reference raising the same type on the same input; a cached file with the right digest
+    is reused without touching the network, a wrong one is re-fetched (here from a file:// URL)"""
+    import hashlib
+    import whisper_amd
+    from whisper_amd import audio as mine_audio
+    with pytest.raises(RuntimeError, match="not found; available models"):
+        whisper_amd.load_model("no-such-model", device="cpu")
+    with pytest.raises(RuntimeError, match="not found; available models"):
+        ref.load_model("no-such-model", device="cpu")
+    assert whisper_amd.available_models() == ref.available_models()
+    for fn in (lambda: mine_audio.mel_filters("cpu", 64), lambda: ref.audio.mel_filters("cpu", 64)):
+        with pytest.raises(AssertionError, match="Unsupported n_mels"):
+            fn()
+
+    payload = b"checkpoint bytes " * 1000
+    digest = hashlib.sha256(payload).hexdigest()
+    src = tmp_path / "srv" / digest
+    src.mkdir(parents=True)
+    (src / "tiny.pt").write_bytes(payload)
+    url = f"file://{src}/tiny.pt"
+    root = tmp_path / "cache"
+    got = whisper_amd._fetch(url, str(root), in_memory=False)                     # fetched and verified
+    assert got == str(root / "tiny.pt") and (root / "tiny.pt").read_bytes() == payload
+    assert whisper_amd._fetch(url, str(root), in_memory=True) == payload           # cached copy, right digest
+    (root / "tiny.pt").write_bytes(b"corrupted")
+    with pytest.warns(UserWarning, match="checksum does not match"):
+        assert whisper_amd._fetch(url, str(root), in_memory=True) == payload       # re-fetched
+    bad = tmp_path / "srv" / ("0" * 64)
+    bad.mkdir()
+    (bad / "base.pt").write_bytes(payload)
+    with pytest.raises(RuntimeError, match="checksum does not not match"):
+        whisper_amd._fetch(f"file://{bad}/base.pt", str(root), in_memory=False)
+    (root / "dir.pt").mkdir()
+    with pytest.raises(RuntimeError, match="not a regular file"):
+        whisper_amd._fetch(f"file://{src}/dir.pt", str(root), in_memory=False)
