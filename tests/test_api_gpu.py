@@ -428,3 +428,33 @@ def test_device_sampling(setup, gpu_device):
         n = len(draws)
         assert n == 384 and len(set(draws)) > 8
         assert abs(np.mean(draws) - mean) < 5.0 * np.sqrt(var / n) + 1e-3, (T, np.mean(draws), mean, var)
+
+
+def test_incremental_decoder_with_kv_cache_hooks(setup, gpu_device):
+    """model.install_kv_cache_hooks() + model.decoder(tokens, xa, kv_cache=cache) (reference model.py:227-249, 310-341):
+    feeding the tokens incrementally — 3 at first, then one at a time — returns, for every token fed, the logits of
+    one teacher-forced pass over the whole sequence (fp32 engine; GEMM prefill vs GEMV step kernels: 5e-3 on logits
+    of order 1), and remove() releases the task"""
+    from whisper_amd import model as mm
+    key, dims, sd, model, mel = setup
+    feats = model.encoder(mel[None].float())
+    tok = get_tokenizer(dims.n_vocab >= 51865, num_languages=dims.n_vocab - 51765 - int(dims.n_vocab >= 51865),
+                        language="en", task="transcribe")
+    rng = np.random.default_rng(12)
+    rows = [list(tok.sot_sequence) + rng.integers(300, 40000, 9).tolist() for _ in range(2)]
+    toks = torch.tensor(rows, device=gpu_device)
+    T = toks.shape[1]
+    full = model.decoder(toks, feats)                                  # (2, T, V), one pass
+    cache, hooks = model.install_kv_cache_hooks()
+    parts = [model.decoder(toks[:, :3], feats, kv_cache=cache)]
+    for at in range(3, T):
+        parts.append(model.decoder(toks[:, at: at + 1], feats, kv_cache=cache))
+    inc = torch.cat(parts, dim=1)
+    assert inc.shape == full.shape
+    assert (inc - full).abs().max().item() < 5e-3
+    assert inc.argmax(-1).tolist() == full.argmax(-1).tolist()
+    task = cache[mm._TASK_KEY]
+    assert task.position == T
+    for h in hooks:
+        h.remove()
+    assert mm._TASK_KEY not in cache and task.handle is None

@@ -649,3 +649,56 @@ def test_loader_and_filter_error_conventions(ref, tmp_path):
     (root / "dir.pt").mkdir()
     with pytest.raises(RuntimeError, match="not a regular file"):
         whisper_amd._fetch(f"file://{src}/dir.pt", str(root), in_memory=False)
+
+
+def test_kv_cache_hooks_surface(monkeypatch):
+    """Whisper.install_kv_cache_hooks / model.decoder(..., kv_cache=) keep the reference's calling convention
+    (model.py:227-249, 310-341): first call feeds every token, later calls the new ones, logits for every token fed,
+    hook.remove() releases the cache.  The device task is replaced by a recorder here; the GPU test
+    tests/test_api_gpu.py::test_incremental_decoder_with_kv_cache_hooks checks the numbers."""
+    from whisper_amd import model as mm
+    calls = []
+
+    class FakeTask:
+        def __init__(self, engine, n_audio, group, max_prefill):
+            calls.append(("create", n_audio, group, max_prefill))
+            self.position, self.closed = 0, False
+
+        def set_audio(self, xa):
+            calls.append(("audio", tuple(xa.shape)))
+
+        def prefill(self, x):
+            calls.append(("prefill", tuple(x.shape)))
+            self.position += x.shape[1]
+            return torch.zeros(x.shape[0], x.shape[1], 7)
+
+        def step(self, last):
+            calls.append(("step", tuple(last.shape)))
+            self.position += 1
+            return torch.zeros(last.shape[0], 7)
+
+        def close(self):
+            self.closed = True
+            calls.append(("close",))
+    monkeypatch.setattr(mm.hip, "HipTask", FakeTask)
+    fm = _fake_model(True)
+    model = mm.Whisper(mm.ModelDimensions(**fm.dims.__dict__), {}, device="cpu")
+    monkeypatch.setattr(model, "engine", lambda dtype: object())
+    cache, hooks = model.install_kv_cache_hooks()
+    assert isinstance(cache, dict) and len(hooks) == 1
+    xa = torch.zeros(2, 1500, 384)
+    toks = torch.tensor([[1, 2, 3]] * 4)
+    assert model.decoder(toks, xa, kv_cache=cache).shape == (4, 3, 7)
+    assert model.decoder(toks[:, -1:], xa, kv_cache=cache).shape == (4, 1, 7)
+    assert model.decoder(toks[:, :2], xa, kv_cache=cache).shape == (4, 2, 7)          # several new tokens at once
+    task = cache[mm._TASK_KEY]
+    for h in hooks:
+        h.remove()
+    assert task.closed and mm._TASK_KEY not in cache
+    assert calls == [("create", 2, 2, 448), ("audio", (2, 1500, 384)), ("prefill", (4, 3)), ("step", (4,)),
+                     ("prefill", (4, 2)), ("close",)]
+    with pytest.raises(NotImplementedError):
+        model.decoder(toks, xa, kv_cache={"foreign": torch.zeros(1)})
+    user = {"note": 1}
+    cache2, hooks2 = model.install_kv_cache_hooks(user)
+    assert cache2 is not user and cache2["note"] == 1                                   # copied, as the reference does

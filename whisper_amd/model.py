@@ -59,19 +59,53 @@ class _EncoderHandle:
     forward = __call__
 
 
+_TASK_KEY = "_wh_task"       # entry of a kv_cache dict made by Whisper.install_kv_cache_hooks: the wh_task holding the caches
+
+
+class _CacheHook:
+    """what install_kv_cache_hooks returns in place of torch's RemovableHandle: remove() frees the device caches"""
+
+    def __init__(self, cache: dict):
+        self._cache = cache
+
+    def remove(self) -> None:
+        task = self._cache.pop(_TASK_KEY, None)
+        if task is not None:
+            task.close()
+
+
 class _DecoderHandle:
-    """callable `model.decoder` (TextDecoder.forward, reference model.py:227-249) for teacher-forced passes.
-    Incremental decoding goes through decoding.HipInference (the KV cache lives in a wh_task, not in a dict of
-    module outputs), so a non-empty `kv_cache` is rejected."""
+    """callable `model.decoder` (TextDecoder.forward, reference model.py:227-249).  Without a cache: one teacher-forced
+    pass.  With the dict returned by `model.install_kv_cache_hooks()`: incremental decoding as in the reference — the
+    first call feeds all tokens, later calls only the new ones (model.py:234 `offset`), logits come back for every
+    token fed — except that the keys / values live in a wh_task on the device, not as tensors in the dict."""
 
     def __init__(self, owner: "Whisper"):
         self._owner = owner
 
-    def __call__(self, x: Tensor, xa: Tensor, kv_cache: Optional[dict] = None) -> Tensor:
-        if kv_cache:
-            raise NotImplementedError("whisper_amd keeps KV caches inside HipInference / wh_task; "
-                                      "hook-based kv_cache dicts are not supported")
+    def _incremental(self, x: Tensor, xa: Tensor, kv_cache: dict) -> Tensor:
         owner = self._owner
+        task = kv_cache[_TASK_KEY]
+        if task is None:
+            engine = owner.engine(xa.dtype)
+            n_rows, n_audio = x.shape[0], xa.shape[0]
+            if n_rows % n_audio != 0:
+                raise ValueError("token rows must be a multiple of the audio batch")
+            task = hip.HipTask(engine, n_audio, n_rows // n_audio, owner.dims.n_text_ctx)
+            task.set_audio(xa.contiguous())
+            kv_cache[_TASK_KEY] = task
+        if task.position == 0 or x.shape[1] > 1:
+            return task.prefill(x.contiguous().long())
+        return task.step(x[:, -1].long())[:, None]
+
+    def __call__(self, x: Tensor, xa: Tensor, kv_cache: Optional[dict] = None) -> Tensor:
+        owner = self._owner
+        if kv_cache is not None and _TASK_KEY in kv_cache:
+            x, xa = x.to(owner.device), xa.to(owner.device)
+            return self._incremental(x[None] if x.dim() == 1 else x, xa[None] if xa.dim() == 2 else xa, kv_cache)
+        if kv_cache:
+            raise NotImplementedError("a kv_cache dict must come from model.install_kv_cache_hooks(): the keys and "
+                                      "values are kept in a wh_task on the device, not as tensors in the dict")
         x = x.to(owner.device)
         xa = xa.to(owner.device)
         if x.dim() == 1:
@@ -169,7 +203,12 @@ class Whisper:
         return self.dims.n_vocab - 51765 - int(self.is_multilingual)
 
     def install_kv_cache_hooks(self, cache: Optional[dict] = None):
-        raise NotImplementedError("no nn.Module hooks here: KV caching is done by decoding.HipInference (wh_task)")
+        """(cache, hooks) as reference model.py:310-341: pass `cache` to `model.decoder(tokens, xa, kv_cache=cache)` to
+        decode incrementally; `hook.remove()` on every returned hook releases the caches.  There are no nn.Module
+        hooks underneath — the dict only carries the handle of the wh_task that owns the device-side K/V."""
+        cache = {**cache} if cache is not None else {}
+        cache[_TASK_KEY] = None
+        return cache, [_CacheHook(cache)]
 
     detect_language = detect_language_function
     transcribe = transcribe_function
