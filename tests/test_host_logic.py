@@ -702,3 +702,49 @@ def test_kv_cache_hooks_surface(monkeypatch):
     user = {"note": 1}
     cache2, hooks2 = model.install_kv_cache_hooks(user)
     assert cache2 is not user and cache2["note"] == 1                                   # copied, as the reference does
+
+
+def test_api_surface_matches_reference(ref):
+    """the names a caller of openai/whisper touches exist here with the same parameters, defaults and
+    dataclass fields (extra keyword parameters of ours — `prompts`, `transcribe_batch` — are additions, never renames)"""
+    import dataclasses
+    import inspect
+    import whisper_amd as mine
+
+    def fields(cls):
+        return [(f.name, f.default) for f in dataclasses.fields(cls)]
+    assert fields(mine.DecodingOptions) == fields(ref.DecodingOptions)
+    assert fields(mine.DecodingResult) == fields(ref.DecodingResult)
+    assert fields(mine.ModelDimensions) == fields(ref.ModelDimensions)
+
+    def params(fn):
+        def plain(v):
+            return dataclasses.asdict(v) if dataclasses.is_dataclass(v) and not isinstance(v, type) else v
+        return [(p.name, plain(p.default), p.kind) for p in inspect.signature(fn).parameters.values()]
+    for name in ("transcribe", "load_model", "pad_or_trim", "load_audio", "log_mel_spectrogram", "available_models",
+                 "detect_language"):
+        assert params(getattr(mine, name)) == params(getattr(ref, name)), name
+    theirs, ours = params(ref.decode), params(mine.decode)
+    assert [p for p in ours if p[0] != "prompts"] == theirs                       # + our per-segment prompts
+    for attr in ("dims", "device", "is_multilingual", "num_languages", "encoder", "decoder", "logits", "embed_audio",
+                 "alignment_heads", "set_alignment_heads", "install_kv_cache_hooks", "transcribe", "decode",
+                 "detect_language", "forward"):
+        assert hasattr(ref.model.Whisper, attr) or attr in ("dims", "encoder", "decoder", "alignment_heads"), attr
+    fm = _fake_model(True)
+    m = mine.Whisper(mine.ModelDimensions(**fm.dims.__dict__), {}, device="cpu")
+    for attr in ("dims", "device", "is_multilingual", "num_languages", "encoder", "decoder", "logits", "embed_audio",
+                 "alignment_heads", "set_alignment_heads", "install_kv_cache_hooks", "transcribe", "decode",
+                 "detect_language", "forward"):
+        assert hasattr(m, attr), attr
+    assert m.is_multilingual and m.num_languages == 99 and m.device == torch.device("cpu")
+    # alignment heads: default = upper half of the decoder layers (model.py:270-276); dumps decode like the reference's
+    dense = m.alignment_heads.to_dense()
+    assert dense.shape == (fm.dims.n_text_layer, fm.dims.n_text_head) and bool(dense[fm.dims.n_text_layer // 2:].all())
+    assert not bool(dense[: fm.dims.n_text_layer // 2].any())
+    from whisper_amd.registry import ALIGNMENT_HEADS, MODEL_URLS
+    assert MODEL_URLS == ref._MODELS and ALIGNMENT_HEADS == ref._ALIGNMENT_HEADS
+    import base64
+    import gzip
+    for name, (layers, heads) in (("tiny.en", (4, 6)), ("large-v3", (32, 20)), ("turbo", (4, 20))):
+        mask = np.frombuffer(gzip.decompress(base64.b85decode(ALIGNMENT_HEADS[name])), dtype=bool)
+        assert mask.size == layers * heads and mask.sum() == {"tiny.en": 8, "large-v3": 10, "turbo": 6}[name]   # SURVEY App. A
