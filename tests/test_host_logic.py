@@ -286,12 +286,23 @@ class _FunctionalModel:
         fm = _fake_model(True)
         self.dims, self.is_multilingual, self.num_languages, self.device = fm.dims, fm.is_multilingual, fm.num_languages, fm.device
         self.decoder = fm.decoder
-        self.result_cls, self.tk, self.calls = result_cls, tokenizer, []
+        self.result_cls, self.tk, self.calls, self.detect_calls = result_cls, tokenizer, [], []
+
+    def detect_language(self, mel):
+        """language from the content of the first window: single (n_mels, 3000) or batched"""
+        single = mel.ndim == 2
+        mels = mel[None] if single else mel
+        self.detect_calls.append(mels.shape[0])
+        langs = [("en", "de", "fr")[int(abs(float(m.double().sum())) * 1000) % 3] for m in mels]
+        probs = [{c: (0.9 if c == lang else 0.05) for c in ("en", "de", "fr")} for lang in langs]
+        toks = torch.tensor([self.tk.to_language_token(lang) for lang in langs])
+        return (toks[0], probs[0]) if single else (toks, probs)
 
     def _one(self, mel, options, prompt):
         key = int(abs(float(mel.double().sum())) * 1000) % 9973
         TB = self.tk.timestamp_begin
-        words = self.tk.encode(" " + " ".join(["alpha", "bravo", "charlie", "delta", "echo"][: 1 + key % 5]))
+        words = self.tk.encode(" " + " ".join(["alpha", "bravo", "charlie", "delta", "echo"][: 1 + key % 5])
+                               + {"en": "", "de": " und", "fr": " et", None: " ?"}[options.language])
         need = (0.0, 0.0, 0.2, 0.4, 0.2)[key % 5]                    # lowest temperature at which this window is fine
         ok = options.temperature >= need - 1e-9
         toks = [TB, *words, TB + 100 + key % 400, TB + 100 + key % 400, *words[: 1 + (len(prompt or ()) % 2)], TB + 700]
@@ -748,3 +759,33 @@ def test_api_surface_matches_reference(ref):
     for name, (layers, heads) in (("tiny.en", (4, 6)), ("large-v3", (32, 20)), ("turbo", (4, 20))):
         mask = np.frombuffer(gzip.decompress(base64.b85decode(ALIGNMENT_HEADS[name])), dtype=bool)
         assert mask.size == layers * heads and mask.sum() == {"tiny.en": 8, "large-v3": 10, "turbo": 6}[name]
+
+
+def test_transcribe_batch_detects_languages_in_one_pass(monkeypatch):
+    """without `language`, transcribe_batch identifies the language of all files in batched passes (transcribe.py:139-152
+    does it file by file); every file then decodes exactly as `transcribe` decodes it"""
+    import oracle
+    import whisper_amd  # noqa: F401
+    mine_tr = sys.modules["whisper_amd.transcribe"]
+    from whisper_amd import decoding as mine
+    from whisper_amd.tokenizer import get_tokenizer
+    tk = get_tokenizer(True, num_languages=99, language="en", task="transcribe")
+    filt = oracle.mel_filterbank(80)
+    monkeypatch.setattr(mine_tr, "log_mel_spectrogram",
+                        lambda a, n_mels=80, padding=0, device=None: oracle.log_mel_spectrogram(a, filt, padding=padding))
+    rng = np.random.default_rng(6)
+    files = [(rng.standard_normal(16000 * n) * 0.01).astype(np.float32) for n in (33, 41, 25, 58, 36, 30, 47)]
+    kw = dict(fp16=False, temperature=(0.0, 0.2, 0.4), verbose=None)
+    ma, mb = _FunctionalModel(mine.DecodingResult, tk), _FunctionalModel(mine.DecodingResult, tk)
+    want = [mine_tr.transcribe(ma, a, **kw) for a in files]
+    got = mine_tr.transcribe_batch(mb, files, batch_size=4, **kw)
+    assert [g["language"] for g in got] == [w["language"] for w in want] and len({w["language"] for w in want}) >= 2
+    assert [g["segments"] for g in got] == [w["segments"] for w in want]
+    assert ma.detect_calls == [1] * len(files) and mb.detect_calls == [4, 3]
+    # a given language switches detection off, a single file keeps the reference's own flow
+    mc = _FunctionalModel(mine.DecodingResult, tk)
+    mine_tr.transcribe_batch(mc, files[:3], language="de", **kw)
+    assert mc.detect_calls == []
+    md = _FunctionalModel(mine.DecodingResult, tk)
+    mine_tr.transcribe_batch(md, files[:1], **kw)
+    assert md.detect_calls == [1]

@@ -121,7 +121,7 @@ class _Transcriber:
         except StopIteration as stop:
             return stop.value
 
-    def _walk(self, audio):
+    def _walk(self, audio, mel: Optional[torch.Tensor] = None):
         """The per-file state machine of reference transcribe.py:126-514 as a generator: yields the next 30 s mel
         window to decode (with `self.decode_options["prompt"]` already set for it) and is sent its DecodingResult;
         returns the result dict.  `run` drives one file; `transcribe_batch` drives many files in lock-step so that
@@ -138,7 +138,8 @@ class _Transcriber:
             opts["fp16"] = False
 
         # whole-file spectrogram with 30 s of trailing silence so every window can be sliced
-        mel = log_mel_spectrogram(audio, model.dims.n_mels, padding=N_SAMPLES, device=model.device)
+        if mel is None:
+            mel = log_mel_spectrogram(audio, model.dims.n_mels, padding=N_SAMPLES, device=model.device)
         content_frames = mel.shape[-1] - N_FRAMES
         content_duration = float(content_frames * HOP_LENGTH / SAMPLE_RATE)
 
@@ -436,7 +437,20 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, **kwargs
     fixed = {k: kwargs.pop(k, defaults[k]) for k in names}
     audios = _load_all(audios)
     workers = [_Transcriber(model, *[fixed[k] for k in names], dict(kwargs)) for _ in audios]
-    walks = [w._walk(a) for w, a in zip(workers, audios)]
+    mels = [None] * len(audios)
+    if kwargs.get("language") is None and model.is_multilingual and len(audios) > 1:
+        # language identification (transcribe.py:139-152) for all files in batched passes instead of one encoder pass +
+        # one decoder step per file; every state machine then starts with its language set, as if it had been given
+        dtype = torch.float16 if kwargs.get("fp16", True) and model.device != torch.device("cpu") else torch.float32
+        mels = [log_mel_spectrogram(a, model.dims.n_mels, padding=N_SAMPLES, device=model.device) for a in audios]
+        for at in range(0, len(mels), batch_size):
+            heads = torch.stack([pad_or_trim(m, N_FRAMES).to(model.device).to(dtype) for m in mels[at: at + batch_size]])
+            _, probs = model.detect_language(heads)
+            for w, p in zip(workers[at: at + batch_size], probs):
+                w.decode_options["language"] = max(p, key=p.get)
+                if fixed["verbose"] is not None:
+                    print(f"Detected language: {LANGUAGES[w.decode_options['language']].title()}")
+    walks = [w._walk(a, m) for w, a, m in zip(workers, audios, mels)]
     results: List[Optional[dict]] = [None] * len(walks)
     pending = {}
 
