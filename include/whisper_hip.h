@@ -84,7 +84,17 @@ typedef struct wh_model_weights {
   const float *dec_pos;
   const wh_layer_weights *dec_layers;   /* n_text_layer entries (host array) */
   const float *dec_ln_w, *dec_ln_b;
+  uint32_t flags;                       /* WH_WEIGHTS_* */
 } wh_model_weights;
+
+/* wh_model_weights.flags
+ * WH_WEIGHTS_DEC_LN_FOLDED: in every DECODER block the affine part of attn_ln / cross_attn_ln / mlp_ln
+ *   (whisper/model.py:39-41,150-157) has been folded into the Linear that consumes it,
+ *     W (g * xhat + beta) + b == (W * g) xhat + (b + W beta),
+ *   i.e. qkv_w/qkv_b, cq_w/cq_b, fc1_w/fc1_b already contain it and the stored ln_w / ln_b are (1, 0).  The decode-step
+ *   projections then normalise in registers without reading gamma / beta.  decoder.ln (tied to the token embedding)
+ *   and the encoder are never folded.  whisper_amd.hip.pack_weights does this for WH_F16 blobs. */
+#define WH_WEIGHTS_DEC_LN_FOLDED 1u
 
 typedef struct wh_model wh_model;   /* opaque: dims + copies of the pointer tables */
 typedef struct wh_task wh_task;     /* opaque: per-DecodingTask KV caches + workspace carve-up */

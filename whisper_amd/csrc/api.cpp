@@ -448,7 +448,7 @@ static const int SKINNY_ROWS = 48;
 static hipError_t proj_ln(const wh_model* m, const float* x, int rows, const float* ln_w, const float* ln_b, const void* W,
                           const float* bias, int N, int K, void* y, int64_t y_ld, bool gelu, hipStream_t s) {
   GemvArgs g; memset(&g, 0, sizeof(g));
-  g.pro = PRO_LN; g.xf = x; g.xf_ld = K; g.ln_w = ln_w; g.ln_b = ln_b;
+  g.pro = PRO_LN; g.xf = x; g.xf_ld = K; g.ln_w = ln_w; g.ln_b = ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
   g.W = W; g.bias = bias; g.N = N; g.K = K; g.R = rows;
   g.epi = gelu ? EPI_GELU : EPI_STORE; g.y = y; g.y_ld = y_ld;
   return launch_gemv(g, m->dtype, s);
@@ -604,7 +604,7 @@ static int step_launch(wh_task* t, hipStream_t s) {
     GemvArgs g;
     // LN -> QKV, K/V appended in place at *d_pos
     memset(&g, 0, sizeof(g));
-    g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.attn_ln_w; g.ln_b = L.attn_ln_b;
+    g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.attn_ln_w; g.ln_b = L.attn_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
     g.W = L.qkv_w; g.bias = L.qkv_b; g.N = 3 * D; g.K = D; g.R = R;
     g.epi = EPI_QKV; g.y = t->qbuf; g.y_ld = D;
     g.kcache = self_k_layer(t, l); g.vcache = self_v_layer(t, l); g.cache_bs = (int64_t)C * D; g.d_pos = t->d_pos; g.D = D;
@@ -631,7 +631,7 @@ static int step_launch(wh_task* t, hipStream_t s) {
     HIPCHK(launch_gemv(g, m->dtype, s));
     // LN -> cross query
     memset(&g, 0, sizeof(g));
-    g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.cross_ln_w; g.ln_b = L.cross_ln_b;
+    g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.cross_ln_w; g.ln_b = L.cross_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
     g.W = L.cq_w; g.bias = L.cq_b; g.N = D; g.K = D; g.R = R;
     g.epi = EPI_STORE; g.y = t->qbuf; g.y_ld = D;
     HIPCHK(launch_gemv(g, m->dtype, s));
@@ -655,7 +655,7 @@ static int step_launch(wh_task* t, hipStream_t s) {
     HIPCHK(launch_gemv(g, m->dtype, s));
     // LN -> MLP
     memset(&g, 0, sizeof(g));
-    g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.mlp_ln_w; g.ln_b = L.mlp_ln_b;
+    g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.mlp_ln_w; g.ln_b = L.mlp_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
     g.W = L.fc1_w; g.bias = L.fc1_b; g.N = 4 * D; g.K = D; g.R = R;
     g.epi = EPI_GELU; g.y = t->h; g.y_ld = 4 * D;
     HIPCHK(launch_gemv(g, m->dtype, s));
@@ -944,14 +944,14 @@ extern "C" int wh_task_bench_kernel(wh_task* t, int kind, int iters, double* byt
         bytes = (double)R * t->pos * 2.0 * D * es;
       } break;
       case 3:
-        g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.attn_ln_w; g.ln_b = L.attn_ln_b;
+        g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.attn_ln_w; g.ln_b = L.attn_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
         g.W = L.qkv_w; g.bias = L.qkv_b; g.N = 3 * D; g.K = D; g.R = R;
         g.epi = EPI_STORE; g.y = t->qkv; g.y_ld = 3 * D;
         HIPCHK(launch_gemv(g, m->dtype, s));
         bytes = 3.0 * D * D * es;
         break;
       case 4:
-        g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.mlp_ln_w; g.ln_b = L.mlp_ln_b;
+        g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.mlp_ln_w; g.ln_b = L.mlp_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
         g.W = L.fc1_w; g.bias = L.fc1_b; g.N = 4 * D; g.K = D; g.R = R;
         g.epi = EPI_GELU; g.y = t->h; g.y_ld = 4 * D;
         HIPCHK(launch_gemv(g, m->dtype, s));

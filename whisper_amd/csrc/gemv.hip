@@ -27,6 +27,7 @@
 //                  residual add | exact GELU | fp32 logits.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -731,6 +732,315 @@ hipError_t launch_stream(const whk::GemvArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// R <= 8 rows, fp16 — the decode step proper (batch of 8 clips): MFMA "diagonal" form, no LDS staging of x rows.
+//
+// tools/probe_floor showed that a dependent launch which only streams a D x D matrix and reduces costs 2.9 us
+// (3.3 MB, 160 workgroups), while the v_dot2 kernels above take 5.0-6.7 us for the same bytes: the gap is the
+// per-wave instruction chain (32 v_dot2 + 8 ds_read_b128 per 16 bytes of weights per lane) and the 40 KB x block every
+// workgroup pushes through the texture addresser and LDS.  Here one v_mfma_f32_16x16x32_f16 consumes a whole
+// wave-load (64 lanes x 16 B of weights), and the x operand is loaded from global memory directly in fragment layout
+// (each wave reads only the K range it multiplies with), so a projection is: loads -> (LayerNorm statistics) ->
+// NU MFMAs -> one LDS exchange of 64 partial sums per wave -> epilogue.
+//
+// Fragment map.  A 16x16x32 MFMA wants 16 A rows x 32 k; with 16 distinct weight rows a wave-load would be 16 rows x
+// 64 B — half cache lines.  Instead the 16 A rows are 8 weight rows x 2 halves of a 64-element K block, and the 16 B
+// columns are the 8 batch rows x the same 2 halves: lane l = 16 c + 8 half + i holds weight row i (A) / batch row i
+// (B), elements [64 blk + 32 half + 8 c, +8).  A wave-load is then 8 weight rows x 128 contiguous bytes, and of the
+// 16 x 16 products only the two diagonal 8 x 8 blocks (same half on both sides) are meaningful:
+// y[n][r] = C[n][r] + C[8 + n][8 + r].  Off-diagonal lanes are zeroed and the pair is summed with one DPP row_ror:8
+// and one v_permlane32_swap.  Half of the MFMA work is discarded — irrelevant next to the HBM stream.
+//
+// LayerNorm is applied to the fragments in registers: a wave holds, for each of the 8 rows, the K range it multiplies;
+// per-wave (mean, M2) are merged across the KS waves with Chan's formula through 64 floats of LDS.  The LayerNorm
+// weight / bias are folded into the projection at load time (WH_WEIGHTS_DEC_LN_FOLDED, whisper_hip.h), so the
+// prologue is (x - mean) * rstd.
+//
+// Workgroup = GS feature-group slots x KS splits of K (WAVES = GS * KS).  With GS > 1 only the KS waves of slot 0
+// build the x fragments; they publish them to LDS in fragment order (lane-linear 16-byte units: conflict-free both
+// ways) while the other slots — which issued their weight loads at once — wait at the barrier.
+// CSm: PRO_COMBINE — exactly the number of attention splits (2..4), so that no partial is requested twice.
+// ---------------------------------------------------------------------------------------------------------------
+template <int PRO, int WAVES, int GS, int NU, int CSm>
+__global__ __launch_bounds__(WAVES * 64) void gemv8_kernel(whk::GemvArgs a) {
+  pin_kernargs(a);
+  constexpr int KS = WAVES / GS;
+  constexpr bool SHARE = GS > 1;
+  __shared__ float red[WAVES][8][8];        // [wave][feature][row] partial sums
+  __shared__ float2v stat[KS][8];           // PRO_LN: per-wave (mean, M2) of every row
+  __shared__ __attribute__((aligned(16))) half8v xfrag[SHARE ? KS * NU * 64 : 1];   // [kw][u][lane]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = wave / KS, kw = wave % KS;
+  const int c = lane >> 4, half = (lane >> 3) & 1, idx = lane & 7;
+  const int koff = half * 32 + c * 8;
+  const int K = a.K, nblk = K >> 6;
+  const int r0 = blockIdx.y * 8;
+  int R = a.R - r0; if (R > 8) R = 8;
+  const int ngroups = (a.N + 7) >> 3;
+  const int g = blockIdx.x * GS + slot;
+  const int row = r0 + (idx < R ? idx : R - 1);            // padded rows re-read a valid row; their outputs are dropped
+  const bool xwave = !SHARE || slot == 0;                  // wave-uniform
+
+  // epilogue operands, requested first (L2 hits): thread -> (slot, row, feature)
+  const int es = tid >> 6, er = (tid >> 3) & 7, ej = tid & 7;
+  const int en = (blockIdx.x * GS + es) * 8 + ej;
+  const bool e_on = es < GS && er < R && en < a.N;
+  float e_bias = 0.f, e_res = 0.f;
+  int e_lag = 0, e_pos = 0;
+  if (a.epi == whk::EPI_QKV) e_pos = load_agent_int(a.d_pos);
+  if (e_on) {
+    if (a.epi == whk::EPI_QKV && a.lag) e_lag = a.lag[r0 + er];
+    if (a.bias) e_bias = a.bias[en];
+    if (a.epi == whk::EPI_RESID) e_res = a.resid[(int64_t)(r0 + er) * a.resid_ld + en];
+  }
+
+  half8v xb[NU], wa[NU];
+  float4v xf[PRO == whk::PRO_LN ? NU : 1][2];
+  float4v po[PRO == whk::PRO_COMBINE ? NU : 1][CSm][2];
+  float2v pml[PRO == whk::PRO_COMBINE ? NU : 1][CSm];
+
+  auto load_weights = [&]() {      // the wave's share of the weight tile: 8 rows x 128 contiguous bytes per wave-load
+    int n = g * 8 + idx; if (n > a.N - 1) n = a.N - 1;
+    const half_t* wrow = (const half_t*)a.W + (int64_t)n * K + koff;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      int blk = kw + KS * u; if (blk > nblk - 1) blk = nblk - 1;          // branch-free: clamped, masked through x == 0
+      wa[u] = __builtin_nontemporal_load((const half8v*)(wrow + blk * 64));
+    }
+  };
+
+  if (xwave) {
+    // x fragments first (L2 hits, the prologue arithmetic needs them first), then the weights
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      int blk = kw + KS * u; if (blk > nblk - 1) blk = nblk - 1;
+      if (PRO == whk::PRO_PLAIN) {
+        xb[u] = *(const half8v*)((const half_t*)a.x + (int64_t)row * a.x_ld + blk * 64 + koff);
+      } else if (PRO == whk::PRO_LN) {
+        const float* src = a.xf + (int64_t)row * a.xf_ld + blk * 64 + koff;
+        xf[u][0] = *(const float4v*)src;
+        xf[u][1] = *(const float4v*)(src + 4);
+      } else {
+        const int64_t pb = ((int64_t)row * a.H + blk) * CSm;               // block == head
+#pragma unroll
+        for (int s = 0; s < CSm; ++s) {
+          pml[u][s] = *(const float2v*)(a.part_ml + (pb + s) * 2);
+          po[u][s][0] = *(const float4v*)(a.part_o + (pb + s) * 64 + koff);
+          po[u][s][1] = *(const float4v*)(a.part_o + (pb + s) * 64 + koff + 4);
+        }
+      }
+    }
+    ISSUE_FENCE();
+  }
+  load_weights();
+  ISSUE_FENCE();
+
+  // ---- prologue arithmetic on the fragments (slot 0, or every wave when GS == 1)
+  if (PRO == whk::PRO_LN) {
+    float mean_w = 0.f, m2 = 0.f;
+    if (xwave) {
+      int nvalid = 0;
+      float sum = 0.f;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const bool on = kw + KS * u < nblk;
+        nvalid += on ? 1 : 0;
+        const float t = ((xf[u][0][0] + xf[u][0][1]) + (xf[u][0][2] + xf[u][0][3])) + ((xf[u][1][0] + xf[u][1][1]) + (xf[u][1][2] + xf[u][1][3]));
+        sum += on ? t : 0.f;
+      }
+      const float cnt = 64.f * (float)nvalid;                  // elements of a row held by this wave
+      mean_w = nvalid ? across_groups8_sum(sum) / cnt : 0.f;   // lanes sharing (lane & 7) hold one row
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (kw + KS * u < nblk) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = xf[u][e >> 2][e & 3] - mean_w; m2 = __builtin_fmaf(d, d, m2); }
+        }
+      }
+      m2 = across_groups8_sum(m2);
+      if (lane < 8) stat[kw][lane] = float2v{mean_w, m2};
+    }
+    __syncthreads();
+    if (xwave) {
+      // merge the KS waves (Chan et al.): mean = sum cnt_k mean_k / K, M2 = sum M2_k + cnt_k (mean_k - mean)^2
+      float mean = 0.f;
+      float2v st[KS];
+      float cntk[KS];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        st[k] = stat[k][idx];
+        int nv = 0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) nv += (k + KS * u < nblk) ? 1 : 0;
+        cntk[k] = 64.f * (float)nv;
+        mean = __builtin_fmaf(st[k][0], cntk[k], mean);
+      }
+      const float invK = 1.0f / (float)K;
+      mean *= invK;
+      float M2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        const float d = st[k][0] - mean;
+        M2 += st[k][1] + cntk[k] * d * d;
+      }
+      const float rstd = rsqrtf(M2 * invK + 1e-5f);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const bool on = kw + KS * u < nblk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = (xf[u][e >> 2][e & 3] - mean) * rstd;
+          xb[u][e] = on ? (half_t)v : (half_t)0.f;
+        }
+      }
+    }
+  } else if (PRO == whk::PRO_COMBINE) {
+    if (xwave) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const bool on = kw + KS * u < nblk;
+        float M = pml[u][0][0];
+#pragma unroll
+        for (int s = 1; s < CSm; ++s) M = fmaxf(M, pml[u][s][0]);
+        float w[CSm], den = 0.f;
+#pragma unroll
+        for (int s = 0; s < CSm; ++s) {
+          w[s] = (pml[u][s][0] != WH_NEG_INF) ? __expf(pml[u][s][0] - M) : 0.f;
+          den = __builtin_fmaf(w[s], pml[u][s][1], den);
+        }
+        const float inv = on ? 1.0f / den : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float num = 0.f;
+#pragma unroll
+          for (int s = 0; s < CSm; ++s) num = __builtin_fmaf(w[s], po[u][s][e >> 2][e & 3], num);
+          xb[u][e] = (half_t)(num * inv);
+        }
+      }
+    }
+  } else {
+    if (xwave) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (!(kw + KS * u < nblk)) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xb[u][e] = (half_t)0.f;
+        }
+      }
+    }
+  }
+  if (SHARE) {
+    if (xwave) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) xfrag[(kw * NU + u) * 64 + lane] = xb[u];
+    }
+    __syncthreads();
+    if (!xwave) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) xb[u] = xfrag[(kw * NU + u) * 64 + lane];
+    }
+  }
+
+  // ---- NU MFMAs: C[m][n] with m = weight row (+8: second half), n = batch row (+8: second half)
+  float4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u], xb[u], acc, 0, 0, 0);
+  // lane holds C[m = 4 (lane >> 4) + e][n = lane & 15]; valid where (m >> 3) == (n >> 3)
+  const bool diag = (lane >> 5) == ((lane >> 3) & 1);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float z = diag ? acc[e] : 0.f;
+    z += lane_xor8(z);
+    float p, q; lane_swap32(z, p, q);
+    acc[e] = p + q;
+  }
+  if (lane < 32 && (lane & 15) < 8) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][4 * (lane >> 4) + e][lane & 7] = acc[e];
+  }
+  __syncthreads();
+  if (e_on) {
+    float v = e_bias;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) v += red[es * KS + k][ej][er];
+    const int64_t rr = r0 + er;
+    const int n = en;
+    switch (a.epi) {
+      case whk::EPI_STORE: ((half_t*)a.y)[rr * a.y_ld + n] = (half_t)v; break;
+      case whk::EPI_GELU: ((half_t*)a.y)[rr * a.y_ld + n] = (half_t)gelu_erf(v); break;
+      case whk::EPI_F32: ((float*)a.y)[rr * a.y_ld + n] = v; break;
+      case whk::EPI_RESID: a.resid[rr * a.resid_ld + n] = e_res + v; break;
+      case whk::EPI_QKV: {
+        const int D = a.D;
+        if (n < D) ((half_t*)a.y)[rr * a.y_ld + n] = (half_t)v;
+        else {
+          const int64_t pos = e_pos - e_lag;
+          if (n < 2 * D) ((half_t*)a.kcache)[rr * a.cache_bs + pos * D + (n - D)] = (half_t)v;
+          else ((half_t*)a.vcache)[rr * a.cache_bs + pos * D + (n - 2 * D)] = (half_t)v;
+        }
+      } break;
+    }
+  }
+  if (a.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.bump, a.bump_by);
+}
+
+template <int PRO, int WAVES, int GS, int CSm>
+hipError_t launch_gemv8_cfg(const whk::GemvArgs& a, hipStream_t stream) {
+  constexpr int KS = WAVES / GS;
+  const int nblk = a.K / 64, ngroups = (a.N + 7) / 8;
+  const int nu = (nblk + KS - 1) / KS;
+  dim3 grid((ngroups + GS - 1) / GS, (a.R + 7) / 8), block(WAVES * 64);
+  if (nu <= 3) hipLaunchKernelGGL((gemv8_kernel<PRO, WAVES, GS, 3, CSm>), grid, block, 0, stream, a);
+  else if (nu <= 5) hipLaunchKernelGGL((gemv8_kernel<PRO, WAVES, GS, 5, CSm>), grid, block, 0, stream, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// shapes follow tools/probe_floor: D x D -> 4 waves per 8-feature group (>= 160 workgroups); 3D x D -> 8 waves = 2
+// groups x 4 K-splits; 4D x D -> 16 waves = 4 groups x 4; D x 4D -> 16 waves splitting K 16 ways
+template <int PRO, int CSm>
+hipError_t launch_gemv8_pro(const whk::GemvArgs& a, hipStream_t stream) {
+  const int nblk = a.K / 64, ngroups = (a.N + 7) / 8;
+  if (nblk > 20) return launch_gemv8_cfg<PRO, 16, 1, CSm>(a, stream);
+  if (PRO == whk::PRO_LN) {
+    if (ngroups >= 600) return launch_gemv8_cfg<PRO, 16, 4, CSm>(a, stream);
+    if (ngroups >= 400) return launch_gemv8_cfg<PRO, 8, 2, CSm>(a, stream);
+  }
+  return launch_gemv8_cfg<PRO, 4, 1, CSm>(a, stream);
+}
+
+bool gemv8_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("WH_GEMV_DOT2"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
+// returns hipErrorNotSupported when the shape / mode is not covered (the caller falls back to the v_dot2 kernels)
+hipError_t launch_gemv8(const whk::GemvArgs& a, hipStream_t stream) {
+  if (!gemv8_enabled() || a.variant != 0) return hipErrorNotSupported;
+  if (a.K % 64 != 0) return hipErrorNotSupported;
+  const int nblk = a.K / 64;
+  if (nblk > 20 ? (nblk + 15) / 16 > 5 : (nblk + 3) / 4 > 5) return hipErrorNotSupported;
+  if (a.epi == whk::EPI_F32 && a.N > 16384) return hipErrorNotSupported;      // logits: the streaming kernel
+  switch (a.pro) {
+    case whk::PRO_PLAIN:
+      if (a.x_ld % 8 != 0) return hipErrorNotSupported;
+      return launch_gemv8_pro<whk::PRO_PLAIN, 1>(a, stream);
+    case whk::PRO_LN:
+      if (!a.ln_folded || a.xf_ld % 4 != 0) return hipErrorNotSupported;
+      return launch_gemv8_pro<whk::PRO_LN, 1>(a, stream);
+    case whk::PRO_COMBINE:
+      if (a.K != a.H * 64) return hipErrorNotSupported;
+      if (a.splits == 2) return launch_gemv8_pro<whk::PRO_COMBINE, 2>(a, stream);
+      if (a.splits == 3) return launch_gemv8_pro<whk::PRO_COMBINE, 3>(a, stream);
+      if (a.splits == 4) return launch_gemv8_pro<whk::PRO_COMBINE, 4>(a, stream);
+      return hipErrorNotSupported;
+  }
+  return hipErrorNotSupported;
+}
+
 }  // namespace
 
 namespace whk {
@@ -738,6 +1048,11 @@ namespace whk {
 hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream) {
   if (a.R <= 0) return hipErrorInvalidValue;
   if (dtype == 1) {
+    // the decode step of up to 8 rows per tile (and the few-row prefill): MFMA diagonal form
+    if (a.R <= 48 && !(a.R > 8 && a.K % 128 == 0 && a.K <= 5120 && (a.K / 32 <= 40 || a.pro == whk::PRO_PLAIN))) {
+      const hipError_t e = launch_gemv8(a, stream);
+      if (e != hipErrorNotSupported) return e;
+    }
     if (a.R <= 4) return launch_rt<half_t, 4>(a, stream);
     // beam-search row counts: row tiles of 16 through the matrix cores while x (16 rows) fits in LDS
     if (a.R > 8 && a.variant == 0 && a.K % 128 == 0 && a.K <= 5120 && (a.K / 32 <= 40 || a.pro == whk::PRO_PLAIN))

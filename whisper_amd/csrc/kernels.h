@@ -111,6 +111,7 @@ struct GemvArgs {
   const void* x; int64_t x_ld;                    // PRO_PLAIN: element type [R][K]
   const float* xf; int64_t xf_ld;                 // PRO_LN: fp32 residual rows [R][K]
   const float* ln_w; const float* ln_b;
+  int ln_folded;                                  // PRO_LN: ln_w == 1, ln_b == 0 (folded into W / bias at load time)
   const float* part_o; const float* part_ml; int splits; int H;  // PRO_COMBINE
   // weights
   const void* W; const float* bias; int N; int K; int R;

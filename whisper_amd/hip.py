@@ -17,6 +17,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwhisper
 
 WH_F32, WH_F16 = 0, 1
 WH_TASK_CAPTURE_Q = 1
+WH_WEIGHTS_DEC_LN_FOLDED = 1
 MEL_SCRATCH_BYTES = 2048
 
 
@@ -50,6 +51,7 @@ class ModelWeights(C.Structure):
         ("tok_emb", C.c_void_p), ("dec_pos", C.c_void_p),
         ("dec_layers", C.POINTER(LayerWeights)),
         ("dec_ln_w", C.c_void_p), ("dec_ln_b", C.c_void_p),
+        ("flags", C.c_uint32),
     ]
 
 
@@ -155,29 +157,49 @@ def _align(x: int, a: int = 256) -> int:
     return (x + a - 1) // a * a
 
 
-def _block_pieces(sd: Dict[str, torch.Tensor], prefix: str, cross: bool, D: int):
-    """yield (field, tensor, is_matrix) for one ResidualAttentionBlock (whisper/model.py:142-171)"""
+def _fold_ln(w: torch.Tensor, b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor):
+    """Linear(LayerNorm(x)) with the affine part of the LayerNorm moved into the Linear:
+    W (g * xhat + beta) + b  ==  (W * g) xhat + (b + W beta).  Computed in fp32 on the weights' device."""
+    wf = w.float()
+    return wf * ln_w.float().to(wf.device)[None, :], b.float().to(wf.device) + wf @ ln_b.float().to(wf.device)
+
+
+def _block_pieces(sd: Dict[str, torch.Tensor], prefix: str, cross: bool, D: int, fold: bool = False):
+    """yield (field, tensor, is_matrix) for one ResidualAttentionBlock (whisper/model.py:142-171).
+    fold (decoder blocks of the fp16 engine): the three LayerNorms' weight / bias are folded into the projection
+    that consumes them and replaced by (1, 0) — WH_WEIGHTS_DEC_LN_FOLDED in include/whisper_hip.h."""
     z = torch.zeros(D, dtype=torch.float32)
     g = lambda k: sd[prefix + k]
-    yield "attn_ln_w", g("attn_ln.weight"), False
-    yield "attn_ln_b", g("attn_ln.bias"), False
-    yield "qkv_w", torch.cat([g("attn.query.weight"), g("attn.key.weight"), g("attn.value.weight")], 0), True
-    yield "qkv_b", torch.cat([g("attn.query.bias").float().cpu(), z, g("attn.value.bias").float().cpu()], 0), False
+    one = lambda: torch.ones(D, dtype=torch.float32)
+    qkv_w = torch.cat([g("attn.query.weight"), g("attn.key.weight"), g("attn.value.weight")], 0)
+    qkv_b = torch.cat([g("attn.query.bias").float().cpu(), z, g("attn.value.bias").float().cpu()], 0)
+    if fold:
+        qkv_w, qkv_b = _fold_ln(qkv_w, qkv_b, g("attn_ln.weight"), g("attn_ln.bias"))
+    yield "attn_ln_w", one() if fold else g("attn_ln.weight"), False
+    yield "attn_ln_b", z if fold else g("attn_ln.bias"), False
+    yield "qkv_w", qkv_w, True
+    yield "qkv_b", qkv_b, False
     yield "out_w", g("attn.out.weight"), True
     yield "out_b", g("attn.out.bias"), False
     if cross:
-        yield "cross_ln_w", g("cross_attn_ln.weight"), False
-        yield "cross_ln_b", g("cross_attn_ln.bias"), False
-        yield "cq_w", g("cross_attn.query.weight"), True
-        yield "cq_b", g("cross_attn.query.bias"), False
+        cq_w, cq_b = g("cross_attn.query.weight"), g("cross_attn.query.bias")
+        if fold:
+            cq_w, cq_b = _fold_ln(cq_w, cq_b, g("cross_attn_ln.weight"), g("cross_attn_ln.bias"))
+        yield "cross_ln_w", one() if fold else g("cross_attn_ln.weight"), False
+        yield "cross_ln_b", z if fold else g("cross_attn_ln.bias"), False
+        yield "cq_w", cq_w, True
+        yield "cq_b", cq_b, False
         yield "ckv_w", torch.cat([g("cross_attn.key.weight"), g("cross_attn.value.weight")], 0), True
         yield "ckv_b", torch.cat([z, g("cross_attn.value.bias").float().cpu()], 0), False
         yield "cout_w", g("cross_attn.out.weight"), True
         yield "cout_b", g("cross_attn.out.bias"), False
-    yield "mlp_ln_w", g("mlp_ln.weight"), False
-    yield "mlp_ln_b", g("mlp_ln.bias"), False
-    yield "fc1_w", g("mlp.0.weight"), True
-    yield "fc1_b", g("mlp.0.bias"), False
+    fc1_w, fc1_b = g("mlp.0.weight"), g("mlp.0.bias")
+    if fold:
+        fc1_w, fc1_b = _fold_ln(fc1_w, fc1_b, g("mlp_ln.weight"), g("mlp_ln.bias"))
+    yield "mlp_ln_w", one() if fold else g("mlp_ln.weight"), False
+    yield "mlp_ln_b", z if fold else g("mlp_ln.bias"), False
+    yield "fc1_w", fc1_w, True
+    yield "fc1_b", fc1_b, False
     yield "fc2_w", g("mlp.2.weight"), True
     yield "fc2_b", g("mlp.2.bias"), False
 
@@ -190,7 +212,14 @@ def _conv_as_gemm(w: torch.Tensor, k_pad: int) -> torch.Tensor:
     return out
 
 
-def model_pieces(sd: Dict[str, torch.Tensor], dims) -> List[Tuple[str, torch.Tensor, bool]]:
+def folds_decoder_ln(dtype: int) -> bool:
+    """The fp16 engine's blobs carry the decoder LayerNorm affine parameters folded into the projections (the decode
+    GEMV then normalises its x fragments in registers without touching gamma / beta); the fp32 strict-parity engine
+    keeps the reference's operation order."""
+    return dtype == WH_F16
+
+
+def model_pieces(sd: Dict[str, torch.Tensor], dims, fold_dec_ln: bool = False) -> List[Tuple[str, torch.Tensor, bool]]:
     D = dims.n_audio_state
     kc1 = _align(3 * dims.n_mels, 64)
     out = [
@@ -210,7 +239,7 @@ def model_pieces(sd: Dict[str, torch.Tensor], dims) -> List[Tuple[str, torch.Ten
         for f, t, mat in _block_pieces(sd, f"encoder.blocks.{i}.", False, D):
             out.append((f"enc.{i}.{f}", t, mat))
     for i in range(dims.n_text_layer):
-        for f, t, mat in _block_pieces(sd, f"decoder.blocks.{i}.", True, dims.n_text_state):
+        for f, t, mat in _block_pieces(sd, f"decoder.blocks.{i}.", True, dims.n_text_state, fold=fold_dec_ln):
             out.append((f"dec.{i}.{f}", t, mat))
     return out
 
@@ -259,7 +288,7 @@ def pack_weights(sd: Dict[str, torch.Tensor], dims, dtype: int, device: torch.de
     layout, total = blob_layout(dims, dtype)
     blob = torch.zeros(total, dtype=torch.uint8, device=device)
     tdt = torch.float16 if dtype == WH_F16 else torch.float32
-    for name, t, mat in model_pieces(sd, dims):
+    for name, t, mat in model_pieces(sd, dims, fold_dec_ln=folds_decoder_ln(dtype)):
         off, shape, mat2 = layout[name]
         assert mat == mat2 and tuple(t.shape) == tuple(shape), (name, t.shape, shape)
         dt = tdt if mat else torch.float32
@@ -295,6 +324,7 @@ class HipModel:
             setattr(w, f, addr(f))
         w.enc_layers = C.cast(self._enc, C.POINTER(LayerWeights))
         w.dec_layers = C.cast(self._dec, C.POINTER(LayerWeights))
+        w.flags = WH_WEIGHTS_DEC_LN_FOLDED if folds_decoder_ln(dtype) else 0
         d = Dims(*[getattr(dims, n) for n, _ in Dims._fields_])
         h = C.c_void_p()
         check(lib().wh_model_create(C.byref(d), dtype, C.byref(w), C.byref(h)), "wh_model_create")
