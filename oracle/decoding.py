@@ -99,6 +99,27 @@ def greedy_decode(model: OracleModel, feats: torch.Tensor, initial_tokens: List[
     return {"tokens": tokens, "sum_logprobs": sum_lp.tolist(), "no_speech_probs": nsp}
 
 
+def filtered_logits(model: OracleModel, feats: torch.Tensor, initial_tokens: List[int], sampled: List[int],
+                    r: SamplingRules) -> torch.Tensor:
+    """Filtered fp32 logits of ONE row after `sampled` tokens have been emitted (teacher-forced, no cache): the
+    vector GreedyDecoder.update takes the arg-max of (decoding.py:277-283).  Test helper for the fp16 engine: where
+    its token ids leave the oracle's, the margin between the two candidates here tells a rounding-level near-tie
+    from an error."""
+    toks = torch.tensor([list(initial_tokens) + list(sampled)], dtype=torch.int64)
+    with torch.no_grad():
+        logits = model.decoder(toks, feats[None] if feats.dim() == 2 else feats)[0, -1].clone()
+    apply_filters(logits, list(sampled), r)
+    return logits
+
+
+def first_divergence(got: List[int], want: List[int]) -> Optional[int]:
+    """index of the first differing token, or None if one list is a prefix of the other and lengths agree"""
+    for i, (g, w) in enumerate(zip(got, want)):
+        if g != w:
+            return i
+    return None if len(got) == len(want) else min(len(got), len(want))
+
+
 def beam_decode(model: OracleModel, feats: torch.Tensor, initial_tokens: List[int], sample_len: int,
                 r: SamplingRules, beam_size: int, patience: Optional[float] = None) -> Dict:
     """BeamSearchDecoder (decoding.py:301-404) inside _main_loop.  The reference's batched beam path is

@@ -139,17 +139,61 @@ def test_batched_beam_vs_oracle(setup, gpu_device):
         assert res.tokens == [t for t in Bm[f"{key}_tokens"][i].tolist() if t >= 0], i
 
 
+FP16_LOGIT_BOUND = 6e-2      # |logit(fp16 engine) - logit(fp32 oracle)|, asserted in test_kernels_gpu / test_wide_gpu
+
+
+def _oracle_rules(dims):
+    multilingual = dims.n_vocab >= 51865
+    tok = get_tokenizer(multilingual, num_languages=dims.n_vocab - 51765 - int(multilingual), language="en", task="transcribe")
+    suppress = sorted(set(list(tok.non_speech_tokens) + [tok.transcribe, tok.translate, tok.sot, tok.sot_prev, tok.sot_lm, tok.no_speech]))
+    init = list(tok.sot_sequence)
+    rules = oracle.SamplingRules(sample_begin=len(init), sot_index=0, eot=tok.eot, timestamp_begin=tok.timestamp_begin,
+                                 no_timestamps=tok.no_timestamps, suppress_tokens=suppress, blank_token=tok.encode(" ")[0],
+                                 no_speech=tok.no_speech)
+    return tok, init, rules
+
+
+def assert_same_or_near_tie(got, want, om, feats, init, rules, what):
+    """Token lists of the fp16 engine: equal, or at the first difference the two candidates are within twice the fp16
+    logit bound of each other in the oracle's filtered logits (a rounding-level tie; everything after it legitimately
+    differs)."""
+    t = oracle.first_divergence(got, want)
+    if t is None:
+        return
+    assert t < len(got) and t < len(want), (what, t, got, want)
+    lg = oracle.filtered_logits(om, feats, init, want[:t], rules)
+    margin = abs(float(lg[got[t]]) - float(lg[want[t]]))
+    assert margin < 2 * FP16_LOGIT_BOUND, (what, "diverged at", t, "margin", margin, got[t], want[t])
+
+
 def test_batch_invariance_fp16(setup, gpu_device):
-    """size-independent property at the bench batch size: 8 clips decoded together == each decoded alone
-    (fp16 engine; rows are independent, so token ids must agree exactly)"""
+    """size-independent property at the bench batch size: 8 clips decoded together == each decoded alone.
+    fp32 engine: token ids exact.  fp16 engine: the number of cross-attention key splits depends on the row count
+    (fp32 partial sums meet in a different order, activations are then rounded to fp16), so a row may leave its
+    single-clip decode at a rounding-level near-tie — and only there (checked against the oracle's margin)."""
     key, dims, sd, model, mel = setup
     mels = torch.stack([whisper_amd.pad_or_trim(whisper_amd.log_mel_spectrogram(audio(60 + i), dims.n_mels,
                                                                                 device=gpu_device), 3000) for i in range(8)])
-    opts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=24)
-    together = whisper_amd.decode(model, mels, opts)
-    for i in range(8):
-        alone = whisper_amd.decode(model, mels[i], opts)
-        assert alone.tokens == together[i].tokens, i
+    om = oracle.OracleModel(dims, sd)
+    tok, init, rules = _oracle_rules(dims)
+    filt = oracle.mel_filterbank(dims.n_mels)
+    for fp16 in (False, True):
+        opts = whisper_amd.DecodingOptions(language="en", fp16=fp16, sample_len=24)
+        together = whisper_amd.decode(model, mels, opts)
+        for i in range(8):
+            alone = whisper_amd.decode(model, mels[i], opts)
+            if not fp16:
+                assert alone.tokens == together[i].tokens, i
+                continue
+            if alone.tokens != together[i].tokens:
+                with torch.no_grad():
+                    feats = om.encoder(oracle.log_mel_spectrogram(audio(60 + i), filt)[None])[0]
+                # the oracle's own continuation decides which of the two is "want"; both must be near-ties of it
+                t = oracle.first_divergence(alone.tokens, together[i].tokens)
+                prefix = alone.tokens[:t]
+                lg = oracle.filtered_logits(om, feats, init, prefix, rules)
+                margin = abs(float(lg[alone.tokens[t]]) - float(lg[together[i].tokens[t]]))
+                assert margin < 2 * FP16_LOGIT_BOUND, (i, t, margin)
 
 
 def test_fp16_tracks_fp32(setup):

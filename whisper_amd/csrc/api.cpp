@@ -269,7 +269,7 @@ struct wh_task {
   void* self_k; void* self_v;   // [L][R][n_ctx][D]
   void* spare_k; void* spare_v; // beam reorder staging (G > 1)
   float* x; void* xn; void* qkv; void* att; void* h; void* qbuf;
-  float* part_o; float* part_ml;
+  void* part_o; float* part_ml;
   float* logits;           // [R][V] step logits / [R][2][V] greedy prefill logits
   float* xsel; void* xseln;
   int* d_pos; int* d_alive; int* d_sel; int* d_src;
@@ -316,7 +316,7 @@ static void task_carve(wh_task* t, void* base) {
   t->h = c.take(Mx * 4 * D * es);
   t->qbuf = c.take(R * D * es);
   const size_t Rp = R > 48 ? R : 48;          // the few-row prefill runs its cross attention through the decode kernel
-  t->part_o = (float*)c.take(Rp * H * DEC_ATTN_MAX_SPLITS * 64 * 4);
+  t->part_o = c.take(Rp * H * DEC_ATTN_MAX_SPLITS * 64 * 4);
   t->part_ml = (float*)c.take(Rp * H * DEC_ATTN_MAX_SPLITS * 2 * 4);
   t->logits = (float*)c.take(R * 2 * V * 4);
   t->xsel = (float*)c.take(Mx * D * 4);

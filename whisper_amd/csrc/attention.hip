@@ -439,8 +439,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArg
     if (S == 1) {
       ((T*)a.out)[(int64_t)r * a.o_ld + h * 64 + tid] = from_f32<T>(o / l);
     } else {
-      const int64_t pi = ((int64_t)r * a.H + h) * S + s;
-      a.part_o[pi * 64 + tid] = nkeys > 0 ? o : 0.f;
+      // split-major partials [split][row][head]: the consumer projection reads, per split, one contiguous
+      // [row][head][64] block with the same lane map; o is stored NORMALISED (o / l) in the element type
+      const int64_t pi = ((int64_t)s * a.R + r) * a.H + h;
+      ((T*)a.part_o)[pi * 64 + tid] = from_f32<T>(nkeys > 0 ? o / l : 0.f);
       if (tid == 0) {
         a.part_ml[pi * 2 + 0] = nkeys > 0 ? mx : WH_NEG_INF;
         a.part_ml[pi * 2 + 1] = nkeys > 0 ? l : 0.f;
@@ -560,8 +562,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_group_kernel(whk::DecA
     if (S == 1) {
       ((T*)a.out)[(int64_t)r * a.o_ld + h * 64 + d] = from_f32<T>(o / l);
     } else {
-      const int64_t pi = ((int64_t)r * a.H + h) * S + s;
-      a.part_o[pi * 64 + d] = nkeys > 0 ? o : 0.f;
+      const int64_t pi = ((int64_t)s * a.R + r) * a.H + h;
+      ((T*)a.part_o)[pi * 64 + d] = from_f32<T>(nkeys > 0 ? o / l : 0.f);
       if (d == 0) {
         a.part_ml[pi * 2 + 0] = nkeys > 0 ? mx[g] : WH_NEG_INF;
         a.part_ml[pi * 2 + 1] = nkeys > 0 ? l : 0.f;

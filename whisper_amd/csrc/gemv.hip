@@ -37,6 +37,13 @@ namespace {
 
 constexpr int CS = 4;          // PRO_COMBINE fast path: splits held in registers
 
+// 4 consecutive attention-partial values (element type T) as fp32
+__device__ __forceinline__ float4v load_part4(const float* p) { return *(const float4v*)p; }
+__device__ __forceinline__ float4v load_part4(const half_t* p) {
+  const half4v h = *(const half4v*)p;
+  return float4v{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
 template <typename T> struct Pack4;
 template <> struct Pack4<float> {
   static __device__ __forceinline__ void store(float* p, float a, float b, float c, float d) {
@@ -237,10 +244,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
         int r = i / per_row; const int rem = i - r * per_row;
         if (r > R - 1) r = R - 1;
         const int h = rem >> 4, d4 = rem & 15;
-        const int64_t pb = ((int64_t)(r0 + r) * H + h) * S;
+        // partials are split-major [S][rows][H][64], normalised (attention.hip)
 #pragma unroll
         for (int s = 0; s < CS; ++s)
-          o[j][s] = *(const float4v*)(a.part_o + (pb + (s < S ? s : S - 1)) * 64 + d4 * 4);
+          o[j][s] = load_part4((const T*)a.part_o + (((int64_t)(s < S ? s : S - 1) * a.R + (r0 + r)) * H + h) * 64 + d4 * 4);
       }
       float2v ml[CS];
       const int pt = tid < RT * H ? tid : RT * H - 1;
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
       const bool pair = tid < RT * H && pr < R;
 #pragma unroll
       for (int s = 0; s < CS; ++s)
-        ml[s] = *(const float2v*)(a.part_ml + (((int64_t)(r0 + (pr < R ? pr : R - 1)) * H + ph) * S + (s < S ? s : S - 1)) * 2);
+        ml[s] = *(const float2v*)(a.part_ml + (((int64_t)(s < S ? s : S - 1) * a.R + (r0 + (pr < R ? pr : R - 1))) * H + ph) * 2);
       ISSUE_FENCE(); load_item(0, wa); ISSUE_FENCE(); WH_PROBE_AT(a, wgid, 1);
 #pragma unroll
       for (int s = 0; s < CS; ++s)
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
         for (int s = 0; s < CS; ++s) { w[s] = (ml[s][0] == WH_NEG_INF) ? 0.f : __expf(ml[s][0] - M); den = __builtin_fmaf(w[s], ml[s][1], den); }
         const float inv = pair ? 1.0f / den : 0.f;
 #pragma unroll
-        for (int s = 0; s < CS; ++s) csc[tid * CS + s] = w[s] * inv;
+        for (int s = 0; s < CS; ++s) csc[tid * CS + s] = w[s] * ml[s][1] * inv;      // partial o is o_s / l_s
       }
       __syncthreads();
 #pragma unroll
@@ -290,17 +297,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
         float4v num = {0.f, 0.f, 0.f, 0.f};
         float den = 1.f;
         if (r < R) {
-          const int64_t pb = ((int64_t)(r0 + r) * H + h) * S;
+          const int64_t pb = (int64_t)(r0 + r) * H + h, ps = (int64_t)a.R * H;     // [S][rows][H], normalised partials
           float M = WH_NEG_INF;
-          for (int s = 0; s < S; ++s) M = fmaxf(M, a.part_ml[(pb + s) * 2]);
+          for (int s = 0; s < S; ++s) M = fmaxf(M, a.part_ml[(pb + s * ps) * 2]);
           den = 0.f;
           for (int s = 0; s < S; ++s) {
-            const float2v ml = *(const float2v*)(a.part_ml + (pb + s) * 2);
-            const float w = __expf(ml[0] - M);
-            const float4v o = *(const float4v*)(a.part_o + (pb + s) * 64 + d4 * 4);
+            const float2v ml = *(const float2v*)(a.part_ml + (pb + s * ps) * 2);
+            const float w = (ml[0] == WH_NEG_INF ? 0.f : __expf(ml[0] - M)) * ml[1];
+            const float4v o = load_part4((const T*)a.part_o + (pb + s * ps) * 64 + d4 * 4);
             num[0] = __builtin_fmaf(w, o[0], num[0]); num[1] = __builtin_fmaf(w, o[1], num[1]);
             num[2] = __builtin_fmaf(w, o[2], num[2]); num[3] = __builtin_fmaf(w, o[3], num[3]);
-            den = __builtin_fmaf(w, ml[1], den);
+            den += w;
           }
         }
         const float inv = 1.0f / den;
@@ -506,7 +513,8 @@ hipError_t launch_rt(const whk::GemvArgs& a, hipStream_t stream) {
   if (a.K % (8 * UNIT) != 0) return hipErrorInvalidValue;
   const int ngroups8 = (a.N + 7) / 8;
   const int nblk8 = a.K / (8 * UNIT);
-  const int force = a.variant;                           // developer override (probe tool); 0 = heuristic
+  const int force = a.variant > 0 ? a.variant : 0;       // developer override (probe tool); 0 = heuristic, < 0 = heuristic
+                                                         // among the v_dot2 forms only (skips the MFMA diagonal kernel)
   if (force == 0) {
     if (ngroups8 > 1024 && a.pro == PRO_LN_ && a.epi == EPI_F32_ && a.K <= 2048) return launch_stream<T, RT>(a, stream);
     if (ngroups8 > 1024) return launch_pro<T, RT, 8, true, 4, 1>(a, (ngroups8 + 1023) / 1024, stream);
@@ -738,11 +746,16 @@ hipError_t launch_stream(const whk::GemvArgs& a, hipStream_t stream) {
 //
 // tools/probe_floor showed that a dependent launch which only streams a D x D matrix and reduces costs 2.9 us
 // (3.3 MB, 160 workgroups), while the v_dot2 kernels above take 5.0-6.7 us for the same bytes: the gap is the
-// per-wave instruction chain (32 v_dot2 + 8 ds_read_b128 per 16 bytes of weights per lane) and the 40 KB x block every
-// workgroup pushes through the texture addresser and LDS.  Here one v_mfma_f32_16x16x32_f16 consumes a whole
-// wave-load (64 lanes x 16 B of weights), and the x operand is loaded from global memory directly in fragment layout
-// (each wave reads only the K range it multiplies with), so a projection is: loads -> (LayerNorm statistics) ->
-// NU MFMAs -> one LDS exchange of 64 partial sums per wave -> epilogue.
+// per-wave instruction chain (32 v_dot2 + 8 ds_read_b128 per 16 bytes of weights per lane), the 40 KB x block every
+// workgroup pushes through the texture addresser and LDS, and the weight requests waiting behind the prologue's own
+// loads.  Here one v_mfma_f32_16x16x32_f16 consumes a whole wave-load (64 lanes x 16 B of weights), the x operand is
+// produced directly in fragment layout, and the waves of a workgroup are specialised:
+//   * weight waves (GS feature-group slots x KS splits of K): request their NU wave-loads of weights as their very
+//     first memory instructions, then wait for the x fragments, run NU MFMAs, and exchange 64 partial sums through LDS;
+//   * prologue waves (KS of them; none for PRO_PLAIN): read the fp32 residual rows / the attention partials for the
+//     K range kw of all 8 rows, LayerNorm or merge them in registers and publish fp16 fragments to LDS in fragment
+//     order (lane-linear 16-byte units: conflict-free both ways).  Their L2 round trip and arithmetic run under the
+//     HBM latency of the weight stream instead of in front of it.
 //
 // Fragment map.  A 16x16x32 MFMA wants 16 A rows x 32 k; with 16 distinct weight rows a wave-load would be 16 rows x
 // 64 B — half cache lines.  Instead the 16 A rows are 8 weight rows x 2 halves of a 64-element K block, and the 16 B
@@ -752,38 +765,171 @@ hipError_t launch_stream(const whk::GemvArgs& a, hipStream_t stream) {
 // y[n][r] = C[n][r] + C[8 + n][8 + r].  Off-diagonal lanes are zeroed and the pair is summed with one DPP row_ror:8
 // and one v_permlane32_swap.  Half of the MFMA work is discarded — irrelevant next to the HBM stream.
 //
-// LayerNorm is applied to the fragments in registers: a wave holds, for each of the 8 rows, the K range it multiplies;
-// per-wave (mean, M2) are merged across the KS waves with Chan's formula through 64 floats of LDS.  The LayerNorm
-// weight / bias are folded into the projection at load time (WH_WEIGHTS_DEC_LN_FOLDED, whisper_hip.h), so the
-// prologue is (x - mean) * rstd.
-//
-// Workgroup = GS feature-group slots x KS splits of K (WAVES = GS * KS).  With GS > 1 only the KS waves of slot 0
-// build the x fragments; they publish them to LDS in fragment order (lane-linear 16-byte units: conflict-free both
-// ways) while the other slots — which issued their weight loads at once — wait at the barrier.
+// LayerNorm: a prologue wave holds, for each of the 8 rows, 64 NU elements; per-wave (sum, sum of squares) meet in 64
+// floats of LDS.  The LayerNorm weight / bias are folded into the projection at load time
+// (WH_WEIGHTS_DEC_LN_FOLDED, whisper_hip.h), so the prologue is (x - mean) * rstd.
+// Addresses are a wave-uniform base (SGPR pair, per K block) plus one 32-bit per-lane offset, so that a load costs
+// no vector ALU work beyond its issue slot.
 // CSm: PRO_COMBINE — exactly the number of attention splits (2..4), so that no partial is requested twice.
 // ---------------------------------------------------------------------------------------------------------------
-template <int PRO, int WAVES, int GS, int NU, int CSm>
-__global__ __launch_bounds__(WAVES * 64) void gemv8_kernel(whk::GemvArgs a) {
+template <int PRO, int GS, int KS, int NU, int CSm, int XW>
+__global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArgs a) {
   pin_kernargs(a);
-  constexpr int KS = WAVES / GS;
-  constexpr bool SHARE = GS > 1;
-  __shared__ float red[WAVES][8][8];        // [wave][feature][row] partial sums
-  __shared__ float2v stat[KS][8];           // PRO_LN: per-wave (mean, M2) of every row
-  __shared__ __attribute__((aligned(16))) half8v xfrag[SHARE ? KS * NU * 64 : 1];   // [kw][u][lane]
+  static_assert((PRO == whk::PRO_PLAIN) == (XW == 0), "prologue waves exist exactly when there is a prologue");
+  static_assert(PRO != whk::PRO_LN || KS == 4, "LayerNorm prologue: one wave-load of fp32 = 256 elements = 4 K blocks");
+  constexpr int MW = GS * KS;                              // weight (MFMA) waves; XW prologue waves in front of them
+  __shared__ float red[MW][8][8];                          // [weight wave][feature][row] partial sums
+  __shared__ __attribute__((aligned(16))) half8v xfrag[XW ? KS * NU * 64 : 1];   // [kw][u][lane]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int slot = wave / KS, kw = wave % KS;
-  const int c = lane >> 4, half = (lane >> 3) & 1, idx = lane & 7;
-  const int koff = half * 32 + c * 8;
+  const bool is_x = wave < XW;                             // wave-uniform role
   const int K = a.K, nblk = K >> 6;
   const int r0 = blockIdx.y * 8;
   int R = a.R - r0; if (R > 8) R = 8;
-  const int ngroups = (a.N + 7) >> 3;
-  const int g = blockIdx.x * GS + slot;
-  const int row = r0 + (idx < R ? idx : R - 1);            // padded rows re-read a valid row; their outputs are dropped
-  const bool xwave = !SHARE || slot == 0;                  // wave-uniform
+  const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
+  (void)wgid;
+  WH_PROBE_AT(a, wgid, 0);
 
-  // epilogue operands, requested first (L2 hits): thread -> (slot, row, feature)
+  half8v wa[NU], xb[NU];
+  const int mw = wave - XW;
+  const int kw = mw % KS;                                  // weight waves: split of K
+
+  if (!is_x) {
+    // ================= weight waves: the whole share of the weight tile as the very first memory instructions
+    // (8 rows x 128 contiguous bytes per wave-load, non-temporal); lane l = 16 c + 8 half + i
+    const int idx = lane & 7, koff = ((lane >> 3) & 1) * 32 + (lane >> 4) * 8;
+    int n = (blockIdx.x * GS + mw / KS) * 8 + idx; if (n > a.N - 1) n = a.N - 1;
+    const uint32_t lane_off = ((uint32_t)n * (uint32_t)K + (uint32_t)koff) * 2u;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      int blk = kw + KS * u; if (blk > nblk - 1) blk = nblk - 1;          // wave-uniform; clamped, masked through x == 0
+      wa[u] = __builtin_nontemporal_load((const half8v*)((const char*)a.W + (size_t)blk * 128 + lane_off));
+    }
+    if (PRO == whk::PRO_PLAIN) {
+      const int row = r0 + (idx < R ? idx : R - 1);        // padded rows re-read a valid row; their outputs are dropped
+      const uint32_t xoff = ((uint32_t)row * (uint32_t)a.x_ld + (uint32_t)koff) * 2u;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        int blk = kw + KS * u; if (blk > nblk - 1) blk = nblk - 1;
+        xb[u] = *(const half8v*)((const char*)a.x + (size_t)blk * 128 + xoff);
+      }
+    }
+  } else if (PRO == whk::PRO_LN) {
+    // ================= LayerNorm waves.  Loads are row-contiguous (a wave-load = 1 KB of one row = 8 full cache
+    // lines: the number of line requests a CU keeps in flight is what bounds these kernels); wave w owns rows w,
+    // w + XW, ... whole, so the statistics never leave the wave; results are scattered to LDS in MFMA fragment order:
+    // element k of row r -> unit ((k >> 6) % KS, (k >> 6) / KS), lane 16 ((k & 31) >> 3) + 8 ((k & 63) >> 5) + r.
+    constexpr int NR = XW ? (8 + XW - 1) / XW : 1;
+    float4v v[NR][NU];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int r = wave + XW * i;
+      const char* src = (const char*)a.xf + (size_t)(r0 + (r < R ? r : R - 1)) * (size_t)a.xf_ld * 4;   // wave-uniform
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+        int k = (j * 64 + lane) * 4; if (k > K - 4) k = K - 4;          // branch-free, masked at use
+        v[i][j] = *(const float4v*)(src + (uint32_t)k * 4u);
+      }
+    }
+    WH_PROBE_AT(a, wgid, 1);
+    const float invK = 1.0f / (float)K;
+    // LDS byte address of this lane's 4 elements of wave-load j, row r: + j * 1024 + r * 16
+    const uint32_t fbase = (uint32_t)((lane >> 4) * NU * 64 + 16 * ((lane >> 1) & 3) + 8 * ((lane >> 3) & 1)) * 16u + (uint32_t)(lane & 1) * 8u;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int r = wave + XW * i;
+      if (r < 8) {
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+          const float t = (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
+          sum += ((j * 64 + lane) * 4 < K) ? t : 0.f;
+        }
+        const float mean = wave_sum(sum) * invK;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+          if ((j * 64 + lane) * 4 < K) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][j][e] - mean; ss = __builtin_fmaf(d, d, ss); }
+          }
+        }
+        const float rstd = rsqrtf(wave_sum(ss) * invK + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+          const bool on = (j * 64 + lane) * 4 < K;
+          half4v o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = on ? (half_t)((v[i][j][e] - mean) * rstd) : (half_t)0.f;
+          *(half4v*)((char*)xfrag + fbase + (uint32_t)(j * 1024 + r * 16)) = o4;
+        }
+      }
+    }
+    WH_PROBE_AT(a, wgid, 2);
+  } else if (PRO == whk::PRO_COMBINE) {
+    // ================= merge waves: partials are split-major [S][rows][H][64] fp16, normalised (attention.hip):
+    // wave-load i of a split covers 8 consecutive (row, head) pairs x 64 dims; lane = 8 (pair in the load) + dim / 8
+    const int H = a.H, npair = 8 * H;                     // pairs of this row tile
+    const int nload = (npair + 7) >> 3;                   // wave-loads per split
+    constexpr int NLD = XW ? (20 + XW - 1) / XW : 1;      // wave-loads per merge wave (H <= 20)
+    half8v po[NLD][CSm];
+    float2v pml[NLD][CSm];
+    const size_t split_stride = (size_t)a.R * H;          // pairs per split
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      int ld = wave + XW * i; if (ld > nload - 1) ld = nload - 1;
+      int pair = ld * 8 + (lane >> 3); if (pair > npair - 1) pair = npair - 1;
+      const int prow = pair / H, ph = pair - prow * H;
+      const int grow = r0 + (prow < R ? prow : R - 1);
+      const uint32_t pidx = (uint32_t)grow * (uint32_t)H + (uint32_t)ph;
+#pragma unroll
+      for (int s = 0; s < CSm; ++s) {
+        pml[i][s] = *(const float2v*)((const char*)a.part_ml + ((size_t)s * split_stride) * 8 + pidx * 8u);
+        po[i][s] = *(const half8v*)((const char*)a.part_o + ((size_t)s * split_stride) * 128 + (pidx * 64u + (uint32_t)(lane & 7) * 8u) * 2u);
+      }
+    }
+    WH_PROBE_AT(a, wgid, 1);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int ld = wave + XW * i;
+      const int pair = ld * 8 + (lane >> 3);
+      if (ld < nload && pair < npair) {
+        const int prow = pair / H, ph = pair - prow * H;
+        float M = pml[i][0][0];
+#pragma unroll
+        for (int s = 1; s < CSm; ++s) M = fmaxf(M, pml[i][s][0]);
+        float w[CSm], den = 0.f;
+#pragma unroll
+        for (int s = 0; s < CSm; ++s) {
+          w[s] = (pml[i][s][0] != WH_NEG_INF) ? __expf(pml[i][s][0] - M) * pml[i][s][1] : 0.f;   // partial o is o_s / l_s
+          den += w[s];
+        }
+        const float inv = 1.0f / den;
+        half8v xo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float num = 0.f;
+#pragma unroll
+          for (int s = 0; s < CSm; ++s) num = __builtin_fmaf(w[s], (float)po[i][s][e], num);
+          xo[e] = (half_t)(num * inv);
+        }
+        // head ph = K block: unit (ph % KS, ph / KS); dims [8 (lane & 7), +8): half = (lane & 7) >> 2, c = lane & 3
+        const int dl = lane & 7;
+        xfrag[((ph % KS) * NU + ph / KS) * 64 + 16 * (dl & 3) + 8 * (dl >> 2) + prow] = xo;
+      }
+    }
+    // K blocks beyond the last head (NU * KS > H) multiply clamped weights: zero them
+    for (int blk = H + wave; blk < NU * KS; blk += XW) {
+      half8v z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (half_t)0.f;
+      xfrag[((blk % KS) * NU + blk / KS) * 64 + lane] = z;
+    }
+    WH_PROBE_AT(a, wgid, 2);
+  }
+  ISSUE_FENCE();
+
+  // ---- epilogue operands (L2 hits, needed last; requested behind every wave's own loads): thread -> (slot, row, feature)
   const int es = tid >> 6, er = (tid >> 3) & 7, ej = tid & 7;
   const int en = (blockIdx.x * GS + es) * 8 + ej;
   const bool e_on = es < GS && er < R && en < a.N;
@@ -795,172 +941,47 @@ __global__ __launch_bounds__(WAVES * 64) void gemv8_kernel(whk::GemvArgs a) {
     if (a.bias) e_bias = a.bias[en];
     if (a.epi == whk::EPI_RESID) e_res = a.resid[(int64_t)(r0 + er) * a.resid_ld + en];
   }
+  if (!XW) WH_PROBE_AT(a, wgid, 1);
 
-  half8v xb[NU], wa[NU];
-  float4v xf[PRO == whk::PRO_LN ? NU : 1][2];
-  float4v po[PRO == whk::PRO_COMBINE ? NU : 1][CSm][2];
-  float2v pml[PRO == whk::PRO_COMBINE ? NU : 1][CSm];
-
-  auto load_weights = [&]() {      // the wave's share of the weight tile: 8 rows x 128 contiguous bytes per wave-load
-    int n = g * 8 + idx; if (n > a.N - 1) n = a.N - 1;
-    const half_t* wrow = (const half_t*)a.W + (int64_t)n * K + koff;
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      int blk = kw + KS * u; if (blk > nblk - 1) blk = nblk - 1;          // branch-free: clamped, masked through x == 0
-      wa[u] = __builtin_nontemporal_load((const half8v*)(wrow + blk * 64));
-    }
-  };
-
-  if (xwave) {
-    // x fragments first (L2 hits, the prologue arithmetic needs them first), then the weights
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      int blk = kw + KS * u; if (blk > nblk - 1) blk = nblk - 1;
-      if (PRO == whk::PRO_PLAIN) {
-        xb[u] = *(const half8v*)((const half_t*)a.x + (int64_t)row * a.x_ld + blk * 64 + koff);
-      } else if (PRO == whk::PRO_LN) {
-        const float* src = a.xf + (int64_t)row * a.xf_ld + blk * 64 + koff;
-        xf[u][0] = *(const float4v*)src;
-        xf[u][1] = *(const float4v*)(src + 4);
-      } else {
-        const int64_t pb = ((int64_t)row * a.H + blk) * CSm;               // block == head
-#pragma unroll
-        for (int s = 0; s < CSm; ++s) {
-          pml[u][s] = *(const float2v*)(a.part_ml + (pb + s) * 2);
-          po[u][s][0] = *(const float4v*)(a.part_o + (pb + s) * 64 + koff);
-          po[u][s][1] = *(const float4v*)(a.part_o + (pb + s) * 64 + koff + 4);
-        }
-      }
-    }
-    ISSUE_FENCE();
-  }
-  load_weights();
-  ISSUE_FENCE();
-
-  // ---- prologue arithmetic on the fragments (slot 0, or every wave when GS == 1)
-  if (PRO == whk::PRO_LN) {
-    float mean_w = 0.f, m2 = 0.f;
-    if (xwave) {
-      int nvalid = 0;
-      float sum = 0.f;
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const bool on = kw + KS * u < nblk;
-        nvalid += on ? 1 : 0;
-        const float t = ((xf[u][0][0] + xf[u][0][1]) + (xf[u][0][2] + xf[u][0][3])) + ((xf[u][1][0] + xf[u][1][1]) + (xf[u][1][2] + xf[u][1][3]));
-        sum += on ? t : 0.f;
-      }
-      const float cnt = 64.f * (float)nvalid;                  // elements of a row held by this wave
-      mean_w = nvalid ? across_groups8_sum(sum) / cnt : 0.f;   // lanes sharing (lane & 7) hold one row
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        if (kw + KS * u < nblk) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { const float d = xf[u][e >> 2][e & 3] - mean_w; m2 = __builtin_fmaf(d, d, m2); }
-        }
-      }
-      m2 = across_groups8_sum(m2);
-      if (lane < 8) stat[kw][lane] = float2v{mean_w, m2};
-    }
+  if (XW) {
     __syncthreads();
-    if (xwave) {
-      // merge the KS waves (Chan et al.): mean = sum cnt_k mean_k / K, M2 = sum M2_k + cnt_k (mean_k - mean)^2
-      float mean = 0.f;
-      float2v st[KS];
-      float cntk[KS];
-#pragma unroll
-      for (int k = 0; k < KS; ++k) {
-        st[k] = stat[k][idx];
-        int nv = 0;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) nv += (k + KS * u < nblk) ? 1 : 0;
-        cntk[k] = 64.f * (float)nv;
-        mean = __builtin_fmaf(st[k][0], cntk[k], mean);
-      }
-      const float invK = 1.0f / (float)K;
-      mean *= invK;
-      float M2 = 0.f;
-#pragma unroll
-      for (int k = 0; k < KS; ++k) {
-        const float d = st[k][0] - mean;
-        M2 += st[k][1] + cntk[k] * d * d;
-      }
-      const float rstd = rsqrtf(M2 * invK + 1e-5f);
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const bool on = kw + KS * u < nblk;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float v = (xf[u][e >> 2][e & 3] - mean) * rstd;
-          xb[u][e] = on ? (half_t)v : (half_t)0.f;
-        }
-      }
-    }
-  } else if (PRO == whk::PRO_COMBINE) {
-    if (xwave) {
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const bool on = kw + KS * u < nblk;
-        float M = pml[u][0][0];
-#pragma unroll
-        for (int s = 1; s < CSm; ++s) M = fmaxf(M, pml[u][s][0]);
-        float w[CSm], den = 0.f;
-#pragma unroll
-        for (int s = 0; s < CSm; ++s) {
-          w[s] = (pml[u][s][0] != WH_NEG_INF) ? __expf(pml[u][s][0] - M) : 0.f;
-          den = __builtin_fmaf(w[s], pml[u][s][1], den);
-        }
-        const float inv = on ? 1.0f / den : 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float num = 0.f;
-#pragma unroll
-          for (int s = 0; s < CSm; ++s) num = __builtin_fmaf(w[s], po[u][s][e >> 2][e & 3], num);
-          xb[u][e] = (half_t)(num * inv);
-        }
-      }
-    }
-  } else {
-    if (xwave) {
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        if (!(kw + KS * u < nblk)) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) xb[u][e] = (half_t)0.f;
-        }
-      }
-    }
-  }
-  if (SHARE) {
-    if (xwave) {
-#pragma unroll
-      for (int u = 0; u < NU; ++u) xfrag[(kw * NU + u) * 64 + lane] = xb[u];
-    }
-    __syncthreads();
-    if (!xwave) {
+    if (!is_x) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) xb[u] = xfrag[(kw * NU + u) * 64 + lane];
     }
+  } else {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (!(kw + KS * u < nblk)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xb[u][e] = (half_t)0.f;
+      }
+    }
   }
+  WH_PROBE_AT(a, wgid, 3);
 
-  // ---- NU MFMAs: C[m][n] with m = weight row (+8: second half), n = batch row (+8: second half)
-  float4v acc = {0.f, 0.f, 0.f, 0.f};
+  // ---- weight waves: NU MFMAs, C[m][n] with m = weight row (+8: second half), n = batch row (+8: second half)
+  if (!is_x) {
+    float4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int u = 0; u < NU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u], xb[u], acc, 0, 0, 0);
-  // lane holds C[m = 4 (lane >> 4) + e][n = lane & 15]; valid where (m >> 3) == (n >> 3)
-  const bool diag = (lane >> 5) == ((lane >> 3) & 1);
+    for (int u = 0; u < NU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u], xb[u], acc, 0, 0, 0);
+    // lane holds C[m = 4 (lane >> 4) + e][n = lane & 15]; valid where (m >> 3) == (n >> 3)
+    const bool diag = (lane >> 5) == ((lane >> 3) & 1);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float z = diag ? acc[e] : 0.f;
-    z += lane_xor8(z);
-    float p, q; lane_swap32(z, p, q);
-    acc[e] = p + q;
+    for (int e = 0; e < 4; ++e) {
+      float z = diag ? acc[e] : 0.f;
+      z += lane_xor8(z);
+      float p, q; lane_swap32(z, p, q);
+      acc[e] = p + q;
+    }
+    if (lane < 32 && (lane & 15) < 8) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[mw][4 * (lane >> 4) + e][lane & 7] = acc[e];
+    }
   }
-  if (lane < 32 && (lane & 15) < 8) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave][4 * (lane >> 4) + e][lane & 7] = acc[e];
-  }
+  WH_PROBE_AT(a, wgid, 4);
   __syncthreads();
+  WH_PROBE_AT(a, wgid, 5);
   if (e_on) {
     float v = e_bias;
 #pragma unroll
@@ -983,32 +1004,42 @@ __global__ __launch_bounds__(WAVES * 64) void gemv8_kernel(whk::GemvArgs a) {
       } break;
     }
   }
+  WH_PROBE_AT(a, wgid, 6);
   if (a.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.bump, a.bump_by);
 }
 
-template <int PRO, int WAVES, int GS, int CSm>
+template <int PRO, int GS, int KS, int CSm, int XW>
 hipError_t launch_gemv8_cfg(const whk::GemvArgs& a, hipStream_t stream) {
-  constexpr int KS = WAVES / GS;
+  constexpr int WAVES = GS * KS + XW;
+  static_assert(WAVES <= 16, "at most 1024 threads per workgroup");
   const int nblk = a.K / 64, ngroups = (a.N + 7) / 8;
   const int nu = (nblk + KS - 1) / KS;
   dim3 grid((ngroups + GS - 1) / GS, (a.R + 7) / 8), block(WAVES * 64);
-  if (nu <= 3) hipLaunchKernelGGL((gemv8_kernel<PRO, WAVES, GS, 3, CSm>), grid, block, 0, stream, a);
-  else if (nu <= 5) hipLaunchKernelGGL((gemv8_kernel<PRO, WAVES, GS, 5, CSm>), grid, block, 0, stream, a);
+  if (nu <= 3) hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 3, CSm, XW>), grid, block, 0, stream, a);
+  else if (nu <= 5) hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 5, CSm, XW>), grid, block, 0, stream, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
-// shapes follow tools/probe_floor: D x D -> 4 waves per 8-feature group (>= 160 workgroups); 3D x D -> 8 waves = 2
-// groups x 4 K-splits; 4D x D -> 16 waves = 4 groups x 4; D x 4D -> 16 waves splitting K 16 ways
+// shapes (large-v3 in brackets; every choice measured with tools/probe_gemv8, profiles/r02_probe_gemv8.txt):
+//   K <= 1280 -> 4 splits of K, K <= 5120 -> 16 (PRO_PLAIN only);
+//   D x D [160 workgroups] and 3D x D [2 feature-group slots, 240 workgroups]: 8 prologue waves, one row each;
+//   4D x D: 3 slots [214 workgroups of 4 + 12 waves] — a launch costs about
+//   1.5 us + (12.6 cycles x HBM lines + 3.7 cycles x L2 lines requested by the busiest CU) / clock.
 template <int PRO, int CSm>
 hipError_t launch_gemv8_pro(const whk::GemvArgs& a, hipStream_t stream) {
   const int nblk = a.K / 64, ngroups = (a.N + 7) / 8;
-  if (nblk > 20) return launch_gemv8_cfg<PRO, 16, 1, CSm>(a, stream);
-  if (PRO == whk::PRO_LN) {
-    if (ngroups >= 600) return launch_gemv8_cfg<PRO, 16, 4, CSm>(a, stream);
-    if (ngroups >= 400) return launch_gemv8_cfg<PRO, 8, 2, CSm>(a, stream);
+  if constexpr (PRO == whk::PRO_PLAIN) {
+    if (nblk > 20) return launch_gemv8_cfg<PRO, 1, 16, CSm, 0>(a, stream);
+    return launch_gemv8_cfg<PRO, 1, 4, CSm, 0>(a, stream);
+  } else {
+    if (nblk > 20) return hipErrorNotSupported;              // the prologue waves cover K <= 1280
+    if (PRO == whk::PRO_LN) {
+      if (ngroups >= 600) return launch_gemv8_cfg<PRO, 3, 4, CSm, 4>(a, stream);
+      if (ngroups >= 400) return launch_gemv8_cfg<PRO, 2, 4, CSm, 8>(a, stream);
+    }
+    return launch_gemv8_cfg<PRO, 1, 4, CSm, 8>(a, stream);
   }
-  return launch_gemv8_cfg<PRO, 4, 1, CSm>(a, stream);
 }
 
 bool gemv8_enabled() {
@@ -1024,15 +1055,16 @@ hipError_t launch_gemv8(const whk::GemvArgs& a, hipStream_t stream) {
   const int nblk = a.K / 64;
   if (nblk > 20 ? (nblk + 15) / 16 > 5 : (nblk + 3) / 4 > 5) return hipErrorNotSupported;
   if (a.epi == whk::EPI_F32 && a.N > 16384) return hipErrorNotSupported;      // logits: the streaming kernel
+  if ((int64_t)a.N * a.K >= (1ll << 31)) return hipErrorNotSupported;         // 32-bit lane offsets
   switch (a.pro) {
     case whk::PRO_PLAIN:
-      if (a.x_ld % 8 != 0) return hipErrorNotSupported;
+      if (a.x_ld % 8 != 0 || (int64_t)a.R * a.x_ld >= (1ll << 30)) return hipErrorNotSupported;
       return launch_gemv8_pro<whk::PRO_PLAIN, 1>(a, stream);
     case whk::PRO_LN:
-      if (!a.ln_folded || a.xf_ld % 4 != 0) return hipErrorNotSupported;
+      if (!a.ln_folded || a.xf_ld % 4 != 0 || (int64_t)a.R * a.xf_ld >= (1ll << 29)) return hipErrorNotSupported;
       return launch_gemv8_pro<whk::PRO_LN, 1>(a, stream);
     case whk::PRO_COMBINE:
-      if (a.K != a.H * 64) return hipErrorNotSupported;
+      if (a.K != a.H * 64 || a.H > 20 || (int64_t)a.R * a.H * a.splits * 64 >= (1ll << 29)) return hipErrorNotSupported;
       if (a.splits == 2) return launch_gemv8_pro<whk::PRO_COMBINE, 2>(a, stream);
       if (a.splits == 3) return launch_gemv8_pro<whk::PRO_COMBINE, 3>(a, stream);
       if (a.splits == 4) return launch_gemv8_pro<whk::PRO_COMBINE, 4>(a, stream);
@@ -1055,7 +1087,7 @@ hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream) {
     }
     if (a.R <= 4) return launch_rt<half_t, 4>(a, stream);
     // beam-search row counts: row tiles of 16 through the matrix cores while x (16 rows) fits in LDS
-    if (a.R > 8 && a.variant == 0 && a.K % 128 == 0 && a.K <= 5120 && (a.K / 32 <= 40 || a.pro == whk::PRO_PLAIN))
+    if (a.R > 8 && a.variant <= 0 && a.K % 128 == 0 && a.K <= 5120 && (a.K / 32 <= 40 || a.pro == whk::PRO_PLAIN))
       return launch_rows16_mf<half_t>(a, stream);
     return launch_rt<half_t, 8>(a, stream);           // R <= 8, or long K: row tiles of 8 on grid.y
   }

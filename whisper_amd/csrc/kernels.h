@@ -91,7 +91,7 @@ struct DecAttnArgs {
   const int* lag;                                 // with d_len: row r holds lag[r] fewer keys (ragged prompts); may be null
   int splits;                                     // key-range splits
   void* out; int64_t o_ld;                        // splits==1: normalized output, element type
-  float* part_o; float* part_ml;                  // splits>1: [R][H][S][64], [R][H][S][2]
+  void* part_o; float* part_ml;                   // splits>1: [S][R][H][64] element type, normalised (o / l); (m, l) fp32 [S][R][H][2]
   WH_PROBE_FIELD
 };
 constexpr int DEC_ATTN_MAX_SPLITS = 16;
@@ -112,7 +112,7 @@ struct GemvArgs {
   const float* xf; int64_t xf_ld;                 // PRO_LN: fp32 residual rows [R][K]
   const float* ln_w; const float* ln_b;
   int ln_folded;                                  // PRO_LN: ln_w == 1, ln_b == 0 (folded into W / bias at load time)
-  const float* part_o; const float* part_ml; int splits; int H;  // PRO_COMBINE
+  const void* part_o; const float* part_ml; int splits; int H;  // PRO_COMBINE: [S][R][H][64] element type, [S][R][H][2]
   // weights
   const void* W; const float* bias; int N; int K; int R;
   // epilogue
