@@ -8,17 +8,23 @@ count is fixed: `sample_len` forced tokens per clip with EOT su
 identical run to run.  Inputs are resident in HBM before the timed region.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, each rank decodes its own 8 clips (weak scaling, no collective in the step);
-rank 0 builds the packed weight blob and RCCL-broadcasts it over xGMI at load.
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+N > 1: one process per GPU (the script re-executes itself under `torch.distributed.run` when it was not launched
+by it), each rank decodes its own 8 clips (weak scaling, no collective in the step); rank 0 builds the packed
+weight blob and RCCL-broadcasts it over xGMI at load.
+Prints ONE JSON line on rank 0 (contract in the task statement).  Besides the headline it carries
+  roofline      dominant kernel (cross-attention K/V stream) + `step_frac` of the whole decode step, HIP events
+  public_api    the same workload through whisper_amd.log_mel_spectrogram + whisper_amd.decode (drop-in surface)
+  parity        row 0 of the timed pass against the tokens of the CPU baseline's oracle (same weights, same clip)
+  extras        BASELINE configs[3] / [4] shaped workloads (beam 5; word timestamps) — never the headline
+  cpu_baseline  the oracle (port of the reference's CPU fp32 path) on this box's host cores: warm-up + repeats
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -38,6 +44,7 @@ def log(msg: str) -> None:
 
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s float4-copy achievable)
+FP16_LOGIT_BOUND = 6e-2     # fp16 engine vs fp32 oracle, asserted by tests/test_wide_gpu.py
 
 
 def parse():
@@ -50,9 +57,27 @@ def parse():
     p.add_argument("--sample-len", type=int, default=224, help="forced decode steps per clip (n_text_ctx // 2)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-extras", action="store_true", help="skip the public-API leg and the beam / word-timestamp workloads")
+    p.add_argument("--beam", type=int, default=5, help="beam size of the extra beam-search workload (0 = skip)")
+    p.add_argument("--beam-steps", type=int, default=64)
+    p.add_argument("--word-timestamps", dest="word_timestamps", action="store_true", default=True)
+    p.add_argument("--no-word-timestamps", dest="word_timestamps", action="store_false")
     p.add_argument("--cpu-steps", type=int, default=12, help="decode steps timed on the CPU baseline")
+    p.add_argument("--cpu-repeats", type=int, default=3)
     p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = all usable cores)")
     return p.parse_args()
+
+
+def relaunch_under_torchrun(args) -> None:
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py ...`"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {args.gpus} without a launcher: re-executing under torch.distributed.run (port {port})")
+    os.execv(sys.executable, cmd)
 
 
 def synth_audio(batch: int, rank: int, device) -> torch.Tensor:
@@ -71,6 +96,8 @@ def synth_audio(batch: int, rank: int, device) -> torch.Tensor:
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,22 +113,31 @@ def main():
         dist = None
 
     import faulthandler
-    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
+    faulthandler.dump_traceback_later(300, repeat=True, file=sys.stderr)
     log(f"rank {rank}/{world} device ready")
+    import whisper_amd
     from whisper_amd import hip
     from whisper_amd.audio import log_mel_spectrogram
     from whisper_amd.launcher import broadcast_weights
-    from whisper_amd.synthetic import dims_for, synthetic_state_dict
+    from whisper_amd.model import ModelDimensions, Whisper
+    from whisper_amd.synthetic import dims_dict, dims_for, synthetic_state_dict
     from whisper_amd.tokenizer import get_tokenizer
 
     dims = dims_for(args.model)
     dtype = hip.WH_F16
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     # ---- weights: rank 0 packs, everyone else receives the blob over RCCL -----------------------
-    blob = None
+    # With the CPU baseline the weights are generated on the host (numpy PCG64, bit-reproducible) so that the oracle and
+    # the HIP engine see the very same tensors and their token ids can be compared; otherwise on the device (seconds).
+    blob, sd_cpu = None, None
     if rank == 0:
-        sd = synthetic_state_dict(dims, seed=0, device=device)
-        blob = hip.pack_weights(sd, dims, dtype, device)
-        del sd
+        if want_cpu:
+            sd_cpu = synthetic_state_dict(dims, seed=0, device="cpu")
+            blob = hip.pack_weights(sd_cpu, dims, dtype, device)
+        else:
+            sd = synthetic_state_dict(dims, seed=0, device=device)
+            blob = hip.pack_weights(sd, dims, dtype, device)
+            del sd
         torch.cuda.empty_cache()
     blob = broadcast_weights(blob, dims, dtype, device, dist)
     model = hip.HipModel(dims, dtype, blob)
@@ -164,6 +200,8 @@ def main():
     log(f"timed: {ms_per_step:.1f} ms per pass")
     audio_s = 30.0 * B * world * args.steps
     value = audio_s / elapsed
+    hip_row0 = tokens[0, T0: T0 + N].tolist()
+    direct_tokens = tokens[:, : T0 + N].clone()
 
     out = {
         "metric": "audio-seconds transcribed per wall-second (large-v3 greedy)",
@@ -203,24 +241,92 @@ def main():
         # HBM traffic per launch from the PMC counters: they cannot be read from inside this process, so the
         # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/, per round),
         # and only when it was taken on this very workload; otherwise null.
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.isfile(tf) and args.model == "large-v3" and B == 8:
-            with open(tf) as f:
-                pm = json.load(f)["kernels"].get("attn_decode_cross")
-            if pm:
-                traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes_raw"]
+        traffic, tsrc = None, None
+        for rnd in ("r02", "r01"):
+            tf = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+            if os.path.isfile(tf) and args.model == "large-v3" and B == 8:
+                with open(tf) as f:
+                    pm = json.load(f)["kernels"].get("attn_decode_cross")
+                if pm:
+                    traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes_raw"]
+                    tsrc = (f"profiles/{rnd}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + "
+                            "WRITE_SIZE raw, bytes per launch)")
+                    break
+        step = kern["decode_step"]
         out["roofline"] = {"bound": "hbm", "kernel": "attn_decode_kernel<half> (cross-attention KV stream)",
                            "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 "
-                                             "correction + WRITE_SIZE raw, bytes per launch)" if traffic else None,
-                           "bytes_per_launch": dom["bytes"], "avg_us": dom["avg_us"], "all_kernels": kern}
+                           "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                           "bytes_per_launch": dom["bytes"], "avg_us": dom["avg_us"],
+                           # the whole decode step (all ~257 dependent launches of one token) against the same peak
+                           "step_frac": round(step["GBps"] / HBM_PEAK_GBS, 4), "step_avg_us": step["avg_us"],
+                           "step_bytes": step["bytes"], "all_kernels": kern}
     task.close()
 
+    # ---- the same workload through the public drop-in surface ----------------------------------------------------
+    if rank == 0 and not args.no_extras:
+        wmodel = Whisper(ModelDimensions(**dims_dict(dims)), {}, device=device)
+        wmodel.adopt_engine(torch.float16, model)
+        opts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=N, suppress_tokens=[-1, tok.eot])
+
+        def api_pass():
+            mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
+            return whisper_amd.decode(wmodel, mel, opts)
+
+        res = api_pass()
+        torch.cuda.synchronize(device)
+        same = all(r.tokens == direct_tokens[i, T0:].tolist() for i, r in enumerate(res))
+        reps = max(2, min(args.steps, 5))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = api_pass()
+        torch.cuda.synchronize(device)
+        api_ms = (time.perf_counter() - t0) / reps * 1e3
+        out["public_api"] = {"ms_per_step": round(api_ms, 3), "vs_direct": round(api_ms / ms_per_step, 4),
+                             "tokens_equal_direct": bool(same),
+                             "path": "whisper_amd.log_mel_spectrogram + whisper_amd.decode(model, mel, DecodingOptions(fp16=True, sample_len=N))"}
+        log(f"public API leg: {api_ms:.1f} ms per pass ({api_ms / ms_per_step:.3f} x direct), tokens equal: {same}")
+
+        extras = {}
+        # BASELINE configs[3] shape: beam search (beam 5) on this GPU's clips, device-side beam loop
+        if args.beam >= 2:
+            bopts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=args.beam_steps, beam_size=args.beam,
+                                                suppress_tokens=[-1, tok.eot])
+            mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
+            whisper_amd.decode(wmodel, mel, bopts)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
+                whisper_amd.decode(wmodel, mel, bopts)
+            torch.cuda.synchronize(device)
+            bms = (time.perf_counter() - t0) / 2 * 1e3
+            extras["beam_search"] = {"beam_size": args.beam, "clips": B, "rows": B * args.beam, "steps": args.beam_steps,
+                                     "ms_per_pass": round(bms, 2), "audio_s_per_s": round(30.0 * B / (bms * 1e-3), 1)}
+            log(f"beam {args.beam}: {bms:.1f} ms per pass of {B} clips x {args.beam_steps} steps")
+        # BASELINE configs[4] shape: word timestamps (cross-attention alignment + DTW) for every clip of the batch
+        if args.word_timestamps:
+            from whisper_amd.timing import find_alignment_batch
+            mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
+            text = [[t for t in r.tokens if t < tok.eot][:200] for r in res]
+            find_alignment_batch(wmodel, tok, text, mel.half(), [3000] * B)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                al = find_alignment_batch(wmodel, tok, text, mel.half(), [3000] * B)
+            torch.cuda.synchronize(device)
+            wms = (time.perf_counter() - t0) / 2 * 1e3
+            extras["word_timestamps"] = {"clips": B, "text_tokens_per_clip": len(text[0]), "ms_per_batch": round(wms, 2),
+                                         "words": sum(len(a) for a in al),
+                                         "note": "find_alignment_batch: encoder + one teacher-forced pass + alignment heads QK + DTW"}
+            log(f"word timestamps: {wms:.1f} ms per batch of {B} clips")
+        out["extras"] = extras
+        wmodel = None
+
     # ---- CPU baseline: the oracle (fp32 torch-CPU restatement of the reference) on this box's host cores ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, dims, init, suppress, tok, audio[:1].cpu().numpy())
+    if want_cpu:
+        base, parity = cpu_baseline(args, dims, init, suppress, tok, audio[:1].cpu().numpy(), sd_cpu, hip_row0)
+        out["cpu_baseline"] = base
+        out["parity"] = parity
 
     if rank == 0:
         print(json.dumps(out))
@@ -228,42 +334,63 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, dims, init, suppress, tok, audio_np):
-    """Oracle = "port": same algorithm as the reference's CPU fp32 path.  Bounded sample: 1 clip, log-mel +
-    encoder + `cpu_steps` decode steps; audio-s/s extrapolated linearly to `sample_len` steps."""
+def cpu_baseline(args, dims, init, suppress, tok, audio_np, sd, hip_row0):
+    """Oracle = "port": same algorithm as the reference's CPU fp32 path (calibrated beside the live reference in
+    BASELINE.md).  Bounded sample: 1 clip; log-mel + encoder + `cpu_steps` decode steps, one warm-up and
+    `cpu_repeats` timed repetitions of each stage, medians; audio-s/s extrapolated linearly to `sample_len` steps.
+    The tokens of those steps are compared with row 0 of the HIP pass (same weights, same clip)."""
     import oracle
-    from whisper_amd.synthetic import synthetic_state_dict
     from whisper_amd.utils import usable_cores
     cores = getattr(args, "cpu_threads", 0) or usable_cores()
     torch.set_num_threads(cores)
-    log(f"cpu_baseline: building {args.model} fp32 oracle on {cores} host threads")
-    sd = synthetic_state_dict(dims, seed=0, device="cpu")
+    log(f"cpu_baseline: {args.model} fp32 oracle on {cores} host threads")
     om = oracle.OracleModel(dims, sd)
-    log("cpu_baseline: oracle model ready")
     filt = oracle.mel_filterbank(dims.n_mels)
-    t0 = time.perf_counter()
-    mel = oracle.log_mel_spectrogram(audio_np[0], filt)
-    t_mel = time.perf_counter() - t0
-    t0 = time.perf_counter()
+    reps = max(1, args.cpu_repeats)
+
+    def timed(fn, n):
+        fn()                                       # warm-up (thread pool, allocator, caches)
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return r, ts
+
+    mel, t_mel = timed(lambda: oracle.log_mel_spectrogram(audio_np[0], filt), reps)
     with torch.no_grad():
-        feats = om.encoder(mel[None])
-    t_enc = time.perf_counter() - t0
-    log(f"cpu_baseline: log-mel {t_mel:.2f}s encoder {t_enc:.2f}s")
+        feats, t_enc = timed(lambda: om.encoder(mel[None]), reps)
+    log(f"cpu_baseline: log-mel {statistics.median(t_mel):.3f}s encoder {statistics.median(t_enc):.2f}s (x{reps})")
     rules = oracle.SamplingRules(sample_begin=len(init), sot_index=0, eot=tok.eot, n_ctx=dims.n_text_ctx,
                                  timestamp_begin=tok.timestamp_begin, no_timestamps=tok.no_timestamps,
                                  suppress_tokens=suppress, blank_token=tok.encode(" ")[0], no_speech=tok.no_speech)
     k = args.cpu_steps
-    t0 = time.perf_counter()
     with torch.no_grad():
-        oracle.greedy_decode(om, feats, init, k, rules)
-    t_dec = time.perf_counter() - t0
-    per_step = t_dec / k
-    log(f"cpu_baseline: {k} decode steps in {t_dec:.2f}s")
-    total = t_mel + t_enc + per_step * args.sample_len
-    return {"value": round(30.0 / total, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "sample": f"1 clip of the same workload: log-mel {t_mel:.2f}s + encoder {t_enc:.2f}s + {k} decode steps "
-                      f"at {per_step * 1e3:.0f} ms/step, extrapolated to {args.sample_len} steps (fp32, torch CPU, "
-                      f"{cores} threads)"}
+        dec, t_dec = timed(lambda: oracle.greedy_decode(om, feats, init, k, rules, keep_logits=True), reps)
+    per_step = [t / k for t in t_dec]
+    log(f"cpu_baseline: {k} decode steps, median {statistics.median(t_dec):.2f}s (x{reps})")
+    m_mel, m_enc, m_step = statistics.median(t_mel), statistics.median(t_enc), statistics.median(per_step)
+    total = m_mel + m_enc + m_step * args.sample_len
+    lo = 30.0 / (max(t_mel) + max(t_enc) + max(per_step) * args.sample_len)
+    hi = 30.0 / (min(t_mel) + min(t_enc) + min(per_step) * args.sample_len)
+    base = {"value": round(30.0 / total, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "repeats": reps, "spread": [round(lo, 3), round(hi, 3)],
+            "sample": f"1 clip of the same workload, 1 warm-up + {reps} repeats, medians: log-mel {m_mel:.3f}s + encoder "
+                      f"{m_enc:.2f}s + {k} decode steps at {m_step * 1e3:.0f} ms/step, extrapolated to {args.sample_len} "
+                      f"steps (fp32, torch CPU, {cores} threads)"}
+    # parity of the benchmarked engine: the oracle's tokens for clip 0 against row 0 of the HIP pass
+    want = dec["tokens"][0, len(init):].tolist()
+    got = hip_row0[: len(want)]
+    t = oracle.first_divergence(got, want)
+    parity = {"steps": len(want), "tokens_equal": t is None, "first_divergence": t, "margin": None,
+              "rule": f"fp16 engine: equal, or the first difference is a near-tie (< {2 * FP16_LOGIT_BOUND}) in the "
+                      "oracle's filtered logits"}
+    if t is not None:
+        lg = dec["step_logits"][t][0]
+        parity["margin"] = round(float(lg[want[t]]) - float(lg[got[t]]), 5)
+        parity["near_tie"] = bool(0 <= parity["margin"] < 2 * FP16_LOGIT_BOUND)
+    log(f"parity vs oracle (clip 0, {len(want)} steps): {parity}")
+    return base, parity
 
 
 if __name__ == "__main__":

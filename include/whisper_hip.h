@@ -154,7 +154,7 @@ int wh_task_step(wh_task *t, const int64_t *last_tokens, int64_t token_stride, f
  * old row source_indices[i] (host array of n_rows ints). */
 int wh_task_rearrange(wh_task *t, const int32_t *source_indices, void *stream);
 /* Inference.cleanup_caching (decoding.py:165-170): forget cached positions (keeps the audio). */
-int wh_task_reset(wh_task *t);
+int wh_task_reset(wh_task *t, void *stream);   /* stream-ordered (no host synchronisation) */
 /* Ragged prompts (no counterpart in the reference, whose DecodingTask shares one initial_tokens tuple between all
  * rows, decoding.py:719).  Row r's token sequence is the longest row's shifted left by lag[r]
  * (host array of n_rows ints, 0 <= lag[r] < max_prefill_tokens; NULL = all zero): it has a shorter leading prompt.

@@ -68,9 +68,11 @@ def _first_logits(model: OracleModel, feats: torch.Tensor, tokens: torch.Tensor,
 
 
 def greedy_decode(model: OracleModel, feats: torch.Tensor, initial_tokens: List[int], sample_len: int,
-                  r: SamplingRules) -> Dict:
+                  r: SamplingRules, keep_logits: bool = False) -> Dict:
     """GreedyDecoder at temperature 0 (decoding.py:277-293) inside _main_loop (:680-710).
-    Returns {"tokens": (R, n) int64 incl. the initial tokens, "sum_logprobs": [R], "no_speech_probs": [R]}."""
+    Returns {"tokens": (R, n) int64 incl. the initial tokens, "sum_logprobs": [R], "no_speech_probs": [R]} and, with
+    keep_logits, "step_logits": the filtered fp32 logits (R, V) every arg-max was taken from (test helper: margins)."""
+    kept = []
     R = feats.shape[0]
     tokens = torch.tensor([list(initial_tokens)] * R, dtype=torch.int64)
     sum_lp = torch.zeros(R)
@@ -93,10 +95,15 @@ def greedy_decode(model: OracleModel, feats: torch.Tensor, initial_tokens: List[
                 sum_lp[k] += lp
             else:
                 nxt[k] = r.eot
+        if keep_logits:
+            kept.append(logits)
         tokens = torch.cat([tokens, nxt[:, None]], dim=-1)
         if bool((tokens[:, -1] == r.eot).all()) or tokens.shape[-1] > r.n_ctx:      # :292, :705
             break
-    return {"tokens": tokens, "sum_logprobs": sum_lp.tolist(), "no_speech_probs": nsp}
+    out = {"tokens": tokens, "sum_logprobs": sum_lp.tolist(), "no_speech_probs": nsp}
+    if keep_logits:
+        out["step_logits"] = kept
+    return out
 
 
 def filtered_logits(model: OracleModel, feats: torch.Tensor, initial_tokens: List[int], sampled: List[int],

@@ -691,10 +691,12 @@ def test_kv_cache_hooks_surface(monkeypatch):
         def close(self):
             self.closed = True
             calls.append(("close",))
-    monkeypatch.setattr(mm.hip, "HipTask", FakeTask)
+    class FakeEngine:          # tasks come from the engine's cache (HipModel.acquire_task)
+        def acquire_task(self, n_audio, group, max_prefill, capture_q=False):
+            return FakeTask(self, n_audio, group, max_prefill)
     fm = _fake_model(True)
     model = mm.Whisper(mm.ModelDimensions(**fm.dims.__dict__), {}, device="cpu")
-    monkeypatch.setattr(model, "engine", lambda dtype: object())
+    monkeypatch.setattr(model, "engine", lambda dtype: FakeEngine())
     cache, hooks = model.install_kv_cache_hooks()
     assert isinstance(cache, dict) and len(hooks) == 1
     xa = torch.zeros(2, 1500, 384)

@@ -165,6 +165,104 @@ def test_large_v3_batch_invariance_and_determinism(gpu_device):
     assert len({tuple(r) for r in tok8.tolist()}) > 1                        # rows are not all the same clip
 
 
+FP16_LOGIT_BOUND = 6e-2     # |logit(fp16 engine) - logit(fp32 oracle)| asserted above at 2 + 2 layers
+
+
+def greedy_rows_match_or_near_tie(got: torch.Tensor, want: dict, n_init: int, bound: float):
+    """Row by row: HIP greedy ids == the oracle's, or at the FIRST difference the HIP token is within `bound` of the
+    oracle's arg-max in the oracle's own filtered logits (a rounding-level tie; later tokens legitimately differ).
+    Returns per-row (first divergence step or None, margin) for the report."""
+    report = []
+    wt = want["tokens"]
+    for k in range(wt.shape[0]):
+        g, w = got[k, n_init:].tolist(), wt[k, n_init:].tolist()
+        t = oracle.first_divergence(g[: len(w)], w)
+        if t is None:
+            report.append((None, 0.0))
+            continue
+        lg = want["step_logits"][t][k]
+        margin = float(lg[w[t]]) - float(lg[g[t]])
+        assert 0.0 <= margin < bound, (k, t, margin, g[t], w[t])
+        report.append((t, margin))
+    return report
+
+
+def test_large_v3_full_depth_vs_oracle(gpu_device):
+    """The benchmarked configuration itself — large-v3, 32 + 32 layers, the seed-0 weights of bench.py — against the
+    CPU oracle (restating whisper/model.py:188-249, decoding.py:680-710):
+      fp32 strict engine: log-mel -> 32-layer encoder on one clip (|d| < 2e-3), teacher-forced prefill + 8 steps of
+        2 rows (logits within 1e-3: the north-star bar), 8 greedy steps (ids exact);
+      fp16 engine (what bench.py times), 8 rows x 32 greedy steps: ids equal to the oracle's, or the first
+        difference of a row is a near-tie inside twice the fp16 logit bound; at least half of the rows agree over all
+        32 steps."""
+    from whisper_amd.synthetic import dims_for, synthetic_state_dict
+    dims = dims_for("large-v3")
+    sd = synthetic_state_dict(dims, seed=0)                         # CPU generation: the same weights on both sides
+    om = oracle.OracleModel(dims, sd)
+    tok, init, params, rules, mask = _greedy_setup(dims, 8, gpu_device, suppress_eot=True)
+
+    # ---- fp32 engine
+    model32 = hip.HipModel(dims, hip.WH_F32, hip.pack_weights(sd, dims, hip.WH_F32, gpu_device))
+    rng = np.random.default_rng(11)
+    t = np.arange(480000) / 16000.0
+    audio = (rng.standard_normal(480000) * 0.05 + 0.2 * np.sin(2 * np.pi * 330 * t)).astype(np.float32)[None]
+    filt = oracle.mel_filterbank(dims.n_mels)
+    mel = oracle.log_mel_spectrogram(audio, filt)
+    with torch.no_grad():
+        want_enc = om.encoder(mel)
+    got_mel = hip.log_mel(torch.from_numpy(audio).to(gpu_device), torch.from_numpy(filt).to(gpu_device))
+    assert (got_mel.cpu() - mel).abs().max().item() < 1e-4
+    got_enc = model32.encode(got_mel).float().cpu()
+    enc_err = (got_enc - want_enc).abs().max().item()
+    assert enc_err < 2e-3, enc_err
+
+    g = torch.Generator().manual_seed(4)
+    feats = (torch.randn(8, dims.n_audio_ctx, dims.n_audio_state, generator=g)
+             + 3.0 * torch.randn(8, 1, dims.n_audio_state, generator=g)).half().float()     # fp16-exact: both engines see the same
+    feats[0] = want_enc[0].half().float()                                                   # row 0: a real encoder output
+    T0 = len(init)
+    toks = torch.randint(0, dims.n_vocab, (2, T0 + 8), generator=g)
+    toks[:, :T0] = torch.tensor(init)
+    cache = om.new_cache()
+    with torch.no_grad():
+        want0 = om.decoder(toks[:, :T0], feats[:2], cache)
+    task = hip.HipTask(model32, 2, 1, 8)
+    try:
+        task.set_audio(feats[:2].to(gpu_device).contiguous())
+        dtoks = toks.to(gpu_device)
+        got0 = task.prefill(dtoks[:, :T0].contiguous()).cpu()
+        assert (got0 - want0).abs().max().item() < 1e-3
+        for i in range(8):
+            with torch.no_grad():
+                want = om.decoder(toks[:, T0 + i: T0 + i + 1], feats[:2], cache)[:, -1]
+            got = task.step(dtoks[:, T0 + i]).cpu()
+            err = (got - want).abs().max().item()
+            assert err < 1e-3, (i, err)
+    finally:
+        task.close()
+    with torch.no_grad():
+        want_g = oracle.greedy_decode(om, feats[:2], init, 8, rules)
+    n, got_g, _, _ = _run_greedy(model32, feats[:2].to(gpu_device), init, params, 8, gpu_device, tok)
+    assert torch.equal(got_g, want_g["tokens"])
+    del model32
+    torch.cuda.empty_cache()
+
+    # ---- fp16 engine: the bench configuration (8 rows), 32 greedy steps
+    n_steps = 32
+    tok, init, params, rules, mask = _greedy_setup(dims, n_steps, gpu_device, suppress_eot=True)
+    model16 = hip.HipModel(dims, hip.WH_F16, hip.pack_weights(sd, dims, hip.WH_F16, gpu_device))
+    with torch.no_grad():
+        want16 = oracle.greedy_decode(om, feats, init, n_steps, rules, keep_logits=True)
+    n, got16, _, _ = _run_greedy(model16, feats.to(gpu_device).half(), init, params, n_steps, gpu_device, tok)
+    assert n == len(init) + n_steps
+    report = greedy_rows_match_or_near_tie(got16, want16, len(init), 2 * FP16_LOGIT_BOUND)
+    full = sum(1 for t, _ in report if t is None)
+    print("fp16 large-v3 vs oracle, per row (first divergence step, margin):", report)
+    assert full >= 4, report
+    distinct = len({int(x) for x in want16["tokens"][:, len(init):].flatten()})
+    assert distinct >= 40                                                       # the decode is not degenerate
+
+
 @pytest.mark.parametrize("name", ["w512", "w768", "w1024"])
 @pytest.mark.parametrize("dt,tol", [(hip.WH_F32, 1e-3), (hip.WH_F16, 6e-2)])
 def test_other_widths_encoder_and_steps(gpu_device, name, dt, tol):

@@ -276,6 +276,7 @@ struct wh_task {
   int* d_lag;              // [R] ragged prompts: row r is lag[r] tokens shorter than the longest row (zeros otherwise)
   int* h_lag;              // host copy
   bool lag_on;
+  bool needs_reset;        // created, position counter / lag not zeroed yet
   int64_t* step_tokens;
   float* samp_part;        // greedy sampler stage-1 partials
   void* beam_scratch;      // beam search partials / candidates (G > 1)
@@ -360,9 +361,9 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
   }
   t->h_lag = (int*)calloc((size_t)t->R, sizeof(int));
   if (!t->h_lag) { delete t; return WH_ERR_ARG; }
-  hipError_t e = hipMemset(t->d_pos, 0, 4);
-  if (e == hipSuccess) e = hipMemset(t->d_lag, 0, (size_t)t->R * 4);
-  if (e != hipSuccess) { g_last_hip = e; free(t->h_lag); delete t; return WH_ERR_HIP; }
+  // no device work here: the position counter and the lag array are zeroed by the first wh_task_reset, which the
+  // caller issues on the stream the workspace is valid on
+  t->needs_reset = true;
   *out = t;
   return WH_OK;
 }
@@ -377,15 +378,17 @@ extern "C" void wh_task_destroy(wh_task* t) {
 
 extern "C" int wh_task_position(const wh_task* t) { return t ? t->pos : -1; }
 
-extern "C" int wh_task_reset(wh_task* t) {
+extern "C" int wh_task_reset(wh_task* t, void* stream_) {
   if (!t) return WH_ERR_ARG;
-  HIPCHK(hipMemset(t->d_pos, 0, 4));
+  hipStream_t s = (hipStream_t)stream_;
+  HIPCHK(hipMemsetAsync(t->d_pos, 0, 4, s));     // stream-ordered: no host or device-wide synchronisation
   t->pos = 0;
-  if (t->lag_on) {
-    HIPCHK(hipMemset(t->d_lag, 0, (size_t)t->R * 4));
+  if (t->lag_on || t->needs_reset) {
+    HIPCHK(hipMemsetAsync(t->d_lag, 0, (size_t)t->R * 4, s));
     memset(t->h_lag, 0, (size_t)t->R * sizeof(int));
     t->lag_on = false;
   }
+  t->needs_reset = false;
   return WH_OK;
 }
 
@@ -397,6 +400,7 @@ extern "C" int wh_task_set_lag(wh_task* t, const int32_t* lag, void* stream) {
   if (!t) return WH_ERR_ARG;
   if (t->pos != 0) return WH_ERR_STATE;
   if (t->flags & WH_TASK_CAPTURE_Q) return WH_ERR_STATE;      // captured queries are indexed by the common position
+  if (t->needs_reset) { const int rc = wh_task_reset(t, stream); if (rc != WH_OK) return rc; }
   bool any = false;
   for (int r = 0; r < t->R; ++r) {
     const int v = lag ? lag[r] : 0;
@@ -412,6 +416,7 @@ extern "C" int wh_task_set_lag(wh_task* t, const int32_t* lag, void* stream) {
 
 extern "C" int wh_task_set_audio(wh_task* t, const void* features, void* stream_) {
   if (!t || !features) return WH_ERR_ARG;
+  if (t->needs_reset) { const int rc = wh_task_reset(t, stream_); if (rc != WH_OK) return rc; }
   hipStream_t s = (hipStream_t)stream_;
   const wh_model* m = t->m;
   const wh_dims& d = m->d;

@@ -142,7 +142,7 @@ class HipInference(Inference):
             group = n_rows // n_audio if n_rows % n_audio == 0 and n_rows >= n_audio else None
             if group is None:
                 raise ValueError(f"rows ({n_rows}) must be a multiple of audio segments ({n_audio})")
-            self.task = hip.HipTask(engine, n_audio, group, max(tokens.shape[1], 8), capture_q=self.capture_q)
+            self.task = engine.acquire_task(n_audio, group, max(tokens.shape[1], 8), capture_q=self.capture_q)
             self.task.set_audio(audio_features.contiguous())
         return self.task
 

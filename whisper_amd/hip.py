@@ -87,7 +87,7 @@ SIGNATURES = {
     "wh_task_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p]),
     "wh_task_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "wh_task_rearrange": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
-    "wh_task_reset": (C.c_int, [C.c_void_p]),
+    "wh_task_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
     "wh_task_set_lag": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "wh_task_position": (C.c_int, [C.c_void_p]),
     "wh_task_greedy": (C.c_int, [C.c_void_p, C.POINTER(GreedyParams), C.c_void_p, C.c_int64, C.c_int, C.c_int,
@@ -331,14 +331,54 @@ class HipModel:
         self.handle = h
         self.stream = torch.cuda.Stream(device=self.device)
         self._enc_ws: Optional[torch.Tensor] = None
+        self._task_cache: List["HipTask"] = []          # idle tasks, most recently used last
+        self.task_cache_bytes = 24 << 30                # workspaces kept alive between windows (288 GB HBM per GPU)
+
+    # -- decoding tasks are expensive to set up (GBs of workspace, a 250-node graph capture): keep them -------------
+    def acquire_task(self, n_audio: int, n_group: int, max_prefill: int, capture_q: bool = False,
+                     stream: Optional[torch.cuda.Stream] = None) -> "HipTask":
+        """A reset task of this shape: a cached one (its workspace and captured step graph are reused) or a new one.
+        `task.close()` hands it back.  max_prefill is rounded up so that windows with prompts of different lengths
+        share a task."""
+        if max_prefill <= 8:
+            max_prefill = 8
+        elif max_prefill <= 64:
+            max_prefill = 64
+        else:
+            max_prefill = self.dims.n_text_ctx
+        key = (n_audio, n_group, max_prefill, capture_q, stream if stream is not None else self.stream)
+        for i in range(len(self._task_cache) - 1, -1, -1):
+            if self._task_cache[i].cache_key == key:
+                task = self._task_cache.pop(i)
+                task.reset()
+                return task
+        task = HipTask(self, n_audio, n_group, max_prefill, capture_q=capture_q, stream=stream)
+        task._cached = True
+        return task
+
+    def _release_task(self, task: "HipTask") -> bool:
+        if task.ws is None or task.ws.numel() > self.task_cache_bytes:
+            return False
+        self._task_cache.append(task)
+        total = sum(t.ws.numel() for t in self._task_cache)
+        while total > self.task_cache_bytes and len(self._task_cache) > 1:
+            old = self._task_cache.pop(0)
+            total -= old.ws.numel()
+            old.destroy()
+        return True
+
+    def drop_cached_tasks(self) -> None:
+        while self._task_cache:
+            self._task_cache.pop().destroy()
 
     def __del__(self):
         try:
+            self.drop_cached_tasks()
             if getattr(self, "handle", None):
                 lib().wh_model_destroy(self.handle)
                 self.handle = None
-        except Exception:
-            pass
+        except (HipError, RuntimeError, OSError, AttributeError, TypeError):
+            pass        # interpreter shutdown
 
     # -- AudioEncoder.forward ----------------------------------------------------------------------
     def encode(self, mel: torch.Tensor) -> torch.Tensor:
@@ -355,6 +395,7 @@ class HipModel:
             self._enc_ws = None
             self._enc_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         out = torch.empty(B, d.n_audio_ctx, d.n_audio_state, dtype=self.torch_dtype, device=self.device)
+        torch.cuda.set_device(self.device)             # the C ABI launches on the calling thread's current device
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
         check(lib().wh_encode(self.handle, mel.data_ptr(), int(mel.dtype == torch.float16), B, out.data_ptr(),
@@ -365,39 +406,61 @@ class HipModel:
 
 
 class HipTask:
-    """wh_task: KV caches + workspace of one DecodingTask (whisper/decoding.py:144-176 PyTorchInference)."""
+    """wh_task: KV caches + workspace of one DecodingTask (whisper/decoding.py:144-176 PyTorchInference).
+
+    No call here synchronises the device: creation touches no device memory, `reset` is a stream-ordered memset and
+    the workspace is returned to torch's allocator with `record_stream`.  `HipModel.acquire_task` keeps finished
+    tasks (workspace + captured step graph) for the next window of the same shape."""
 
     def __init__(self, model: HipModel, n_audio: int, n_group: int, max_prefill: int, capture_q: bool = False,
                  stream: Optional[torch.cuda.Stream] = None):
         self.model = model
         self.n_audio, self.n_group, self.n_rows = n_audio, n_group, n_audio * n_group
         self.max_prefill = max_prefill
+        self.capture_q = capture_q
         flags = WH_TASK_CAPTURE_Q if capture_q else 0
-        need = lib().wh_task_workspace_bytes(model.handle, n_audio, n_group, max_prefill, flags)
-        if need == 0:
-            raise HipError("wh_task_workspace_bytes: invalid arguments")
-        self.ws = torch.empty(need, dtype=torch.uint8, device=model.device)
-        h = C.c_void_p()
-        torch.cuda.synchronize(model.device)
-        check(lib().wh_task_create(model.handle, n_audio, n_group, max_prefill, flags, self.ws.data_ptr(),
-                                   self.ws.numel(), C.byref(h)), "wh_task_create")
-        self.handle = h
         self.stream = stream if stream is not None else model.stream   # independent tasks may run on own streams
+        with torch.cuda.device(model.device):
+            need = lib().wh_task_workspace_bytes(model.handle, n_audio, n_group, max_prefill, flags)
+            if need == 0:
+                raise HipError("wh_task_workspace_bytes: invalid arguments")
+            self.ws = torch.empty(need, dtype=torch.uint8, device=model.device)
+            h = C.c_void_p()
+            check(lib().wh_task_create(model.handle, n_audio, n_group, max_prefill, flags, self.ws.data_ptr(),
+                                       self.ws.numel(), C.byref(h)), "wh_task_create")
+        self.handle = h
+        self._cached = False
+        self.reset()
+
+    @property
+    def cache_key(self):
+        return (self.n_audio, self.n_group, self.max_prefill, self.capture_q, self.stream)
 
     def close(self):
+        """release: into the engine's task cache when it came from `acquire_task`, otherwise destroy"""
+        if getattr(self, "handle", None) is None:
+            return
+        if self._cached and self.model._release_task(self):
+            return
+        self.destroy()
+
+    def destroy(self):
         if getattr(self, "handle", None):
-            torch.cuda.synchronize(self.model.device)
+            # the captured step graph and the workspace may still be in flight on the task's stream: wait for THAT
+            # stream only, then hand the memory back
+            self.stream.synchronize()
             lib().wh_task_destroy(self.handle)
             self.handle = None
             self.ws = None
 
     def __del__(self):
         try:
-            self.close()
-        except Exception:
-            pass
+            self.destroy()
+        except (HipError, RuntimeError, OSError, AttributeError, TypeError):
+            pass        # interpreter shutdown: the library or torch may already be gone
 
     def _enter(self):
+        torch.cuda.set_device(self.model.device)       # the C ABI launches on the calling thread's current device
         cur = torch.cuda.current_stream(self.model.device)
         self.stream.wait_stream(cur)
         return cur
@@ -443,8 +506,9 @@ class HipTask:
         cur.wait_stream(self.stream)
 
     def reset(self):
-        torch.cuda.synchronize(self.model.device)
-        check(lib().wh_task_reset(self.handle), "wh_task_reset")
+        cur = self._enter()
+        check(lib().wh_task_reset(self.handle, stream_ptr(self.stream)), "wh_task_reset")
+        cur.wait_stream(self.stream)
 
     def set_lag(self, lag: Optional[Sequence[int]]):
         """ragged prompts: row r's sequence is the longest row's shifted left by lag[r] (include/whisper_hip.h)"""

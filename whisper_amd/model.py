@@ -91,7 +91,7 @@ class _DecoderHandle:
             n_rows, n_audio = x.shape[0], xa.shape[0]
             if n_rows % n_audio != 0:
                 raise ValueError("token rows must be a multiple of the audio batch")
-            task = hip.HipTask(engine, n_audio, n_rows // n_audio, owner.dims.n_text_ctx)
+            task = engine.acquire_task(n_audio, n_rows // n_audio, owner.dims.n_text_ctx)
             task.set_audio(xa.contiguous())
             kv_cache[_TASK_KEY] = task
         if task.position == 0 or x.shape[1] > 1:
@@ -120,7 +120,7 @@ class _DecoderHandle:
             group = n_rows // n_audio
         else:
             raise ValueError("token rows must be a multiple of the audio batch")
-        task = hip.HipTask(engine, n_audio, group, max(int(x.shape[1]), 8))
+        task = engine.acquire_task(n_audio, group, max(int(x.shape[1]), 8))
         try:
             task.set_audio(xa.contiguous())
             return task.prefill(x.contiguous().long())

@@ -78,7 +78,7 @@ def find_alignment(model: "Whisper", tokenizer: Tokenizer, text_tokens: List[int
     with torch.no_grad():
         features = model.encoder(mel.unsqueeze(0))
         engine = model.engine(features.dtype)
-        task = hip.HipTask(engine, 1, 1, max(int(tokens.numel()), 8), capture_q=True)
+        task = engine.acquire_task(1, 1, max(int(tokens.numel()), 8), capture_q=True)
         try:
             task.set_audio(features.contiguous())
             text_positions = list(range(n_sot, n_sot + len(text_tokens)))
@@ -104,6 +104,13 @@ def find_alignment(model: "Whisper", tokenizer: Tokenizer, text_tokens: List[int
     word_probabilities = [np.mean(text_token_probs[i:j]) for i, j in zip(word_boundaries[:-1], word_boundaries[1:])]
     return [WordTiming(w, t, s, e, p)
             for w, t, s, e, p in zip(words, word_tokens, start_times, end_times, word_probabilities)]
+
+
+def find_alignment_batch(model: "Whisper", tokenizer: Tokenizer, text_tokens: List[List[int]], mel: torch.Tensor,
+                         num_frames: List[int], *, medfilt_width: int = 7, qk_scale: float = 1.0) -> List[List[WordTiming]]:
+    """`find_alignment` for every clip of a batch (mel: (B, n_mels, 3000)); identical results, clip by clip."""
+    return [find_alignment(model, tokenizer, list(t), mel[i], int(num_frames[i]), medfilt_width=medfilt_width,
+                           qk_scale=qk_scale) for i, t in enumerate(text_tokens)]
 
 
 def merge_punctuations(alignment: List[WordTiming], prepended: str, appended: str):
