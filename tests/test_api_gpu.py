@@ -500,4 +500,5 @@ def test_incremental_decoder_with_kv_cache_hooks(setup, gpu_device):
     assert task.position == T
     for h in hooks:
         h.remove()
-    assert mm._TASK_KEY not in cache and task.handle is None
+    # the caches were released: destroyed, or parked in the engine's task cache for the next decode of this shape
+    assert mm._TASK_KEY not in cache and (task.handle is None or task in model.engine(feats.dtype)._task_cache)
