@@ -248,9 +248,23 @@ int wh_dtw_trace(const float *x, int N, int M, int8_t *trace_out, void *stream);
  * (from wh_task_cross_qk) -> crop to the first n_frames frames, softmax(qk * qk_scale) over frames, z-normalise
  * over the token axis (biased std), median filter of odd `width` along frames, mean over heads, keep token rows
  * [row_begin, row_end) and negate -> out fp32 [row_end-row_begin][n_frames], the cost matrix handed to dtw.
- * scratch: >= 2*n_heads*n_tok*n_frames*4 bytes. */
+ * scratch: >= 2*n_heads*n_tok*n_frames*4 + 16 bytes. */
 int wh_align_matrix(const float *qk, int n_heads, int n_tok, int n_audio_ctx, int n_frames, int width,
                     int row_begin, int row_end, float qk_scale, float *out, void *scratch, void *stream);
+
+/* find_alignment for every row of a task at once (timing.py:186-216 per clip; BASELINE configs[4]: a batch of clips
+ * with word_timestamps).  The task (WH_TASK_CAPTURE_Q, one row per clip) has been teacher-forced with
+ * [sot sequence, <|notimestamps|>, text tokens, <|endoftext|>] of every clip (shorter rows padded on the right).  For row r
+ * the alignment covers tokens [0, n_tok[r]) and frames [0, n_frames[r]):
+ *   QK of the (layer, head) pairs -> softmax over frames -> z-norm over tokens -> median(width) -> -mean over heads,
+ *   rows [row_begin, n_tok[r] - 1) -> cost_out [n_rows][Nmax][Fmax] fp32 (Nmax = max n_tok - 1 - row_begin, Fmax = max
+ *   n_frames) -> dtw: trace_out row r at byte r * trace_stride, dense [(N_r + 1)][(n_frames[r] + 1)] int8 (dtw_cpu codes).
+ * n_tok / n_frames / layers / heads are host arrays.  Results are bit-identical to wh_task_cross_qk + wh_align_matrix +
+ * wh_dtw_trace clip by clip (the single-clip entry points run the same kernels as a batch of one). */
+size_t wh_align_batch_scratch_bytes(int n_rows, int n_pairs, int max_tok, int n_audio_ctx, int max_frames);
+int wh_task_align_batch(wh_task *t, const int32_t *layers, const int32_t *heads, int n_pairs, const int32_t *n_tok,
+                        const int32_t *n_frames, int width, int row_begin, float qk_scale, float *cost_out,
+                        int8_t *trace_out, int64_t trace_stride, void *scratch, size_t scratch_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -61,11 +61,11 @@ def test_hip_path_on_jfk(gpu_device, tmp_path):
     assert [t for s in r["segments"] for t in s["tokens"]] == J["tokens"].tolist()       # greedy token ids: exact
     bounds = np.array([[s["seek"], s["start"], s["end"]] for s in r["segments"]])
     assert np.array_equal(bounds[:, 0], J["seg_bounds"][:, 0])
-    assert np.abs(bounds[:, 1:] - J["seg_bounds"][:, 1:]).max() <= 0.0201
+    assert np.abs(bounds[:, 1:] - J["seg_bounds"][:, 1:]).max() < 1e-6
     assert np.abs(np.array([s["avg_logprob"] for s in r["segments"]]) - J["seg_logprob"]).max() < 1e-3
     words = np.array([[w["start"], w["end"]] for s in r["segments"] for w in s["words"]]).reshape(-1, 2)
     assert words.shape == J["word_times"].shape
-    assert np.abs(words - J["word_times"]).max() <= 0.0201                                # one 20 ms frame
+    assert np.abs(words - J["word_times"]).max() < 1e-6                                  # fp32 engine: frame indices exact
     res = whisper_amd.decode(model, whisper_amd.pad_or_trim(mel, 3000),
                              whisper_amd.DecodingOptions(language="en", fp16=False, without_timestamps=True, sample_len=40))
     assert res.tokens == J["greedy_nots_tokens"].tolist()

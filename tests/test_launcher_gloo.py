@@ -99,3 +99,31 @@ def test_balanced_shards():
         assert sorted(i for s in shards for i in s) == list(range(n))
         loads = [sum(costs[i] for i in s) for s in shards]
         assert max(loads) - min(loads) <= max(costs)
+
+
+@pytest.mark.gpu
+def test_broadcast_weights_nccl_world1(gpu_device):
+    """the RCCL leg of the launcher on the real device: process group "nccl" (= RCCL on ROCm), world size 1 —
+    `dist.broadcast` of a packed blob must run through the library and leave the bytes intact (a single-GPU box cannot
+    show more; the N-rank path is the same call, covered on gloo above)"""
+    import torch.distributed as dist
+    from whisper_amd import hip
+    from whisper_amd.launcher import broadcast_weights
+    from whisper_amd.synthetic import dims_for, synthetic_state_dict
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dims = dims_for("micro.en")
+    blob = hip.pack_weights(synthetic_state_dict(dims, seed=1), dims, hip.WH_F16, gpu_device)
+    ref = blob.clone()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu_device)
+    try:
+        out = broadcast_weights(blob, dims, hip.WH_F16, gpu_device, dist)      # world 1: returned as is
+        assert out is blob
+        dist.broadcast(blob, src=0)                                             # the collective itself, on RCCL
+        t = torch.ones(4, device=gpu_device)
+        dist.all_reduce(t)
+        torch.cuda.synchronize(gpu_device)
+        assert torch.equal(blob, ref) and t.tolist() == [1.0] * 4
+        assert dist.get_backend() == "nccl"
+    finally:
+        dist.destroy_process_group()

@@ -1010,6 +1010,60 @@ extern "C" int wh_task_cross_qk(wh_task* t, int row, const int32_t* layers, cons
   return WH_OK;
 }
 
+// ---- batched find_alignment core --------------------------------------------------------------------------------
+static size_t align_batch_carve(int R, int P, int Tmax, int Ta, int Fmax, void* base, float** qk, float** w, int** ints) {
+  Carver c(base);
+  *qk = (float*)c.take((size_t)R * P * Tmax * Ta * 4);
+  *w = (float*)c.take((size_t)2 * R * P * Tmax * Fmax * 4);
+  *ints = (int*)c.take((size_t)(2 * R + 2 * P) * 4);
+  return align_up(c.off, 256);
+}
+
+extern "C" size_t wh_align_batch_scratch_bytes(int n_rows, int n_pairs, int max_tok, int n_audio_ctx, int max_frames) {
+  if (n_rows <= 0 || n_pairs <= 0 || max_tok <= 0 || n_audio_ctx <= 0 || max_frames <= 0) return 0;
+  float *a, *b; int* i;
+  return align_batch_carve(n_rows, n_pairs, max_tok, n_audio_ctx, max_frames, nullptr, &a, &b, &i);
+}
+
+extern "C" int wh_task_align_batch(wh_task* t, const int32_t* layers, const int32_t* heads, int n_pairs,
+                                   const int32_t* n_tok, const int32_t* n_frames, int width, int row_begin, float qk_scale,
+                                   float* cost_out, int8_t* trace_out, int64_t trace_stride, void* scratch,
+                                   size_t scratch_bytes, void* stream_) {
+  if (!t || !layers || !heads || !n_tok || !n_frames || !cost_out || !trace_out || !scratch || n_pairs <= 0) return WH_ERR_ARG;
+  if (!t->qcap) return WH_ERR_STATE;
+  if (width <= 0 || (width & 1) == 0 || width > 63 || row_begin < 0) return WH_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream_;
+  const wh_dims& d = t->m->d;
+  const int R = t->R, D = d.n_text_state, C = d.n_text_ctx, Ta = d.n_audio_ctx;
+  int Tmax = 0, Fmax = 0;
+  for (int r = 0; r < R; ++r) {
+    if (n_tok[r] <= row_begin + 1 || n_tok[r] > t->pos || n_frames[r] <= 0 || n_frames[r] > Ta) return WH_ERR_ARG;
+    if (n_tok[r] > Tmax) Tmax = n_tok[r];
+    if (n_frames[r] > Fmax) Fmax = n_frames[r];
+  }
+  for (int i = 0; i < n_pairs; ++i)
+    if (layers[i] < 0 || layers[i] >= d.n_text_layer || heads[i] < 0 || heads[i] >= d.n_text_head) return WH_ERR_ARG;
+  const int Nmax = Tmax - 1 - row_begin;
+  if (Nmax > 8192) return WH_ERR_LIMIT;
+  if (trace_stride < (int64_t)(Nmax + 1) * (Fmax + 1)) return WH_ERR_ARG;
+  float *qk, *w; int* ints;
+  if (align_batch_carve(R, n_pairs, Tmax, Ta, Fmax, scratch, &qk, &w, &ints) > scratch_bytes) return WH_ERR_WORKSPACE;
+  std::vector<int> h((size_t)2 * R + 2 * n_pairs);
+  for (int r = 0; r < R; ++r) { h[r] = n_tok[r]; h[R + r] = n_frames[r]; }
+  for (int i = 0; i < n_pairs; ++i) { h[2 * R + i] = layers[i]; h[2 * R + n_pairs + i] = heads[i]; }
+  HIPCHK(hipMemcpyAsync(ints, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));       // `h` is host stack memory
+  const int *d_ntok = ints, *d_nfr = ints + R, *d_layers = ints + 2 * R, *d_heads = ints + 2 * R + n_pairs;
+  const size_t es = t->m->esize;
+  (void)es;
+  HIPCHK(launch_cross_qk_batch(t->qcap, (int64_t)R * C * D, (int64_t)C * D, D, t->cross_kv, (int64_t)t->B * Ta * 2 * D,
+                               (int64_t)Ta * 2 * D, t->G, d_layers, d_heads, n_pairs, d_ntok, R, Tmax, Ta, qk,
+                               t->m->dtype, s));
+  HIPCHK(launch_align_batch(qk, d_ntok, d_nfr, R, n_pairs, Tmax, Ta, Fmax, width, row_begin, 1, qk_scale, cost_out, Nmax, w, s));
+  HIPCHK(launch_dtw_batch(cost_out, d_ntok, d_nfr, R, Tmax, Fmax, row_begin, 1, Nmax, trace_out, trace_stride, s));
+  return WH_OK;
+}
+
 extern "C" int wh_median_filter(const float* x, float* out, int64_t rows, int n, int width, void* stream) {
   if (!x || !out || rows < 0 || n <= 0) return WH_ERR_ARG;
   if (width <= 0 || (width & 1) == 0 || width > 63) return WH_ERR_ARG;

@@ -591,9 +591,47 @@ __global__ void cross_qk_kernel(const T* __restrict__ q, int64_t q_ld, const T* 
   out[(int64_t)t * Tk + j] = s * SCALE;
 }
 
+// all (row, pair) score planes of a batch in one launch (word timestamps for a batch of clips)
+template <typename T>
+__global__ void cross_qk_batch_kernel(const T* __restrict__ qcap, int64_t q_layer_stride, int64_t q_row_stride, int D,
+                                      const T* __restrict__ cross_kv, int64_t kv_layer_stride, int64_t kv_audio_stride,
+                                      int kv_group, const int* __restrict__ layers, const int* __restrict__ heads,
+                                      int n_pairs, const int* __restrict__ ntok, int Tmax, int Tk, float* __restrict__ out) {
+  __shared__ float qs[64];
+  const int t = blockIdx.y;
+  const int r = blockIdx.z / n_pairs, p = blockIdx.z - r * n_pairs;
+  if (t >= ntok[r]) return;                        // workgroup-uniform
+  const int l = layers[p], head = heads[p];
+  const T* q = qcap + l * q_layer_stride + r * q_row_stride + (int64_t)t * D + head * 64;
+  if (threadIdx.x < 64) qs[threadIdx.x] = to_f32(q[threadIdx.x]);
+  __syncthreads();
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Tk) return;
+  const T* kr = cross_kv + l * kv_layer_stride + (r / kv_group) * kv_audio_stride + (int64_t)j * 2 * D + head * 64;
+  float s = 0.f;
+#pragma unroll 16
+  for (int d = 0; d < 64; ++d) s = __builtin_fmaf(qs[d], to_f32(kr[d]), s);
+  out[(((int64_t)r * n_pairs + p) * Tmax + t) * Tk + j] = s * SCALE;
+}
+
 }  // namespace
 
 namespace whk {
+
+hipError_t launch_cross_qk_batch(const void* qcap, int64_t q_layer_stride, int64_t q_row_stride, int D, const void* cross_kv,
+                                 int64_t kv_layer_stride, int64_t kv_audio_stride, int kv_group, const int* d_layers,
+                                 const int* d_heads, int n_pairs, const int* d_ntok, int R, int Tmax, int Tk, float* out,
+                                 int dtype, hipStream_t stream) {
+  if ((int64_t)R * n_pairs > 65535) return hipErrorInvalidValue;
+  dim3 grid((Tk + 255) / 256, Tmax, R * n_pairs), block(256);
+  if (dtype == 1)
+    hipLaunchKernelGGL((cross_qk_batch_kernel<half_t>), grid, block, 0, stream, (const half_t*)qcap, q_layer_stride, q_row_stride, D,
+                       (const half_t*)cross_kv, kv_layer_stride, kv_audio_stride, kv_group, d_layers, d_heads, n_pairs, d_ntok, Tmax, Tk, out);
+  else
+    hipLaunchKernelGGL((cross_qk_batch_kernel<float>), grid, block, 0, stream, (const float*)qcap, q_layer_stride, q_row_stride, D,
+                       (const float*)cross_kv, kv_layer_stride, kv_audio_stride, kv_group, d_layers, d_heads, n_pairs, d_ntok, Tmax, Tk, out);
+  return hipGetLastError();
+}
 
 hipError_t launch_attn_generic(const AttnArgs& a, int batch, int dtype, hipStream_t stream) {
   dim3 grid((a.Tq + GQ - 1) / GQ, a.H, batch), block(256);

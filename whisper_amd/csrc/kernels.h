@@ -99,6 +99,12 @@ constexpr int DEC_ATTN_MAX_SPLITS = 16;
 int attn_decode_capacity(int dtype);
 hipError_t launch_attn_decode(const DecAttnArgs& a, int dtype, hipStream_t stream);
 // scores of selected (layer, head) pairs: out[pair][t][j] = scale^2 * q[t]·k[j]
+// batched: row r (grid.z = r * n_pairs + pair), queries qcap [layer][R][C][D] at positions [0, Tmax), keys of audio
+// r / kv_group in cross_kv [layer][B * Tk][2D]; out [R][n_pairs][Tmax][Tk]; positions >= ntok[r] are skipped
+hipError_t launch_cross_qk_batch(const void* qcap, int64_t q_layer_stride, int64_t q_row_stride, int D, const void* cross_kv,
+                                 int64_t kv_layer_stride, int64_t kv_audio_stride, int kv_group, const int* d_layers,
+                                 const int* d_heads, int n_pairs, const int* d_ntok, int R, int Tmax, int Tk, float* out,
+                                 int dtype, hipStream_t stream);
 hipError_t launch_cross_qk(const void* q, int64_t q_ld, const void* k, int64_t k_ld, int head, int n_tok,
                            int Tk, float* out, int dtype, hipStream_t stream);
 
@@ -179,8 +185,17 @@ hipError_t launch_beam_step(const BeamArgs& a, int B, hipStream_t stream);
 hipError_t launch_median_filter(const float* x, float* out, int64_t rows, int n, int width,
                                 hipStream_t stream);
 hipError_t launch_dtw(const float* x, int N, int M, int8_t* trace, hipStream_t stream);
+// batched find_alignment post-processing: clip b has ntok[b] token rows and nfr[b] frames (device arrays) inside slabs
+// qk [clips][H][Tmax][Tk]; cost [clips][Nmax][Fmax] = -mean over heads of rows [row_begin, ntok[b] - row_tail);
+// scratch: 2 * clips * H * Tmax * Fmax floats
+hipError_t launch_align_batch(const float* qk, const int* d_ntok, const int* d_nfr, int clips, int H, int Tmax, int Tk,
+                              int Fmax, int width, int row_begin, int row_tail, float qk_scale, float* cost, int Nmax,
+                              float* scratch, hipStream_t stream);
+// dtw of every clip's cost matrix; trace of clip b dense [(N_b + 1)][(F_b + 1)] at trace + b * trace_bs
+hipError_t launch_dtw_batch(const float* cost, const int* d_ntok, const int* d_nfr, int clips, int Tmax, int Fmax,
+                            int row_begin, int row_tail, int Nmax, int8_t* trace, int64_t trace_bs, hipStream_t stream);
 // qk [H][T][Tk] -> softmax over first F frames, z-norm over tokens, median(width), -mean over heads of rows
-// [row_begin,row_end) -> out [rows][F]; scratch: 2*H*T*F floats
+// [row_begin,row_end) -> out [rows][F]; scratch: 2*H*T*F floats + 2 ints
 hipError_t launch_align_matrix(const float* qk, int H, int T, int Tk, int F, int width, int row_begin,
                                int row_end, float qk_scale, float* out, float* scratch, hipStream_t stream);
 

@@ -98,6 +98,10 @@ SIGNATURES = {
     "wh_task_cross_qk": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "wh_task_bench_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
+    "wh_align_batch_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "wh_task_align_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "wh_median_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "wh_dtw_trace": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "wh_align_matrix": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -586,6 +590,36 @@ class HipTask:
         return out
 
 
+    def align_batch(self, layers: Sequence[int], heads: Sequence[int], n_tok: Sequence[int], n_frames: Sequence[int],
+                    width: int, row_begin: int, qk_scale: float = 1.0):
+        """find_alignment core for every row of the task (wh_task_align_batch).  Returns (cost [R][Nmax][Fmax] fp32,
+        traces: list of int8 numpy arrays [(N_r + 1)][(n_frames[r] + 1)])."""
+        R, P = self.n_rows, len(layers)
+        assert len(n_tok) == R and len(n_frames) == R
+        Tmax, Fmax = max(n_tok), max(n_frames)
+        Nmax = Tmax - 1 - row_begin
+        dev = self.model.device
+        need = lib().wh_align_batch_scratch_bytes(R, P, Tmax, self.model.dims.n_audio_ctx, Fmax)
+        scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+        cost = torch.empty(R, Nmax, Fmax, dtype=torch.float32, device=dev)
+        stride = (Nmax + 1) * (Fmax + 1)
+        trace = torch.empty(R, stride, dtype=torch.int8, device=dev)
+        arr = lambda v: (C.c_int32 * len(v))(*[int(x) for x in v])
+        cur = self._enter()
+        check(lib().wh_task_align_batch(self.handle, arr(layers), arr(heads), P, arr(n_tok), arr(n_frames), width, row_begin,
+                                        float(qk_scale), cost.data_ptr(), trace.data_ptr(), stride, scratch.data_ptr(),
+                                        scratch.numel(), stream_ptr(self.stream)), "wh_task_align_batch")
+        cur.wait_stream(self.stream)
+        for t_ in (scratch, cost, trace):
+            t_.record_stream(self.stream)
+        host = trace.cpu().numpy()
+        traces = []
+        for r in range(R):
+            n, m = n_tok[r] - 1 - row_begin, n_frames[r]
+            traces.append(host[r, : (n + 1) * (m + 1)].reshape(n + 1, m + 1))
+        return cost, traces
+
+
 # ---------------------------------------------------------------------------------------------------
 # stand-alone kernels
 # ---------------------------------------------------------------------------------------------------
@@ -634,7 +668,7 @@ def align_matrix(qk: torch.Tensor, n_frames: int, width: int, row_begin: int, ro
     q = qk.contiguous().float()
     H, T, Tk = q.shape
     out = torch.empty(row_end - row_begin, n_frames, dtype=torch.float32, device=q.device)
-    scratch = torch.empty(2 * H * T * n_frames, dtype=torch.float32, device=q.device)
+    scratch = torch.empty(2 * H * T * n_frames + 4, dtype=torch.float32, device=q.device)
     s = torch.cuda.current_stream(q.device)
     check(lib().wh_align_matrix(q.data_ptr(), H, T, Tk, n_frames, width, row_begin, row_end, float(qk_scale),
                                 out.data_ptr(), scratch.data_ptr(), stream_ptr(s)), "wh_align_matrix")

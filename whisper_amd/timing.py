@@ -93,6 +93,12 @@ def find_alignment(model: "Whisper", tokenizer: Tokenizer, text_tokens: List[int
         matrix = hip.align_matrix(qk, num_frames // 2, medfilt_width, n_sot, int(tokens.numel()) - 1, qk_scale)
         text_indices, time_indices = dtw(matrix)
 
+    return _words_from_path(tokenizer, list(text_tokens), text_token_probs, text_indices, time_indices)
+
+
+def _words_from_path(tokenizer: Tokenizer, text_tokens: List[int], text_token_probs: List[float],
+                     text_indices: np.ndarray, time_indices: np.ndarray) -> List[WordTiming]:
+    """token / frame path -> word boundaries (reference timing.py:218-242)"""
     words, word_tokens = tokenizer.split_to_word_tokens(text_tokens + [tokenizer.eot])
     if len(word_tokens) <= 1:
         return []          # only EOT: nothing to align
@@ -106,11 +112,53 @@ def find_alignment(model: "Whisper", tokenizer: Tokenizer, text_tokens: List[int
             for w, t, s, e, p in zip(words, word_tokens, start_times, end_times, word_probabilities)]
 
 
+ALIGN_BATCH_SCRATCH_BYTES = 6 << 30      # bound on the QK / softmax slabs of one find_alignment_batch chunk
+
+
 def find_alignment_batch(model: "Whisper", tokenizer: Tokenizer, text_tokens: List[List[int]], mel: torch.Tensor,
                          num_frames: List[int], *, medfilt_width: int = 7, qk_scale: float = 1.0) -> List[List[WordTiming]]:
-    """`find_alignment` for every clip of a batch (mel: (B, n_mels, 3000)); identical results, clip by clip."""
-    return [find_alignment(model, tokenizer, list(t), mel[i], int(num_frames[i]), medfilt_width=medfilt_width,
-                           qk_scale=qk_scale) for i, t in enumerate(text_tokens)]
+    """`find_alignment` for every clip of a batch — mel (B, n_mels, 3000), one token list and frame count per clip —
+    with identical results, clip by clip (BASELINE configs[4]: word timestamps over a batch).  One encoder pass, ONE
+    teacher-forced decoder pass over all clips (rows padded on the right; causal attention keeps the padding out of the
+    real positions), one launch each for the alignment heads' QK, softmax, z-norm, median, head mean and DTW
+    (wh_task_align_batch, a workgroup per clip for the DTW wavefront); only the back-trace walk is host code."""
+    B = len(text_tokens)
+    out: List[List[WordTiming]] = [[] for _ in range(B)]
+    live = [i for i in range(B) if len(text_tokens[i]) > 0]
+    if not live:
+        return out
+    n_sot = len(tokenizer.sot_sequence)
+    heads = model.alignment_heads.indices().T.tolist()
+    dims = model.dims
+    # chunk so that the fp32 score slabs stay bounded: (n_audio_ctx + 2 F) floats per (clip, pair, token)
+    tmax_all = max(len(text_tokens[i]) for i in live) + n_sot + 2
+    per_clip = len(heads) * tmax_all * (dims.n_audio_ctx + 2 * (max(num_frames) // 2)) * 4
+    chunk = max(1, min(len(live), ALIGN_BATCH_SCRATCH_BYTES // max(per_clip, 1)))
+    with torch.no_grad():
+        for c0 in range(0, len(live), chunk):
+            ids = live[c0: c0 + chunk]
+            rows = [[*tokenizer.sot_sequence, tokenizer.no_timestamps, *text_tokens[i], tokenizer.eot] for i in ids]
+            n_tok = [len(r) for r in rows]
+            Tmax = max(n_tok)
+            tokens = torch.tensor([r + [tokenizer.eot] * (Tmax - len(r)) for r in rows], device=model.device)
+            features = model.encoder(mel[ids])
+            engine = model.engine(features.dtype)
+            task = engine.acquire_task(len(ids), 1, max(Tmax, 8), capture_q=True)
+            try:
+                task.set_audio(features.contiguous())
+                n_text_max = Tmax - n_sot - 2
+                logits = task.prefill(tokens.contiguous(), sel=list(range(n_sot, n_sot + n_text_max)))   # (rows, n_text_max, V)
+                cost, traces = task.align_batch([h[0] for h in heads], [h[1] for h in heads], n_tok,
+                                                [int(num_frames[i]) // 2 for i in ids], medfilt_width, n_sot, qk_scale)
+            finally:
+                task.close()
+            for k, i in enumerate(ids):
+                tt = list(text_tokens[i])
+                probs = logits[k, : len(tt), : tokenizer.eot].softmax(dim=-1)
+                text_token_probs = probs[torch.arange(len(tt)), torch.tensor(tt)].tolist()
+                text_indices, time_indices = backtrace(traces[k])
+                out[i] = _words_from_path(tokenizer, tt, text_token_probs, text_indices, time_indices)
+    return out
 
 
 def merge_punctuations(alignment: List[WordTiming], prepended: str, appended: str):
