@@ -532,6 +532,8 @@ def test_transcribe_word_timestamp_seeking_matches_reference(ref, monkeypatch):
             seg["words"] = words
     monkeypatch.setattr(mine_tr, "add_word_timestamps", fake_words)
     monkeypatch.setattr(ref_tr, "add_word_timestamps", fake_words)
+    # the state machine asks its driver for the alignment (so that transcribe_batch can batch it); stand-in aligner
+    monkeypatch.setattr(mine_tr, "find_alignment", lambda *a, **k: [])
     filt = oracle.mel_filterbank(80)
     monkeypatch.setattr(mine_tr, "log_mel_spectrogram", lambda a, n_mels=80, padding=0, device=None: oracle.log_mel_spectrogram(a, filt, padding=padding))
     rng = np.random.default_rng(2)
@@ -620,6 +622,51 @@ def test_transcribe_batch_loads_files_concurrently(monkeypatch, tmp_path):
     assert [g["text"] for g in got] == [w["text"] for w in want[:3]]
     with pytest.raises(RuntimeError, match="Failed to load audio"):
         mine_tr.transcribe_batch(_FunctionalModel(mine.DecodingResult, tk), list(arrays) + [str(tmp_path / "missing.wav")], **kw)
+
+
+def test_transcribe_batch_bounds_active_files(monkeypatch, tmp_path):
+    """memory follows the window, not the total audio: with max_active_files = 2 at most two files are loaded and hold
+    a whole-file spectrogram at any time, a new file starts only when one finishes, and the results equal the
+    unbounded run (file by file state machines are independent)"""
+    import oracle
+    import whisper_amd  # noqa: F401
+    mine_tr = sys.modules["whisper_amd.transcribe"]
+    from whisper_amd import decoding as mine
+    from whisper_amd.tokenizer import get_tokenizer
+    tk = get_tokenizer(True, num_languages=99, language="en", task="transcribe")
+    filt = oracle.mel_filterbank(80)
+    live = {"mels": 0, "peak": 0, "loads": []}
+
+    class CountedMel(torch.Tensor):
+        pass
+
+    def counted_mel(a, n_mels=80, padding=0, device=None):
+        m = oracle.log_mel_spectrogram(a, filt, padding=padding)
+        live["mels"] += 1
+        live["peak"] = max(live["peak"], live["mels"])
+        import weakref
+        weakref.finalize(m, lambda: live.__setitem__("mels", live["mels"] - 1))
+        return m
+    monkeypatch.setattr(mine_tr, "log_mel_spectrogram", counted_mel)
+    rng = np.random.default_rng(5)
+    arrays = {str(tmp_path / f"g{i}.wav"): (rng.standard_normal(16000 * n) * 0.01).astype(np.float32)
+              for i, n in enumerate((35, 64, 20, 50, 31, 45))}
+
+    def fake_load(path, sr=16000):
+        live["loads"].append((path, live["mels"]))
+        return arrays[path]
+    monkeypatch.setattr(mine_tr, "load_audio", fake_load)
+    kw = dict(language="en", fp16=False, temperature=(0.0, 0.2))
+    want = mine_tr.transcribe_batch(_FunctionalModel(mine.DecodingResult, tk), list(arrays), **kw)
+    import gc
+    gc.collect()
+    live.update(mels=0, peak=0, loads=[])
+    got = mine_tr.transcribe_batch(_FunctionalModel(mine.DecodingResult, tk), list(arrays), max_active_files=2, **kw)
+    gc.collect()
+    assert [g["segments"] for g in got] == [w["segments"] for w in want]
+    assert live["peak"] <= 2, live
+    assert [p for p, _ in live["loads"]] == list(arrays)          # admitted in input order, later ones only after a finish
+    assert all(n <= 1 for _, n in live["loads"][2:]), live["loads"]
 
 
 def test_loader_and_filter_error_conventions(ref, tmp_path):

@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import itertools
 from dataclasses import dataclass
-from typing import TYPE_CHECKING, List
+from typing import TYPE_CHECKING, List, Optional
 
 import numpy as np
 import torch
@@ -185,16 +185,24 @@ def merge_punctuations(alignment: List[WordTiming], prepended: str, appended: st
         j += 1
 
 
+def alignment_text_tokens(segments: List[dict], tokenizer: Tokenizer) -> List[int]:
+    """the token list add_word_timestamps aligns: the text tokens of all segments of the window (timing.py:293-297)"""
+    return list(itertools.chain.from_iterable([t for t in seg["tokens"] if t < tokenizer.eot] for seg in segments))
+
+
 def add_word_timestamps(*, segments: List[dict], model: "Whisper", tokenizer: Tokenizer, mel: torch.Tensor,
                         num_frames: int, prepend_punctuations: str = "\"'“¿([{-",
                         append_punctuations: str = "\"'.。,，!！?？:：”)]}、", last_speech_timestamp: float,
-                        **kwargs):
-    """attach a "words" list to every segment (reference timing.py:279-388, same clipping heuristics)"""
+                        alignment: Optional[List[WordTiming]] = None, **kwargs):
+    """attach a "words" list to every segment (reference timing.py:279-388, same clipping heuristics).
+    `alignment` (extension): the result of find_alignment for this window when the caller already has it —
+    transcribe_batch aligns the windows of many files in one find_alignment_batch pass."""
     if len(segments) == 0:
         return
     per_segment = [[t for t in seg["tokens"] if t < tokenizer.eot] for seg in segments]
     text_tokens = list(itertools.chain.from_iterable(per_segment))
-    alignment = find_alignment(model, tokenizer, text_tokens, mel, num_frames, **kwargs)
+    if alignment is None:
+        alignment = find_alignment(model, tokenizer, text_tokens, mel, num_frames, **kwargs)
 
     durations = np.array([w.end - w.start for w in alignment])
     durations = durations[durations.nonzero()]

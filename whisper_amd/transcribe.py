@@ -21,7 +21,7 @@ from .audio import (FRAMES_PER_SECOND, HOP_LENGTH, N_FRAMES, N_SAMPLES, SAMPLE_R
 from dataclasses import replace
 
 from .decoding import DecodingOptions, DecodingResult, DecodingTask
-from .timing import add_word_timestamps
+from .timing import add_word_timestamps, alignment_text_tokens, find_alignment, find_alignment_batch
 from .tokenizer import LANGUAGES, get_tokenizer
 from .utils import exact_div, format_timestamp, get_end, make_safe
 
@@ -55,6 +55,15 @@ def _first_segment_with_words(segments: List[dict]) -> Optional[dict]:
         if s["words"]:
             return s
     return None
+
+
+class _AlignRequest:
+    """what a file's state machine yields when it needs the word alignment of the window it just decoded; the driver
+    answers with find_alignment's result (one file) or one row of find_alignment_batch (many files)"""
+
+    def __init__(self, text_tokens: List[int], mel: torch.Tensor, num_frames: int, tokenizer, language: str, task: str):
+        self.text_tokens, self.mel, self.num_frames = text_tokens, mel, num_frames
+        self.tokenizer, self.language, self.task = tokenizer, language, task
 
 
 class _Transcriber:
@@ -115,9 +124,13 @@ class _Transcriber:
         """one file, windows decoded one at a time (the reference's control flow)"""
         walk = self._walk(audio)
         try:
-            segment = next(walk)
+            request = next(walk)
             while True:
-                segment = walk.send(self.decode_with_fallback(segment))
+                if isinstance(request, _AlignRequest):
+                    request = walk.send(find_alignment(self.model, request.tokenizer, request.text_tokens, request.mel,
+                                                       request.num_frames))
+                else:
+                    request = walk.send(self.decode_with_fallback(request))
         except StopIteration as stop:
             return stop.value
 
@@ -266,10 +279,15 @@ class _Transcriber:
                     seek += segment_size
 
                 if self.word_timestamps:
+                    # the alignment itself (encoder + teacher-forced pass + DTW) is the driver's job: it may batch the
+                    # requests of many files
+                    alignment = yield _AlignRequest(alignment_text_tokens(current_segments, tokenizer), mel_segment,
+                                                    segment_size, tokenizer, language, task)
                     add_word_timestamps(
                         segments=current_segments, model=model, tokenizer=tokenizer, mel=mel_segment,
                         num_frames=segment_size, prepend_punctuations=self.prepend_punctuations,
-                        append_punctuations=self.append_punctuations, last_speech_timestamp=last_speech_timestamp)
+                        append_punctuations=self.append_punctuations, last_speech_timestamp=last_speech_timestamp,
+                        alignment=alignment)
 
                     if not single_timestamp_ending:
                         last_word_end = get_end(current_segments)
@@ -406,7 +424,10 @@ def _load_all(audios) -> list:
     GIL) instead of one after the other at the start of every file's state machine; arrays pass through untouched"""
     paths = [i for i, a in enumerate(audios) if isinstance(a, str)]
     out = list(audios)
-    if len(paths) < 2:
+    if len(paths) == 0:
+        return out
+    if len(paths) == 1:
+        out[paths[0]] = load_audio(out[paths[0]])
         return out
     from concurrent.futures import ThreadPoolExecutor
     from .utils import usable_cores
@@ -416,7 +437,8 @@ def _load_all(audios) -> list:
     return out
 
 
-def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, **kwargs) -> List[dict]:
+def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, max_active_files: Optional[int] = None,
+                     **kwargs) -> List[dict]:
     """Transcribe several files at once (no counterpart in the reference, which is strictly
     one file at a time).  Every file keeps its own seek / prompt / fallback state machine exactly as `transcribe`;
     the driver advances them in lock-step and decodes the windows that are pending at the same moment — and whose
@@ -425,7 +447,10 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, **kwargs
     share a greedy call; beam search batches rows of equal prompt length).  Results are the same dicts `transcribe`
     returns, in input order.  Windows of one file stay sequential (seek and prompt depend on the previous window).
     Windows whose result trips the temperature-fallback criteria climb the temperature ladder together: the next
-    rung decodes them as a batch again (sampling runs on the device, `best_of` rows per window)."""
+    rung decodes them as a batch again (sampling runs on the device, `best_of` rows per window).  With
+    `word_timestamps` the alignments of the windows just decoded are computed together (find_alignment_batch).
+    At most `max_active_files` (default 2 * batch_size) files are in flight: only those are decoded to PCM and keep
+    their whole-file spectrogram on the device; the next file starts when one finishes."""
     names = ("verbose", "temperature", "compression_ratio_threshold", "logprob_threshold", "no_speech_threshold",
              "condition_on_previous_text", "initial_prompt", "carry_initial_prompt", "word_timestamps",
              "prepend_punctuations", "append_punctuations", "clip_timestamps", "hallucination_silence_threshold")
@@ -435,35 +460,74 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, **kwargs
                     prepend_punctuations="\"'“¿([{-", append_punctuations="\"'.。,，!！?？:：”)]}、",
                     clip_timestamps="0", hallucination_silence_threshold=None)
     fixed = {k: kwargs.pop(k, defaults[k]) for k in names}
-    audios = _load_all(audios)
+    audios = list(audios)
+    if max_active_files is None:
+        max_active_files = 2 * batch_size
     workers = [_Transcriber(model, *[fixed[k] for k in names], dict(kwargs)) for _ in audios]
-    mels = [None] * len(audios)
-    if kwargs.get("language") is None and model.is_multilingual and len(audios) > 1:
-        # language identification (transcribe.py:139-152) for all files in batched passes instead of one encoder pass +
-        # one decoder step per file; every state machine then starts with its language set, as if it had been given
-        dtype = torch.float16 if kwargs.get("fp16", True) and model.device != torch.device("cpu") else torch.float32
-        mels = [log_mel_spectrogram(a, model.dims.n_mels, padding=N_SAMPLES, device=model.device) for a in audios]
-        for at in range(0, len(mels), batch_size):
-            heads = torch.stack([pad_or_trim(m, N_FRAMES).to(model.device).to(dtype) for m in mels[at: at + batch_size]])
-            _, probs = model.detect_language(heads)
-            for w, p in zip(workers[at: at + batch_size], probs):
-                w.decode_options["language"] = max(p, key=p.get)
-                if fixed["verbose"] is not None:
-                    print(f"Detected language: {LANGUAGES[w.decode_options['language']].title()}")
-    walks = [w._walk(a, m) for w, a, m in zip(workers, audios, mels)]
-    results: List[Optional[dict]] = [None] * len(walks)
+    detect = kwargs.get("language") is None and model.is_multilingual and len(audios) > 1
+    walks: List[Optional[object]] = [None] * len(audios)
+    results: List[Optional[dict]] = [None] * len(audios)
     pending = {}
+    waiting = list(range(len(audios)))          # files not started yet: neither decoded nor on the device
 
     def advance(i: int, value):
         try:
             pending[i] = walks[i].send(value) if value is not None else next(walks[i])
         except StopIteration as stop:
             pending.pop(i, None)
+            walks[i] = None                      # drops the file's whole-file mel
             results[i] = stop.value
 
-    for i in range(len(walks)):
-        advance(i, None)
-    while pending:
+    def admit():
+        """start state machines until `max_active_files` are running: only those files are decoded to PCM and hold a
+        whole-file spectrogram on the device, so memory follows the window, not the total audio duration"""
+        room = max_active_files - len(pending)
+        if room <= 0 or not waiting:
+            return
+        take = waiting[:room]
+        del waiting[:room]
+        loaded = _load_all([audios[i] for i in take])
+        mels = [None] * len(take)
+        if detect:
+            # language identification (transcribe.py:139-152) of the admitted files in batched passes instead of one
+            # encoder pass + one decoder step per file; every state machine then starts with its language set
+            dtype = torch.float16 if kwargs.get("fp16", True) and model.device != torch.device("cpu") else torch.float32
+            mels = [log_mel_spectrogram(a, model.dims.n_mels, padding=N_SAMPLES, device=model.device) for a in loaded]
+            for at in range(0, len(mels), batch_size):
+                heads = torch.stack([pad_or_trim(m, N_FRAMES).to(model.device).to(dtype) for m in mels[at: at + batch_size]])
+                _, probs = model.detect_language(heads)
+                for i, p in zip(take[at: at + batch_size], probs):
+                    workers[i].decode_options["language"] = max(p, key=p.get)
+                    if fixed["verbose"] is not None:
+                        print(f"Detected language: {LANGUAGES[workers[i].decode_options['language']].title()}")
+        for i, a, m in zip(take, loaded, mels):
+            walks[i] = workers[i]._walk(a, m)
+            advance(i, None)
+
+    admit()
+    while pending or waiting:
+        if not pending:
+            admit()
+            continue
+        # word alignment requests of the windows just decoded: one find_alignment_batch pass per (language, task)
+        aligns = {i: r for i, r in pending.items() if isinstance(r, _AlignRequest)}
+        if aligns:
+            groups = {}
+            for i, r in aligns.items():
+                groups.setdefault((r.language, r.task), []).append(i)
+            for members in groups.values():
+                for at in range(0, len(members), batch_size):
+                    chunk = members[at: at + batch_size]
+                    reqs = [aligns[i] for i in chunk]
+                    if len(chunk) == 1:          # alone: exactly the call `transcribe` makes
+                        answers = [find_alignment(model, reqs[0].tokenizer, reqs[0].text_tokens, reqs[0].mel, reqs[0].num_frames)]
+                    else:
+                        answers = find_alignment_batch(model, reqs[0].tokenizer, [r.text_tokens for r in reqs],
+                                                       torch.stack([r.mel for r in reqs]), [r.num_frames for r in reqs])
+                    for i, answer in zip(chunk, answers):
+                        advance(i, answer)
+            admit()
+            continue
         # one round = the windows pending right now, taken up the temperature ladder together: every rung decodes,
         # in batches, the windows that still fail the fallback criteria of transcribe.py:202-222 at the rung below
         rung = {i: 0 for i in pending}
@@ -493,4 +557,5 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, **kwargs
             todo.sort()
         for i, result in sorted(answers.items()):
             advance(i, result)
+        admit()
     return results
