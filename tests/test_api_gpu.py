@@ -387,7 +387,8 @@ def test_ragged_prompts_equal_single_row_decodes(setup, gpu_device, fp16):
 def test_row_prompts_other_modes(setup, gpu_device):
     """per-row prompts outside the fused greedy loop: equal-length prompts under beam search and under the generic
     host loop equal the single-row decodes; language detection writes every row's own language slot; prompts of
-    different lengths are refused where rows cannot sit at different positions (beam search, long prompts)."""
+    different lengths also run under the device-side beam search (equal to the single-row decodes) and are refused
+    where rows cannot sit at different positions (host loop, long prompts)."""
     key, dims, sd, model, mel = setup
     rng = np.random.default_rng(8)
     mels = _prompted_mels(dims, gpu_device, 3)
@@ -397,8 +398,17 @@ def test_row_prompts_other_modes(setup, gpu_device):
     for i in range(3):
         assert got[i].tokens == whisper_amd.decode(model, mels[i], opts, prompt=same_len[i]).tokens, i
     ragged = [same_len[0], same_len[1][:4], None]
-    with pytest.raises(ValueError):
-        whisper_amd.decode(model, mels, opts, prompts=ragged)
+    # prompts of different lengths under beam search: the device-side loop carries a lag per segment
+    for bopts in (opts, whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=10, beam_size=5, patience=1.5)):
+        got = whisper_amd.decode(model, mels, bopts, prompts=ragged)
+        for i in range(3):
+            want = whisper_amd.decode(model, mels[i], bopts, prompt=ragged[i])
+            assert got[i].tokens == want.tokens, i
+            assert abs(got[i].avg_logprob - want.avg_logprob) < 1e-4 and got[i].text == want.text
+    with pytest.raises(ValueError):      # a user filter forces the host loop, which cannot place rows at different positions
+        task = whisper_amd.decoding.DecodingTask(model, opts, prompts=ragged)
+        task.logit_filters.append(whisper_amd.decoding.LogitFilter())
+        task.run(mels)
     with pytest.raises(ValueError):      # 230 + 3 initial tokens + 224 steps do not fit n_text_ctx for the short rows' shared counter
         whisper_amd.decode(model, mels, whisper_amd.DecodingOptions(language="en", fp16=False),
                            prompts=[list(range(1000, 1230)), [5], None])

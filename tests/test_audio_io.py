@@ -181,6 +181,44 @@ def test_load_audio_native_wav_and_flac(tmp_path, monkeypatch):
         A.load_audio(str(tmp_path / "junk.bin"))
 
 
+def _riff(fmt_body: bytes, data: bytes) -> bytes:
+    chunks = b"fmt " + struct.pack("<I", len(fmt_body)) + fmt_body + b"data" + struct.pack("<I", len(data)) + data
+    return b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks
+
+
+def test_wav_extensible_and_malformed_headers(tmp_path, monkeypatch):
+    """WAVE_FORMAT_EXTENSIBLE carries the real sample format in the SubFormat GUID: an extensible IEEE-float file must
+    decode as float (not as int32 PCM), an extensible PCM file as PCM; truncated fmt chunks and zero channels make
+    load_audio raise its RuntimeError instead of struct.error / ZeroDivisionError"""
+    import subprocess
+
+    def no_ffmpeg(*a, **k):
+        raise FileNotFoundError("ffmpeg")
+    monkeypatch.setattr(subprocess, "run", no_ffmpeg)
+    t = np.arange(16000) / 16000.0
+    sine = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    guid_tail = bytes.fromhex("000000001000800000aa00389b71")
+
+    def ext(sub, bits, block):
+        return struct.pack("<HHIIHH", 0xFFFE, 1, 16000, 16000 * block, block, bits) + struct.pack("<HHI", 22, bits, 4) + \
+            struct.pack("<H", sub) + guid_tail
+    p = str(tmp_path / "ext_float.wav")
+    open(p, "wb").write(_riff(ext(3, 32, 4), sine.astype("<f4").tobytes()))
+    got = A.load_audio(p)
+    assert got.shape == (16000,) and np.abs(got - sine).max() < 1e-4        # 16-bit quantisation of the s16 round trip
+    p = str(tmp_path / "ext_pcm16.wav")
+    open(p, "wb").write(_riff(ext(1, 16, 2), np.round(sine * 32767).astype("<i2").tobytes()))
+    assert np.abs(A.load_audio(p) - sine).max() < 1e-4
+    plain = struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16)
+    for name, blob in (("short_fmt.wav", _riff(plain[:10], b"\0" * 64)),
+                       ("zero_ch.wav", _riff(struct.pack("<HHIIHH", 1, 0, 16000, 32000, 2, 16), b"\0" * 64)),
+                       ("ext_short.wav", _riff(ext(3, 32, 4)[:20], b"\0" * 64))):
+        q = str(tmp_path / name)
+        open(q, "wb").write(blob)
+        with pytest.raises(RuntimeError):
+            A.load_audio(q)
+
+
 @pytest.mark.reference
 def test_jfk_flac_decodes_and_matches_reference_test_invariants():
     """tests/jfk.flac of the reference: decodes (CRCs + MD5 signature verified inside the decoder) to the PCM whose

@@ -206,7 +206,10 @@ def test_row_prompts_setup_matches_reference_per_row(ref):
         assert task.ragged_limit() == 448 - task.sample_len
     with pytest.raises(ValueError):
         mine.DecodingTask(model, mine.DecodingOptions(language="en", prompt=[3]), prompts=prompts)
-    assert mine.DecodingTask(model, mine.DecodingOptions(language="en", beam_size=2), prompts=prompts).ragged_limit() is None
+    # beam search runs on the device too (wh_task_beam carries a lag per segment): same limit; 9 beams fall back to the
+    # host loop, which cannot place rows at different positions
+    assert mine.DecodingTask(model, mine.DecodingOptions(language="en", beam_size=2), prompts=prompts).ragged_limit() == 448 - 224
+    assert mine.DecodingTask(model, mine.DecodingOptions(language="en", beam_size=9), prompts=prompts).ragged_limit() is None
     assert mine.DecodingTask(model, mine.DecodingOptions(language="en", temperature=0.4, best_of=3),
                              prompts=prompts).ragged_limit() == 448 - 224       # sampling runs on the device too
     by_index = dict(enumerate(prompts))
@@ -214,8 +217,10 @@ def test_row_prompts_setup_matches_reference_per_row(ref):
     # greedy: everything below the limit shares one ragged class; the saturated prompt (227 initial tokens) is alone
     assert _prompt_batches(model, mine.DecodingOptions(language="en"), by_index, members, 16) == [[0, 1, 2, 4], [3]]
     assert _prompt_batches(model, mine.DecodingOptions(language="en"), by_index, members, 3) == [[0, 1, 2], [4], [3]]
-    # beam search: only rows of equal length (no prompt == empty prompt) share a call
-    assert _prompt_batches(model, mine.DecodingOptions(language="en", beam_size=2), by_index, members, 16) == \
+    # beam search on the device batches like greedy; beyond 8 beams (host loop) only rows of equal length (no prompt ==
+    # empty prompt) share a call
+    assert _prompt_batches(model, mine.DecodingOptions(language="en", beam_size=2), by_index, members, 16) == [[0, 1, 2, 4], [3]]
+    assert _prompt_batches(model, mine.DecodingOptions(language="en", beam_size=9), by_index, members, 16) == \
         [[0, 4], [1], [2], [3]]
 
 

@@ -134,6 +134,30 @@ def test_wide_fused_greedy_vs_oracle(wide, gpu_device):
         assert abs(float(sum_lp[i]) / (len(row) + 1) - W["greedy_stats"][i, 0]) < 1e-3
 
 
+def test_wide_beam5_vs_reference(wide, gpu_device):
+    """device-side beam search (wh_task_beam, beam 5) at D = 1280 / 51866 tokens, fp32 strict engine, against the LIVE
+    reference's `decode(beam_size=5)` on the same two rows of audio features (tests/golden/make_golden_wide.py):
+    token ids exact, avg_logprob 1e-3 — the two clips decoded one at a time (as the reference must) and as one batch
+    of 2 x 5 rows (which the reference cannot do)."""
+    import os
+    import whisper_amd
+    from whisper_amd.model import ModelDimensions, Whisper
+    from whisper_amd.synthetic import dims_dict
+    dims, sd, om, models = wide
+    W = np.load(os.path.join(os.path.dirname(__file__), "golden", "wide_v3.npz"))
+    model = Whisper(ModelDimensions(**dims_dict(dims)), sd, device=gpu_device)
+    model.adopt_engine(torch.float32, models[hip.WH_F32])
+    feats = _feats(dims, 8, seed=21)[:2].to(gpu_device)
+    opts = whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=10, beam_size=5)
+    want = [[t for t in W["beam5_tokens"][i].tolist() if t >= 0] for i in range(2)]
+    for i in range(2):
+        r = whisper_amd.decode(model, feats[i], opts)
+        assert r.tokens == want[i], i
+        assert abs(r.avg_logprob - W["beam5_stats"][i]) < 1e-3
+    both = whisper_amd.decode(model, feats, opts)
+    assert [r.tokens for r in both] == want
+
+
 def test_large_v3_batch_invariance_and_determinism(gpu_device):
     """Full-size property test (large-v3, 32 + 32 layers, fp16, random-init weights generated on the device):
     a clip decodes to the same token ids alone and inside the batch of 8 (the reference treats batch rows

@@ -38,20 +38,30 @@ def _read_wav(path: str, sr: int) -> Optional[np.ndarray]:
         tag, size = data[pos: pos + 4], struct.unpack("<I", data[pos + 4: pos + 8])[0]
         body = data[pos + 8: pos + 8 + size]
         if tag == b"fmt ":
+            if len(body) < 16:
+                return None                                   # truncated fmt chunk: not a file we can read
             fmt = struct.unpack("<HHIIHH", body[:16])
+            if fmt[0] == 0xFFFE:                              # WAVE_FORMAT_EXTENSIBLE: the real format tag is the first
+                if len(body) < 26:                            # two bytes of the SubFormat GUID (1 = PCM, 3 = IEEE float)
+                    return None
+                fmt = (struct.unpack("<H", body[24:26])[0],) + fmt[1:]
         elif tag == b"data":
             pcm = body
         pos += 8 + size + (size & 1)
     if fmt is None or pcm is None:
         return None
     code, channels, rate, _, _, bits = fmt
+    if channels == 0 or rate == 0:
+        return None
     if code == 3 and bits == 32:
-        x = np.frombuffer(pcm, "<f4").astype(np.float32)
-    elif code in (1, 0xFFFE) and bits == 16:
-        x = np.frombuffer(pcm, "<i2").astype(np.float32) / 32768.0
-    elif code in (1, 0xFFFE) and bits == 32:
-        x = np.frombuffer(pcm, "<i4").astype(np.float32) / 2147483648.0
-    elif code in (1, 0xFFFE) and bits == 24:
+        x = np.frombuffer(pcm[: len(pcm) // 4 * 4], "<f4").astype(np.float32)
+    elif code == 3 and bits == 64:
+        x = np.frombuffer(pcm[: len(pcm) // 8 * 8], "<f8").astype(np.float32)
+    elif code == 1 and bits == 16:
+        x = np.frombuffer(pcm[: len(pcm) // 2 * 2], "<i2").astype(np.float32) / 32768.0
+    elif code == 1 and bits == 32:
+        x = np.frombuffer(pcm[: len(pcm) // 4 * 4], "<i4").astype(np.float32) / 2147483648.0
+    elif code == 1 and bits == 24:
         b = np.frombuffer(pcm[: len(pcm) // 3 * 3], np.uint8).reshape(-1, 3).astype(np.int32)
         v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
         x = (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0

@@ -832,8 +832,14 @@ extern "C" int wh_task_beam(wh_task* t, const wh_beam_params* bp, int64_t* token
   const wh_dims& d = t->m->d;
   const int V = d.n_vocab, R = t->R, B = t->B, G = t->G, T0 = p->sample_begin;
   if (G < 2 || G > 8 || bp->beam_size != G || bp->max_candidates < 1 || !t->beam_scratch) return WH_ERR_ARG;
-  if (t->pos != 0 || T0 <= 0 || T0 > t->Tmax || p->max_steps <= 0 || t->lag_on) return WH_ERR_ARG;
+  if (t->pos != 0 || T0 <= 0 || T0 > t->Tmax || p->max_steps <= 0) return WH_ERR_ARG;
   if (token_stride < (int64_t)T0 + p->max_steps + 1) return WH_ERR_ARG;
+  // ragged prompts: rows share one step counter (no row may reach the context limit before the budget ends), and the
+  // beams of one segment share its prompt
+  if (t->lag_on) {
+    if (T0 + p->max_steps > p->n_ctx || T0 + p->max_steps > d.n_text_ctx) return WH_ERR_ARG;
+    for (int r = 0; r < R; ++r) if (t->h_lag[r] != t->h_lag[r / G * G]) return WH_ERR_ARG;
+  }
 
   int32_t sel[2]; int n_sel;
   const bool want_ns = no_speech_token >= 0 && no_speech_probs != nullptr;
@@ -850,7 +856,7 @@ extern "C" int wh_task_beam(wh_task* t, const wh_beam_params* bp, int64_t* token
   int* done[2] = {t->beam_flags, t->beam_flags + B};
   int* d_applied = t->beam_flags + 2 * B;
   BeamArgs a; memset(&a, 0, sizeof(a));
-  a.R = R; a.V = V; a.G = G; a.K = G + 1; a.token_stride = token_stride; a.d_ntok = t->d_pos;
+  a.R = R; a.V = V; a.G = G; a.K = G + 1; a.token_stride = token_stride; a.d_ntok = t->d_pos; a.lag = t->d_lag;
   a.sample_begin = T0; a.eot = p->eot; a.timestamp_begin = p->timestamp_begin; a.no_timestamps = p->no_timestamps;
   a.max_initial_ts = p->max_initial_timestamp_index; a.suppress_blank = p->suppress_blank;
   a.blank_token = p->blank_token; a.suppress_mask = p->suppress_mask; a.sum_logprobs = sum_logprobs;

@@ -88,9 +88,11 @@ __global__ __launch_bounds__(256) void beam_partial_kernel(whk::BeamArgs a) {
     const int v = c * BCHUNK + j * 256 + tid;
     xv[j] = v < a.V ? x[v] : WH_NEG_INF;
   }
-  const int ntok = load_uniform_int(a.d_ntok);
+  const int lag = a.lag ? a.lag[k] : 0;                   // ragged prompts: this row's sequence is `lag` tokens shorter
+  const int ntok = load_uniform_int(a.d_ntok) - lag;
+  const int sample_begin = a.sample_begin - lag;
   const int64_t* row = a.tokens_in + (int64_t)k * a.token_stride;
-  const int L = ntok - a.sample_begin;
+  const int L = ntok - sample_begin;
   const int TB = a.timestamp_begin;       // < 0: timestamp rules disabled (without_timestamps)
   const bool ts_rules = TB >= 0;
 
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void beam_partial_kernel(whk::BeamArgs a) {
   __syncthreads();
   if (ts_rules) {
     for (int t = tid; t < L; t += 256)
-      if (row[a.sample_begin + t] >= TB) atomicMax(&sh_last_ts, t);
+      if (row[sample_begin + t] >= TB) atomicMax(&sh_last_ts, t);
   }
   __syncthreads();
 
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void beam_partial_kernel(whk::BeamArgs a) {
     last_ts = (L >= 1) && (row[ntok - 1] >= TB);
     pen_ts = (L < 2) || (row[ntok - 2] >= TB);
     if (sh_last_ts >= 0) {
-      const int t = (int)row[a.sample_begin + sh_last_ts];
+      const int t = (int)row[sample_begin + sh_last_ts];
       ts_lo = TB;
       ts_hi = (last_ts && !pen_ts) ? t : t + 1;
     }
@@ -291,8 +293,8 @@ __global__ __launch_bounds__(64) void beam_update_kernel(whk::BeamArgs a, int B)
   const int tid = threadIdx.x;
   const int au = blockIdx.x;
   const int G = a.G, K = a.K;
-  const int len = load_uniform_int(a.d_ntok);
   const int r0 = au * G;
+  const int len = load_uniform_int(a.d_ntok) - (a.lag ? a.lag[r0] : 0);    // the beams of a segment share its prompt
 
   // completed at the previous update (every segment full): leave the state as it is
   int not_done = 0;
@@ -321,7 +323,10 @@ __global__ __launch_bounds__(64) void beam_update_kernel(whk::BeamArgs a, int B)
     csrc[c] = r0 + j;
   }
   __syncthreads();
-  // stable descending order: rank = number of candidates that come before this one (NaN marks "not a candidate")
+  // stable descending order: rank = number of candidates that come before this one (NaN marks "not a candidate").
+  // A row with fewer than K finite logits yields (-inf, token 0) candidates; they sort behind every finite one (in
+  // index order, so the outcome is deterministic) and are only taken when a segment has nothing else to continue —
+  // the reference's torch.topk picks arbitrary -inf entries in that case.
   for (int c = tid; c < N; c += 64) {
     const float s = score[c];
     if (s != s) continue;

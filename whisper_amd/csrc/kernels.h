@@ -163,6 +163,8 @@ struct BeamArgs {
   int R, V, G, K;                           // rows = segments x G beams; K = G + 1
   const int64_t* tokens_in; int64_t* tokens_out; int64_t token_stride;   // [R][stride] each; rows hold *d_ntok tokens
   const int* d_ntok;
+  const int* lag;                           // row r holds lag[r] fewer tokens and its sample_begin is lag[r] earlier (ragged
+                                            // prompts; equal within a beam group); may be null
   int sample_begin, eot, timestamp_begin, no_timestamps, max_initial_ts, suppress_blank, blank_token;
   const uint8_t* suppress_mask;
   float* sum_logprobs;                      // [R] in/out

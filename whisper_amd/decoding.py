@@ -533,13 +533,21 @@ class DecodingTask:
                 and all(type(f) in (SuppressBlank, SuppressTokens, ApplyTimestampRules) for f in self.logit_filters)
                 and self.sample_begin + self.sample_len <= 2 * self.n_ctx)
 
+    def _beam_shape_ok(self) -> bool:
+        return (type(self.decoder) is BeamSearchDecoder and self.options.beam_size == self.n_group
+                and 2 <= self.n_group <= 8 and type(self.inference) is HipInference
+                and self.logit_filters == self._stock_filters
+                and all(type(f) in (SuppressBlank, SuppressTokens, ApplyTimestampRules) for f in self.logit_filters))
+
     def _fused_beam_ok(self) -> bool:
-        """device-side beam search (wh_task_beam): stock decoder / filters / inference, 2..8 beams, rows of equal length"""
+        """device-side beam search (wh_task_beam): stock decoder / filters / inference, 2..8 beams; rows of different
+        prompt lengths (every row at its own positions, the beams of a segment sharing its prompt) as long as no row can
+        reach the context limit before the step budget ends"""
         return (type(self.decoder) is BeamSearchDecoder and self.options.beam_size == self.n_group
                 and 2 <= self.n_group <= 8 and type(self.inference) is HipInference
                 and self.logit_filters == self._stock_filters
                 and all(type(f) in (SuppressBlank, SuppressTokens, ApplyTimestampRules) for f in self.logit_filters)
-                and not self._ragged())
+                and (not self._ragged() or self.sample_begin + self.sample_len <= self.n_ctx))
 
     def _sampling_rules(self, T0: int, dev) -> Tuple["hip.GreedyParams", Tensor]:
         """the stock logit filters as the parameter block of the device-side loops (the mask tensor must stay alive)"""
@@ -574,13 +582,25 @@ class DecodingTask:
             rules, mask = self._sampling_rules(T0, dev)
             params = hip.BeamParams(rules=rules, beam_size=self.n_group, max_candidates=self.decoder.max_candidates)
             no_speech = tk.no_speech if tk.no_speech is not None else -1
+            ragged = self._ragged()
+            row_lag = [lag for lag in self.row_lag for _ in range(self.n_group)] if ragged else None
+            if ragged:
+                task.set_lag(row_lag)
             n, sum_logprobs, nsp, (fin_tok, fin_len, fin_score, fin_count) = task.beam(buf, params, self.sot_index, no_speech)
             no_speech_probs = nsp.tolist() if nsp is not None else [np.nan] * n_rows
             fin_tok, fin_len, fin_score, fin_count = fin_tok.cpu(), fin_len.tolist(), fin_score.tolist(), fin_count.tolist()
+            # rows with a shorter prompt hold fewer tokens: left-pad (as the greedy path does) so that every sequence's
+            # sampled part starts at sample_begin, where finalize() / the ranker slice it
+            pad = (lambda a: (tk.sot,) * self.row_lag[a]) if ragged else (lambda a: ())
             self.decoder.finished_sequences = [
-                {tuple(fin_tok[a, i, : fin_len[a][i]].tolist()): fin_score[a][i] for i in range(fin_count[a])}
+                {pad(a) + tuple(fin_tok[a, i, : fin_len[a][i]].tolist()): fin_score[a][i] for i in range(fin_count[a])}
                 for a in range(n_rows // self.n_group)]
-            return buf[0, :, :n], sum_logprobs, no_speech_probs
+            if not ragged:
+                return buf[0, :, :n], sum_logprobs, no_speech_probs
+            out = torch.full((n_rows, n), tk.sot, dtype=torch.int64, device=dev)
+            for r, lag in enumerate(row_lag):
+                out[r, lag:] = buf[0, r, : n - lag]
+            return out, sum_logprobs, no_speech_probs
         finally:
             self.inference.cleanup_caching()
 
@@ -617,14 +637,15 @@ class DecodingTask:
         """longest initial sequence that rows of different lengths may have in one call (None: this task can only
         take rows of equal length).  Rows share one step counter on the device, so none may reach the context
         limit (reference decoding.py:705) before the `sample_len` budget runs out."""
-        return self.n_ctx - self.sample_len if self._fused_greedy_ok(None) else None
+        fused = self._fused_greedy_ok(None) or (type(self.decoder) is BeamSearchDecoder and self._beam_shape_ok())
+        return self.n_ctx - self.sample_len if fused else None
 
     def _main_loop(self, audio_features: Tensor, tokens: Tensor):
         if self._ragged():
             limit = self.ragged_limit()
             if limit is None:
-                raise ValueError("prompts of different lengths need the device-side greedy / sampling loop (no beam "
-                                 "search, stock logit filters)")
+                raise ValueError("prompts of different lengths need a device-side loop (greedy / sampling / beam search "
+                                 "with the stock decoder and logit filters)")
             if self.sample_begin > limit:
                 raise ValueError(f"prompts of different lengths: the longest initial sequence ({self.sample_begin}) "
                                  f"+ sample_len ({self.sample_len}) exceeds n_text_ctx ({self.n_ctx})")
