@@ -73,8 +73,9 @@ __device__ __forceinline__ void block_best(float& v, int& i, float* sh_v, int* s
   for (int w = 1; w < 4; ++w) best_merge(v, i, sh_v[w], sh_i[w]);
 }
 
-__global__ __launch_bounds__(256) void beam_partial_kernel(whk::BeamArgs a) {
+__global__ __launch_bounds__(256) void beam_partial_kernel(whk::BeamArgs a, int nchunk) {
   pin_kernargs(a);
+  asm volatile("" ::"s"(nchunk));      // == gridDim.x, as an argument: gridDim sits in the implicit arguments
   __shared__ int sh_last_ts;
   __shared__ float sh_m[2][4], sh_s[2][4];
   __shared__ float sh_bv[4];
@@ -152,7 +153,6 @@ __global__ __launch_bounds__(256) void beam_partial_kernel(whk::BeamArgs a) {
     if (lane == 0) { sh_m[g][wave] = st[g].m; sh_s[g][wave] = st[g].s; }
   }
   __syncthreads();
-  const int nchunk = gridDim.x;
   if (tid < 2) {
     Stat t = Stat{WH_NEG_INF, 0.f};
     for (int w = 0; w < 4; ++w) stat_merge(t, sh_m[tid][w], sh_s[tid][w]);
@@ -408,7 +408,7 @@ void beam_scratch_carve(BeamArgs& a, void* base, int R, int V) {
 hipError_t launch_beam_step(const BeamArgs& a, int B, hipStream_t stream) {
   const int nchunk = (a.V + BCHUNK - 1) / BCHUNK;
   if (a.K != a.G + 1 || a.K > KMAX || a.G > 8 || nchunk > 64 || a.R != B * a.G) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(beam_partial_kernel, dim3(nchunk, a.R), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(beam_partial_kernel, dim3(nchunk, a.R), dim3(256), 0, stream, a, nchunk);
   hipLaunchKernelGGL(beam_row_kernel, dim3(a.R), dim3(256), 0, stream, a, nchunk);
   hipLaunchKernelGGL(beam_update_kernel, dim3(B), dim3(64), 0, stream, a, B);
   return hipGetLastError();

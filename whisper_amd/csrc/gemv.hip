@@ -477,14 +477,18 @@ hipError_t launch_pro(const whk::GemvArgs& a, int gp, hipStream_t stream) {
       if (upr <= 3 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 3, MULTI, WAVES, GS, MF>(a, gp, stream);
       if (upr <= 6 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 6, MULTI, WAVES, GS, MF>(a, gp, stream);
       if (upr <= 12 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 12, MULTI, WAVES, GS, MF>(a, gp, stream);
-      if (WAVES == 4) {                              // narrow workgroups stage long rows with more units per thread
+      if constexpr (WAVES == 4) {                    // narrow workgroups stage long rows with more units per thread (a
+                                                     // 16-wave instantiation would spill: 128 VGPRs per lane)
         if (upr <= 24 * TPR) return launch_cfg<T, RT, LPR, whk::PRO_PLAIN, 24, MULTI, WAVES, GS, MF>(a, gp, stream);
       }
       return hipErrorInvalidValue;
     }
     case whk::PRO_LN:
       if (a.K <= 256 * 5) return launch_cfg<T, RT, LPR, whk::PRO_LN, 5, MULTI, WAVES, GS, MF>(a, gp, stream);
-      if (a.K <= 256 * 8) return launch_cfg<T, RT, LPR, whk::PRO_LN, 8, MULTI, WAVES, GS, MF>(a, gp, stream);
+      if constexpr (WAVES <= 8) {                    // rows wider than 1280 (no released Whisper width): 8 float4 per lane per
+                                                     // row only fit the register budget of <= 8-wave workgroups
+        if (a.K <= 256 * 8) return launch_cfg<T, RT, LPR, whk::PRO_LN, 8, MULTI, WAVES, GS, MF>(a, gp, stream);
+      }
       return hipErrorInvalidValue;
     case whk::PRO_COMBINE:
       if (a.K != a.H * 64) return hipErrorInvalidValue;
@@ -1034,7 +1038,7 @@ hipError_t launch_gemv8_pro(const whk::GemvArgs& a, hipStream_t stream) {
     return launch_gemv8_cfg<PRO, 1, 4, CSm, 0>(a, stream);
   } else {
     if (nblk > 20) return hipErrorNotSupported;              // the prologue waves cover K <= 1280
-    if (PRO == whk::PRO_LN) {
+    if constexpr (PRO == whk::PRO_LN) {
       if (ngroups >= 600) return launch_gemv8_cfg<PRO, 3, 4, CSm, 4>(a, stream);
       if (ngroups >= 400) return launch_gemv8_cfg<PRO, 2, 4, CSm, 8>(a, stream);
     }

@@ -81,8 +81,9 @@ constexpr int PSTRIDE = 8;      // floats per (row, chunk, range) partial: m, s,
 // to two partial statistics (text range, timestamp range): {max, sum exp(x - max), first arg-max}.
 // All four logits of a thread are requested before any is used (one L2 round trip per workgroup).
 template <bool SAMPLE>
-__global__ __launch_bounds__(256) void greedy_partial_kernel(whk::SampleArgs a) {
+__global__ __launch_bounds__(256) void greedy_partial_kernel(whk::SampleArgs a, int nchunk) {
   pin_kernargs(a);
+  asm volatile("" ::"s"(nchunk));
   __shared__ int sh_last_ts;
   __shared__ float sh_m[2][4], sh_s[2][4];
   __shared__ int sh_i[2][4];
@@ -172,7 +173,8 @@ __global__ __launch_bounds__(256) void greedy_partial_kernel(whk::SampleArgs a) 
   __syncthreads();
   if (tid < 2) {
     Stat t = Stat{WH_NEG_INF, 0.f, 0x7fffffff};
-    float* o = a.partials + (((int64_t)k * gridDim.x + c) * 2 + tid) * PSTRIDE;
+    float* o = a.partials + (((int64_t)k * nchunk + c) * 2 + tid) * PSTRIDE;   // nchunk == gridDim.x, passed as an argument:
+                                                                               // gridDim sits in the implicit arguments (a second kernarg round trip)
     if constexpr (SAMPLE) {
       Pick p = Pick{WH_NEG_INF, WH_NEG_INF, 0x7fffffff};
       for (int w = 0; w < 4; ++w) {
@@ -319,10 +321,10 @@ hipError_t launch_greedy_sample(const SampleArgs& a, hipStream_t stream) {
   const int nchunk = (a.V + SCHUNK - 1) / SCHUNK;
   if (!a.partials) return hipErrorInvalidValue;
   if (a.inv_temperature > 0.f) {
-    hipLaunchKernelGGL(greedy_partial_kernel<true>, dim3(nchunk, a.R), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(greedy_partial_kernel<true>, dim3(nchunk, a.R), dim3(256), 0, stream, a, nchunk);
     hipLaunchKernelGGL(greedy_final_kernel<true>, dim3(a.R), dim3(256), 0, stream, a, nchunk);
   } else {
-    hipLaunchKernelGGL(greedy_partial_kernel<false>, dim3(nchunk, a.R), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(greedy_partial_kernel<false>, dim3(nchunk, a.R), dim3(256), 0, stream, a, nchunk);
     hipLaunchKernelGGL(greedy_final_kernel<false>, dim3(a.R), dim3(256), 0, stream, a, nchunk);
   }
   return hipGetLastError();
