@@ -229,13 +229,14 @@ int wh_task_cross_qk(wh_task *t, int row, const int32_t *layers, const int32_t *
                      int tok_begin, int n_tok, float *out, void *stream);
 
 /* ---- measurement hook (bench.py roofline leg; not part of the reference surface) ------------------
- * Launches ONE kernel of the decode step `iters` times back-to-back on `stream`, rotating over the
- * decoder layers so every launch streams HBM-cold data exactly like the real step does; the caller
- * brackets the call with HIP events.  kind: 0 = whole decode step (eager launches, position not advanced
- * beyond the cache), 1 = cross-attention decode kernel, 2 = self-attention decode kernel,
+ * ONE kernel of the decode step, `iters` launches rotating over the decoder layers (every launch streams HBM-cold data
+ * exactly like the real step does), captured into a hipGraph and replayed on `stream` (non-null) — the dependent-launch
+ * boundaries of the real step — with HIP events around the replay; *ms_per_launch = best of 3 replays / iters.
+ * kind: 0 = whole decode step (position not advanced beyond the cache), 1 = cross-attention decode kernel, 2 = self-attention decode kernel,
  * 3 = LN+QKV GEMV, 4 = LN+FC1 GEMV, 5 = FC2 GEMV, 6 = LN+logits GEMV, 7 = out-proj GEMV.
  * *bytes_per_launch receives the algorithmic HBM bytes of one launch (SURVEY.md §8d accounting). */
-int wh_task_bench_kernel(wh_task *t, int kind, int iters, double *bytes_per_launch, void *stream);
+int wh_task_bench_kernel(wh_task *t, int kind, int iters, double *bytes_per_launch, float *ms_per_launch,
+                         void *stream);
 
 /* ---- word-timestamp kernels — whisper/timing.py:19-54 (median_filter), :82-151 (dtw) -------- */
 /* x: fp32 [rows][n] -> out: fp32 [rows][n], reflect-padded sliding median of odd `width` along n. */

@@ -912,7 +912,7 @@ extern "C" int wh_task_beam(wh_task* t, const wh_beam_params* bp, int64_t* token
 }
 
 // ---- measurement hook ----------------------------------------------------------------------------------
-extern "C" int wh_task_bench_kernel(wh_task* t, int kind, int iters, double* bytes_per_launch, void* stream_) {
+static int bench_issue(wh_task* t, int kind, int iters, double* bytes_per_launch, void* stream_) {
   if (!t || iters <= 0) return WH_ERR_ARG;
   if (!t->audio_set || t->pos <= 0) return WH_ERR_STATE;
   hipStream_t s = (hipStream_t)stream_;
@@ -993,6 +993,44 @@ extern "C" int wh_task_bench_kernel(wh_task* t, int kind, int iters, double* byt
     }
   }
   if (bytes_per_launch) *bytes_per_launch = bytes;
+  return WH_OK;
+}
+
+// Average duration of one launch of a decode-step kernel, measured with HIP events on the launch stream: `iters`
+// launches (rotating over the layers, so every launch is HBM-cold) are captured into a hipGraph and replayed — the
+// same dependent-launch boundaries the kernels see inside the decode step (an eager loop of short kernels measures the
+// host's launch rate instead).  kind 0 = the whole step (257 launches + the counter reset), captured the same way.
+extern "C" int wh_task_bench_kernel(wh_task* t, int kind, int iters, double* bytes_per_launch, float* ms_per_launch,
+                                    void* stream_) {
+  if (!t || iters <= 0 || !ms_per_launch) return WH_ERR_ARG;
+  if (!t->audio_set || t->pos <= 0) return WH_ERR_STATE;
+  hipStream_t s = (hipStream_t)stream_;
+  if (s == nullptr) return WH_ERR_ARG;            // stream capture needs a real stream
+  int rc = bench_issue(t, kind, 2, bytes_per_launch, stream_);      // warm-up: function attributes, code objects
+  if (rc != WH_OK) return rc;
+  hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+  HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  rc = bench_issue(t, kind, iters, bytes_per_launch, stream_);
+  hipError_t e = hipStreamEndCapture(s, &graph);
+  if (rc != WH_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  HIPCHK(e);
+  HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipGraphLaunch(exec, s));                // first replay untimed
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    HIPCHK(hipEventRecord(e0, s));
+    HIPCHK(hipGraphLaunch(exec, s));
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
+  *ms_per_launch = best / (float)iters;
   return WH_OK;
 }
 

@@ -333,7 +333,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArg
   const int s = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
   const int S = a.splits;
   int Tk = a.Tk;
-  if (a.d_len) {                          // cached length and this row's lag: two independent scalar loads
+  if (a.d_len) {                          // cached length and this row's lag: two independent agent-scope loads
+    // (measured alternative: `s_load_dword ... glc` past the scalar cache — 1280 waves polling one word that way take
+    // 38 us per launch instead of 5.6; the plain s_load is stale between launches, see load_agent_int)
     const int vn = load_agent_int(a.d_len);
     const int vl = load_agent_int(a.lag ? a.lag + r : a.d_len);
     Tk = uniform(vn) + a.len_plus - (a.lag ? uniform(vl) : 0);

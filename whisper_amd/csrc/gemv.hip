@@ -776,9 +776,13 @@ hipError_t launch_stream(const whk::GemvArgs& a, hipStream_t stream) {
 // no vector ALU work beyond its issue slot.
 // CSm: PRO_COMBINE — exactly the number of attention splits (2..4), so that no partial is requested twice.
 // ---------------------------------------------------------------------------------------------------------------
+// fw: output features per workgroup (<= 8 GS; slot s covers features [8 s, min(8 s + 8, fw)) of the workgroup's range):
+// the launcher picks it so that a projection spreads over all 256 CUs (1280 features -> 256 workgroups x 5) — the time
+// of these kernels is set by the line requests of the busiest CU.
 template <int PRO, int GS, int KS, int NU, int CSm, int XW>
-__global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArgs a) {
+__global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArgs a, int fw) {
   pin_kernargs(a);
+  asm volatile("" ::"s"(fw));
   static_assert((PRO == whk::PRO_PLAIN) == (XW == 0), "prologue waves exist exactly when there is a prologue");
   static_assert(PRO != whk::PRO_LN || KS == 4, "LayerNorm prologue: one wave-load of fp32 = 256 elements = 4 K blocks");
   constexpr int MW = GS * KS;                              // weight (MFMA) waves; XW prologue waves in front of them
@@ -802,7 +806,9 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
     // ================= weight waves: the whole share of the weight tile as the very first memory instructions
     // (8 rows x 128 contiguous bytes per wave-load, non-temporal); lane l = 16 c + 8 half + i
     const int idx = lane & 7, koff = ((lane >> 3) & 1) * 32 + (lane >> 4) * 8;
-    int n = (blockIdx.x * GS + mw / KS) * 8 + idx; if (n > a.N - 1) n = a.N - 1;
+    // rows beyond the workgroup's range re-read its last row (same cache lines: no extra requests); their outputs are dropped
+    int n_last = (blockIdx.x + 1) * fw - 1; if (n_last > a.N - 1) n_last = a.N - 1;
+    int n = blockIdx.x * fw + (mw / KS) * 8 + idx; if (n > n_last) n = n_last;
     const uint32_t lane_off = ((uint32_t)n * (uint32_t)K + (uint32_t)koff) * 2u;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -935,8 +941,8 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
 
   // ---- epilogue operands (L2 hits, needed last; requested behind every wave's own loads): thread -> (slot, row, feature)
   const int es = tid >> 6, er = (tid >> 3) & 7, ej = tid & 7;
-  const int en = (blockIdx.x * GS + es) * 8 + ej;
-  const bool e_on = es < GS && er < R && en < a.N;
+  const int en = blockIdx.x * fw + es * 8 + ej;
+  const bool e_on = es < GS && er < R && es * 8 + ej < fw && en < a.N;
   float e_bias = 0.f, e_res = 0.f;
   int e_lag = 0, e_pos = 0;
   if (a.epi == whk::EPI_QKV) e_pos = load_agent_int(a.d_pos);
@@ -1013,16 +1019,26 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
 }
 
 template <int PRO, int GS, int KS, int CSm, int XW>
-hipError_t launch_gemv8_cfg(const whk::GemvArgs& a, hipStream_t stream) {
+hipError_t launch_gemv8_cfg(const whk::GemvArgs& a, int fw, hipStream_t stream) {
   constexpr int WAVES = GS * KS + XW;
   static_assert(WAVES <= 16, "at most 1024 threads per workgroup");
-  const int nblk = a.K / 64, ngroups = (a.N + 7) / 8;
+  if (fw < 1 || fw > 8 * GS) return hipErrorInvalidValue;
+  const int nblk = a.K / 64;
   const int nu = (nblk + KS - 1) / KS;
-  dim3 grid((ngroups + GS - 1) / GS, (a.R + 7) / 8), block(WAVES * 64);
-  if (nu <= 3) hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 3, CSm, XW>), grid, block, 0, stream, a);
-  else if (nu <= 5) hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 5, CSm, XW>), grid, block, 0, stream, a);
+  dim3 grid((a.N + fw - 1) / fw, (a.R + 7) / 8), block(WAVES * 64);
+  if (nu <= 3) hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 3, CSm, XW>), grid, block, 0, stream, a, fw);
+  else if (nu <= 5) hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 5, CSm, XW>), grid, block, 0, stream, a, fw);
   else return hipErrorInvalidValue;
   return hipGetLastError();
+}
+
+// features per workgroup: spread N over all 256 CUs when that leaves >= 4 features per workgroup, never more than 8 per slot
+static int gemv8_fw(int N, int gs) {
+  static int ncu = 256;
+  int fw = (N + ncu - 1) / ncu;
+  if (fw > 8 * gs) fw = 8 * gs;
+  if (fw < 4) fw = N < 8 ? N : 8 < 8 * gs ? 8 : 8 * gs;      // small matrices: whole 8-feature groups
+  return fw;
 }
 
 // shapes (large-v3 in brackets; every choice measured with tools/probe_gemv8, profiles/r02_probe_gemv8.txt):
@@ -1034,15 +1050,15 @@ template <int PRO, int CSm>
 hipError_t launch_gemv8_pro(const whk::GemvArgs& a, hipStream_t stream) {
   const int nblk = a.K / 64, ngroups = (a.N + 7) / 8;
   if constexpr (PRO == whk::PRO_PLAIN) {
-    if (nblk > 20) return launch_gemv8_cfg<PRO, 1, 16, CSm, 0>(a, stream);
-    return launch_gemv8_cfg<PRO, 1, 4, CSm, 0>(a, stream);
+    if (nblk > 20) return launch_gemv8_cfg<PRO, 1, 16, CSm, 0>(a, gemv8_fw(a.N, 1), stream);
+    return launch_gemv8_cfg<PRO, 1, 4, CSm, 0>(a, gemv8_fw(a.N, 1), stream);
   } else {
     if (nblk > 20) return hipErrorNotSupported;              // the prologue waves cover K <= 1280
     if constexpr (PRO == whk::PRO_LN) {
-      if (ngroups >= 600) return launch_gemv8_cfg<PRO, 3, 4, CSm, 4>(a, stream);
-      if (ngroups >= 400) return launch_gemv8_cfg<PRO, 2, 4, CSm, 8>(a, stream);
+      if (ngroups >= 600) return launch_gemv8_cfg<PRO, 3, 4, CSm, 4>(a, gemv8_fw(a.N, 3), stream);
+      if (ngroups >= 400) return launch_gemv8_cfg<PRO, 2, 4, CSm, 8>(a, gemv8_fw(a.N, 2), stream);
     }
-    return launch_gemv8_cfg<PRO, 1, 4, CSm, 8>(a, stream);
+    return launch_gemv8_cfg<PRO, 1, 4, CSm, 8>(a, gemv8_fw(a.N, 1), stream);
   }
 }
 

@@ -97,7 +97,7 @@ SIGNATURES = {
                                C.POINTER(C.c_int32), C.c_void_p]),
     "wh_task_cross_qk": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "wh_task_bench_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
+    "wh_task_bench_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_void_p]),
     "wh_align_batch_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "wh_task_align_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
@@ -567,16 +567,13 @@ class HipTask:
         return n_out.value, sum_lp, nsp, (fin_tok, fin_len, fin_score, fin_count)
 
     def bench_kernel(self, kind: int, iters: int) -> Tuple[float, float]:
-        """(average ms per launch measured with HIP events on the launch stream, algorithmic bytes per launch)"""
-        nbytes = C.c_double(0.0)
-        st = self.stream
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        check(lib().wh_task_bench_kernel(self.handle, kind, 3, C.byref(nbytes), stream_ptr(st)), "bench warmup")
-        e0.record(st)
-        check(lib().wh_task_bench_kernel(self.handle, kind, iters, C.byref(nbytes), stream_ptr(st)), "bench")
-        e1.record(st)
-        e1.synchronize()
-        return e0.elapsed_time(e1) / iters, nbytes.value
+        """(average ms per launch, algorithmic bytes per launch): `iters` layer-rotated launches replayed from a hipGraph
+        and timed with HIP events on the launch stream inside wh_task_bench_kernel (best of 3 replays)"""
+        nbytes, ms = C.c_double(0.0), C.c_float(0.0)
+        cur = self._enter()
+        check(lib().wh_task_bench_kernel(self.handle, kind, iters, C.byref(nbytes), C.byref(ms), stream_ptr(self.stream)), "bench")
+        cur.wait_stream(self.stream)
+        return float(ms.value), nbytes.value
 
     def cross_qk(self, row: int, layers: Sequence[int], heads: Sequence[int], tok_begin: int, n_tok: int) -> torch.Tensor:
         n = len(layers)
