@@ -779,26 +779,32 @@ hipError_t launch_stream(const whk::GemvArgs& a, hipStream_t stream) {
 // fw: output features per workgroup (<= 8 GS; slot s covers features [8 s, min(8 s + 8, fw)) of the workgroup's range):
 // the launcher picks it so that a projection spreads over all 256 CUs (1280 features -> 256 workgroups x 5) — the time
 // of these kernels is set by the line requests of the busiest CU.
-template <int PRO, int GS, int KS, int NU, int CSm, int XW>
+// NRT: row tiles of 8 handled by ONE workgroup against the same weight fragments (beam search: 8 clips x 5 beams = 40
+// rows -> NRT = 6; the few-row prefill likewise): the weights are streamed once for all rows, every further tile costs
+// NU more MFMAs and its x fragments.
+template <int PRO, int GS, int KS, int NU, int CSm, int XW, int NRT>
 __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArgs a, int fw) {
   pin_kernargs(a);
   asm volatile("" ::"s"(fw));
   static_assert((PRO == whk::PRO_PLAIN) == (XW == 0), "prologue waves exist exactly when there is a prologue");
   static_assert(PRO != whk::PRO_LN || KS == 4, "LayerNorm prologue: one wave-load of fp32 = 256 elements = 4 K blocks");
   constexpr int MW = GS * KS;                              // weight (MFMA) waves; XW prologue waves in front of them
-  __shared__ float red[MW][8][8];                          // [weight wave][feature][row] partial sums
-  __shared__ __attribute__((aligned(16))) half8v xfrag[XW ? KS * NU * 64 : 1];   // [kw][u][lane]
+  constexpr int NT = (MW + XW) * 64;
+  constexpr int RW = 8 * NRT;                              // rows per workgroup
+  constexpr int FRAG = KS * NU * 64;                       // x fragment units of one row tile
+  __shared__ float red[MW][NRT][8][8];                     // [weight wave][row tile][feature][row] partial sums
+  __shared__ __attribute__((aligned(16))) half8v xfrag[XW ? NRT * FRAG : 1];   // [row tile][kw][u][lane]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_x = wave < XW;                             // wave-uniform role
   const int K = a.K, nblk = K >> 6;
-  const int r0 = blockIdx.y * 8;
-  int R = a.R - r0; if (R > 8) R = 8;
+  const int r0 = blockIdx.y * RW;
+  int R = a.R - r0; if (R > RW) R = RW;
   const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
   (void)wgid;
   WH_PROBE_AT(a, wgid, 0);
 
-  half8v wa[NU], xb[NU];
+  half8v wa[NU], xb[NRT][NU];
   const int mw = wave - XW;
   const int kw = mw % KS;                                  // weight waves: split of K
 
@@ -816,62 +822,70 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
       wa[u] = __builtin_nontemporal_load((const half8v*)((const char*)a.W + (size_t)blk * 128 + lane_off));
     }
     if (PRO == whk::PRO_PLAIN) {
-      const int row = r0 + (idx < R ? idx : R - 1);        // padded rows re-read a valid row; their outputs are dropped
-      const uint32_t xoff = ((uint32_t)row * (uint32_t)a.x_ld + (uint32_t)koff) * 2u;
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        int blk = kw + KS * u; if (blk > nblk - 1) blk = nblk - 1;
-        xb[u] = *(const half8v*)((const char*)a.x + (size_t)blk * 128 + xoff);
+      for (int rt = 0; rt < NRT; ++rt) {
+        int rr = rt * 8 + idx; if (rr > R - 1) rr = R - 1;  // padded rows re-read a valid row; their outputs are dropped
+        const uint32_t xoff = ((uint32_t)(r0 + rr) * (uint32_t)a.x_ld + (uint32_t)koff) * 2u;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          int blk = kw + KS * u; if (blk > nblk - 1) blk = nblk - 1;
+          xb[rt][u] = *(const half8v*)((const char*)a.x + (size_t)blk * 128 + xoff);
+        }
       }
     }
   } else if (PRO == whk::PRO_LN) {
     // ================= LayerNorm waves.  Loads are row-contiguous (a wave-load = 1 KB of one row = 8 full cache
     // lines: the number of line requests a CU keeps in flight is what bounds these kernels); wave w owns rows w,
     // w + XW, ... whole, so the statistics never leave the wave; results are scattered to LDS in MFMA fragment order:
-    // element k of row r -> unit ((k >> 6) % KS, (k >> 6) / KS), lane 16 ((k & 31) >> 3) + 8 ((k & 63) >> 5) + r.
-    constexpr int NR = XW ? (8 + XW - 1) / XW : 1;
-    float4v v[NR][NU];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int r = wave + XW * i;
-      const char* src = (const char*)a.xf + (size_t)(r0 + (r < R ? r : R - 1)) * (size_t)a.xf_ld * 4;   // wave-uniform
-#pragma unroll
-      for (int j = 0; j < NU; ++j) {
-        int k = (j * 64 + lane) * 4; if (k > K - 4) k = K - 4;          // branch-free, masked at use
-        v[i][j] = *(const float4v*)(src + (uint32_t)k * 4u);
-      }
-    }
-    WH_PROBE_AT(a, wgid, 1);
+    // element k of row r -> tile r / 8, unit ((k >> 6) % KS, (k >> 6) / KS), lane 16 ((k & 31) >> 3) + 8 ((k & 63) >> 5) + r % 8.
+    constexpr int NR = XW ? (RW + XW - 1) / XW : 1;
     const float invK = 1.0f / (float)K;
-    // LDS byte address of this lane's 4 elements of wave-load j, row r: + j * 1024 + r * 16
+    // LDS byte address of this lane's 4 elements of wave-load j, row r: + j * 1024 + (r / 8) * FRAG * 16 + (r % 8) * 16
     const uint32_t fbase = (uint32_t)((lane >> 4) * NU * 64 + 16 * ((lane >> 1) & 3) + 8 * ((lane >> 3) & 1)) * 16u + (uint32_t)(lane & 1) * 8u;
+    constexpr int RB = NR > 2 ? 2 : NR;                    // rows in flight per wave (register budget)
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int r = wave + XW * i;
-      if (r < 8) {
-        float sum = 0.f;
+    for (int i0 = 0; i0 < NR; i0 += RB) {
+      float4v v[RB][NU];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int r = wave + XW * (i0 + i);
+        const char* src = (const char*)a.xf + (size_t)(r0 + (r < R ? r : R - 1)) * (size_t)a.xf_ld * 4;   // wave-uniform
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
-          const float t = (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
-          sum += ((j * 64 + lane) * 4 < K) ? t : 0.f;
+          int k = (j * 64 + lane) * 4; if (k > K - 4) k = K - 4;          // branch-free, masked at use
+          v[i][j] = *(const float4v*)(src + (uint32_t)k * 4u);
         }
-        const float mean = wave_sum(sum) * invK;
-        float ss = 0.f;
+      }
+      if (i0 == 0) WH_PROBE_AT(a, wgid, 1);
 #pragma unroll
-        for (int j = 0; j < NU; ++j) {
-          if ((j * 64 + lane) * 4 < K) {
+      for (int i = 0; i < RB; ++i) {
+        const int r = wave + XW * (i0 + i);
+        if (i0 + i < NR && r < RW) {
+          float sum = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][j][e] - mean; ss = __builtin_fmaf(d, d, ss); }
+          for (int j = 0; j < NU; ++j) {
+            const float t = (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
+            sum += ((j * 64 + lane) * 4 < K) ? t : 0.f;
           }
-        }
-        const float rstd = rsqrtf(wave_sum(ss) * invK + 1e-5f);
+          const float mean = wave_sum(sum) * invK;
+          float ss = 0.f;
 #pragma unroll
-        for (int j = 0; j < NU; ++j) {
-          const bool on = (j * 64 + lane) * 4 < K;
-          half4v o4;
+          for (int j = 0; j < NU; ++j) {
+            if ((j * 64 + lane) * 4 < K) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o4[e] = on ? (half_t)((v[i][j][e] - mean) * rstd) : (half_t)0.f;
-          *(half4v*)((char*)xfrag + fbase + (uint32_t)(j * 1024 + r * 16)) = o4;
+              for (int e = 0; e < 4; ++e) { const float d = v[i][j][e] - mean; ss = __builtin_fmaf(d, d, ss); }
+            }
+          }
+          const float rstd = rsqrtf(wave_sum(ss) * invK + 1e-5f);
+          const uint32_t rbase = fbase + (uint32_t)((r >> 3) * FRAG * 16 + (r & 7) * 16);
+#pragma unroll
+          for (int j = 0; j < NU; ++j) {
+            const bool on = (j * 64 + lane) * 4 < K;
+            half4v o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = on ? (half_t)((v[i][j][e] - mean) * rstd) : (half_t)0.f;
+            *(half4v*)((char*)xfrag + rbase + (uint32_t)(j * 1024)) = o4;
+          }
         }
       }
     }
@@ -879,53 +893,57 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
   } else if (PRO == whk::PRO_COMBINE) {
     // ================= merge waves: partials are split-major [S][rows][H][64] fp16, normalised (attention.hip):
     // wave-load i of a split covers 8 consecutive (row, head) pairs x 64 dims; lane = 8 (pair in the load) + dim / 8
-    const int H = a.H, npair = 8 * H;                     // pairs of this row tile
+    const int H = a.H, npair = RW * H;                    // pairs of this row block
     const int nload = (npair + 7) >> 3;                   // wave-loads per split
-    constexpr int NLD = XW ? (20 + XW - 1) / XW : 1;      // wave-loads per merge wave (H <= 20)
-    half8v po[NLD][CSm];
-    float2v pml[NLD][CSm];
+    constexpr int NLD = XW ? (20 * NRT + XW - 1) / XW : 1;   // wave-loads per merge wave (H <= 20)
+    constexpr int LB = NLD > 5 ? 5 : NLD;                 // wave-loads in flight per merge wave (register budget)
     const size_t split_stride = (size_t)a.R * H;          // pairs per split
+#pragma unroll 1
+    for (int i0 = 0; i0 < NLD; i0 += LB) {
+      half8v po[LB][CSm];
+      float2v pml[LB][CSm];
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      int ld = wave + XW * i; if (ld > nload - 1) ld = nload - 1;
-      int pair = ld * 8 + (lane >> 3); if (pair > npair - 1) pair = npair - 1;
-      const int prow = pair / H, ph = pair - prow * H;
-      const int grow = r0 + (prow < R ? prow : R - 1);
-      const uint32_t pidx = (uint32_t)grow * (uint32_t)H + (uint32_t)ph;
-#pragma unroll
-      for (int s = 0; s < CSm; ++s) {
-        pml[i][s] = *(const float2v*)((const char*)a.part_ml + ((size_t)s * split_stride) * 8 + pidx * 8u);
-        po[i][s] = *(const half8v*)((const char*)a.part_o + ((size_t)s * split_stride) * 128 + (pidx * 64u + (uint32_t)(lane & 7) * 8u) * 2u);
-      }
-    }
-    WH_PROBE_AT(a, wgid, 1);
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int ld = wave + XW * i;
-      const int pair = ld * 8 + (lane >> 3);
-      if (ld < nload && pair < npair) {
+      for (int i = 0; i < LB; ++i) {
+        int ld = wave + XW * (i0 + i); if (ld > nload - 1) ld = nload - 1;
+        int pair = ld * 8 + (lane >> 3); if (pair > npair - 1) pair = npair - 1;
         const int prow = pair / H, ph = pair - prow * H;
-        float M = pml[i][0][0];
-#pragma unroll
-        for (int s = 1; s < CSm; ++s) M = fmaxf(M, pml[i][s][0]);
-        float w[CSm], den = 0.f;
+        const int grow = r0 + (prow < R ? prow : R - 1);
+        const uint32_t pidx = (uint32_t)grow * (uint32_t)H + (uint32_t)ph;
 #pragma unroll
         for (int s = 0; s < CSm; ++s) {
-          w[s] = (pml[i][s][0] != WH_NEG_INF) ? __expf(pml[i][s][0] - M) * pml[i][s][1] : 0.f;   // partial o is o_s / l_s
-          den += w[s];
+          pml[i][s] = *(const float2v*)((const char*)a.part_ml + ((size_t)s * split_stride) * 8 + pidx * 8u);
+          po[i][s] = *(const half8v*)((const char*)a.part_o + ((size_t)s * split_stride) * 128 + (pidx * 64u + (uint32_t)(lane & 7) * 8u) * 2u);
         }
-        const float inv = 1.0f / den;
-        half8v xo;
+      }
+      if (i0 == 0) WH_PROBE_AT(a, wgid, 1);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float num = 0.f;
+      for (int i = 0; i < LB; ++i) {
+        const int ld = wave + XW * (i0 + i);
+        const int pair = ld * 8 + (lane >> 3);
+        if (i0 + i < NLD && ld < nload && pair < npair) {
+          const int prow = pair / H, ph = pair - prow * H;
+          float M = pml[i][0][0];
 #pragma unroll
-          for (int s = 0; s < CSm; ++s) num = __builtin_fmaf(w[s], (float)po[i][s][e], num);
-          xo[e] = (half_t)(num * inv);
+          for (int s = 1; s < CSm; ++s) M = fmaxf(M, pml[i][s][0]);
+          float w[CSm], den = 0.f;
+#pragma unroll
+          for (int s = 0; s < CSm; ++s) {
+            w[s] = (pml[i][s][0] != WH_NEG_INF) ? __expf(pml[i][s][0] - M) * pml[i][s][1] : 0.f;   // partial o is o_s / l_s
+            den += w[s];
+          }
+          const float inv = 1.0f / den;
+          half8v xo;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float num = 0.f;
+#pragma unroll
+            for (int s = 0; s < CSm; ++s) num = __builtin_fmaf(w[s], (float)po[i][s][e], num);
+            xo[e] = (half_t)(num * inv);
+          }
+          // head ph = K block: unit (ph % KS, ph / KS); dims [8 (lane & 7), +8): half = (lane & 7) >> 2, c = lane & 3
+          const int dl = lane & 7;
+          xfrag[(prow >> 3) * FRAG + ((ph % KS) * NU + ph / KS) * 64 + 16 * (dl & 3) + 8 * (dl >> 2) + (prow & 7)] = xo;
         }
-        // head ph = K block: unit (ph % KS, ph / KS); dims [8 (lane & 7), +8): half = (lane & 7) >> 2, c = lane & 3
-        const int dl = lane & 7;
-        xfrag[((ph % KS) * NU + ph / KS) * 64 + 16 * (dl & 3) + 8 * (dl >> 2) + prow] = xo;
       }
     }
     // K blocks beyond the last head (NU * KS > H) multiply clamped weights: zero them
@@ -933,23 +951,33 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
       half8v z;
 #pragma unroll
       for (int e = 0; e < 8; ++e) z[e] = (half_t)0.f;
-      xfrag[((blk % KS) * NU + blk / KS) * 64 + lane] = z;
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) xfrag[rt * FRAG + ((blk % KS) * NU + blk / KS) * 64 + lane] = z;
     }
     WH_PROBE_AT(a, wgid, 2);
   }
   ISSUE_FENCE();
 
-  // ---- epilogue operands (L2 hits, needed last; requested behind every wave's own loads): thread -> (slot, row, feature)
-  const int es = tid >> 6, er = (tid >> 3) & 7, ej = tid & 7;
-  const int en = blockIdx.x * fw + es * 8 + ej;
-  const bool e_on = es < GS && er < R && es * 8 + ej < fw && en < a.N;
-  float e_bias = 0.f, e_res = 0.f;
-  int e_lag = 0, e_pos = 0;
+  // ---- epilogue operands (L2 hits, needed last; requested behind every wave's own loads): output o = tid + NT j ->
+  // (slot, row tile, row, feature)
+  constexpr int NOUT = (GS * NRT * 64 + NT - 1) / NT;
+  float e_bias[NOUT], e_res[NOUT];
+  int e_lag[NOUT];
+  int e_pos = 0;
   if (a.epi == whk::EPI_QKV) e_pos = load_agent_int(a.d_pos);
-  if (e_on) {
-    if (a.epi == whk::EPI_QKV && a.lag) e_lag = a.lag[r0 + er];
-    if (a.bias) e_bias = a.bias[en];
-    if (a.epi == whk::EPI_RESID) e_res = a.resid[(int64_t)(r0 + er) * a.resid_ld + en];
+#pragma unroll
+  for (int j = 0; j < NOUT; ++j) {
+    const int o = tid + NT * j;
+    const int es = o / (NRT * 64), ert = (o >> 6) % NRT, er = (o >> 3) & 7, ej = o & 7;
+    const int en = blockIdx.x * fw + es * 8 + ej;
+    const bool on = o < GS * NRT * 64 && ert * 8 + er < R && es * 8 + ej < fw && en < a.N;
+    e_bias[j] = 0.f; e_res[j] = 0.f; e_lag[j] = 0;
+    if (on) {
+      const int64_t rr = r0 + ert * 8 + er;
+      if (a.epi == whk::EPI_QKV && a.lag) e_lag[j] = a.lag[rr];
+      if (a.bias) e_bias[j] = a.bias[en];
+      if (a.epi == whk::EPI_RESID) e_res[j] = a.resid[rr * a.resid_ld + en];
+    }
   }
   if (!XW) WH_PROBE_AT(a, wgid, 1);
 
@@ -957,79 +985,104 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
     __syncthreads();
     if (!is_x) {
 #pragma unroll
-      for (int u = 0; u < NU; ++u) xb[u] = xfrag[(kw * NU + u) * 64 + lane];
+      for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) xb[rt][u] = xfrag[rt * FRAG + (kw * NU + u) * 64 + lane];
     }
   } else {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       if (!(kw + KS * u < nblk)) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) xb[u][e] = (half_t)0.f;
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xb[rt][u][e] = (half_t)0.f;
       }
     }
   }
   WH_PROBE_AT(a, wgid, 3);
 
-  // ---- weight waves: NU MFMAs, C[m][n] with m = weight row (+8: second half), n = batch row (+8: second half)
+  // ---- weight waves: NU MFMAs per row tile, C[m][n] with m = weight row (+8: second half), n = batch row (+8: second half)
   if (!is_x) {
-    float4v acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < NU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u], xb[u], acc, 0, 0, 0);
-    // lane holds C[m = 4 (lane >> 4) + e][n = lane & 15]; valid where (m >> 3) == (n >> 3)
     const bool diag = (lane >> 5) == ((lane >> 3) & 1);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float z = diag ? acc[e] : 0.f;
-      z += lane_xor8(z);
-      float p, q; lane_swap32(z, p, q);
-      acc[e] = p + q;
-    }
-    if (lane < 32 && (lane & 15) < 8) {
+    for (int rt = 0; rt < NRT; ++rt) {
+      float4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) red[mw][4 * (lane >> 4) + e][lane & 7] = acc[e];
+      for (int u = 0; u < NU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u], xb[rt][u], acc, 0, 0, 0);
+      // lane holds C[m = 4 (lane >> 4) + e][n = lane & 15]; valid where (m >> 3) == (n >> 3)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float z = diag ? acc[e] : 0.f;
+        z += lane_xor8(z);
+        float p, q; lane_swap32(z, p, q);
+        acc[e] = p + q;
+      }
+      if (lane < 32 && (lane & 15) < 8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[mw][rt][4 * (lane >> 4) + e][lane & 7] = acc[e];
+      }
     }
   }
   WH_PROBE_AT(a, wgid, 4);
   __syncthreads();
   WH_PROBE_AT(a, wgid, 5);
-  if (e_on) {
-    float v = e_bias;
 #pragma unroll
-    for (int k = 0; k < KS; ++k) v += red[es * KS + k][ej][er];
-    const int64_t rr = r0 + er;
-    const int n = en;
-    switch (a.epi) {
-      case whk::EPI_STORE: ((half_t*)a.y)[rr * a.y_ld + n] = (half_t)v; break;
-      case whk::EPI_GELU: ((half_t*)a.y)[rr * a.y_ld + n] = (half_t)gelu_erf(v); break;
-      case whk::EPI_F32: ((float*)a.y)[rr * a.y_ld + n] = v; break;
-      case whk::EPI_RESID: a.resid[rr * a.resid_ld + n] = e_res + v; break;
-      case whk::EPI_QKV: {
-        const int D = a.D;
-        if (n < D) ((half_t*)a.y)[rr * a.y_ld + n] = (half_t)v;
-        else {
-          const int64_t pos = e_pos - e_lag;
-          if (n < 2 * D) ((half_t*)a.kcache)[rr * a.cache_bs + pos * D + (n - D)] = (half_t)v;
-          else ((half_t*)a.vcache)[rr * a.cache_bs + pos * D + (n - 2 * D)] = (half_t)v;
-        }
-      } break;
+  for (int j = 0; j < NOUT; ++j) {
+    const int o = tid + NT * j;
+    const int es = o / (NRT * 64), ert = (o >> 6) % NRT, er = (o >> 3) & 7, ej = o & 7;
+    const int en = blockIdx.x * fw + es * 8 + ej;
+    const bool on = o < GS * NRT * 64 && ert * 8 + er < R && es * 8 + ej < fw && en < a.N;
+    if (on) {
+      float v = e_bias[j];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) v += red[es * KS + k][ert][ej][er];
+      const int64_t rr = r0 + ert * 8 + er;
+      const int n = en;
+      switch (a.epi) {
+        case whk::EPI_STORE: ((half_t*)a.y)[rr * a.y_ld + n] = (half_t)v; break;
+        case whk::EPI_GELU: ((half_t*)a.y)[rr * a.y_ld + n] = (half_t)gelu_erf(v); break;
+        case whk::EPI_F32: ((float*)a.y)[rr * a.y_ld + n] = v; break;
+        case whk::EPI_RESID: a.resid[rr * a.resid_ld + n] = e_res[j] + v; break;
+        case whk::EPI_QKV: {
+          const int D = a.D;
+          if (n < D) ((half_t*)a.y)[rr * a.y_ld + n] = (half_t)v;
+          else {
+            const int64_t pos = e_pos - e_lag[j];
+            if (n < 2 * D) ((half_t*)a.kcache)[rr * a.cache_bs + pos * D + (n - D)] = (half_t)v;
+            else ((half_t*)a.vcache)[rr * a.cache_bs + pos * D + (n - 2 * D)] = (half_t)v;
+          }
+        } break;
+      }
     }
   }
   WH_PROBE_AT(a, wgid, 6);
   if (a.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.bump, a.bump_by);
 }
 
-template <int PRO, int GS, int KS, int CSm, int XW>
-hipError_t launch_gemv8_cfg(const whk::GemvArgs& a, int fw, hipStream_t stream) {
+template <int PRO, int GS, int KS, int CSm, int XW, int NRT>
+hipError_t launch_gemv8_nrt(const whk::GemvArgs& a, int fw, hipStream_t stream) {
   constexpr int WAVES = GS * KS + XW;
   static_assert(WAVES <= 16, "at most 1024 threads per workgroup");
   if (fw < 1 || fw > 8 * GS) return hipErrorInvalidValue;
   const int nblk = a.K / 64;
   const int nu = (nblk + KS - 1) / KS;
-  dim3 grid((a.N + fw - 1) / fw, (a.R + 7) / 8), block(WAVES * 64);
-  if (nu <= 3) hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 3, CSm, XW>), grid, block, 0, stream, a, fw);
-  else if (nu <= 5) hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 5, CSm, XW>), grid, block, 0, stream, a, fw);
+  dim3 grid((a.N + fw - 1) / fw, (a.R + 8 * NRT - 1) / (8 * NRT)), block(WAVES * 64);
+  if (nu <= 3) hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 3, CSm, XW, NRT>), grid, block, 0, stream, a, fw);
+  else if (nu <= 5) hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 5, CSm, XW, NRT>), grid, block, 0, stream, a, fw);
   else return hipErrorInvalidValue;
   return hipGetLastError();
+}
+
+// rows per workgroup: 8 (the decode step of up to 8 clips), 24 or 48 (beam search / best_of rows, the few-row prefill)
+template <int PRO, int GS, int KS, int CSm, int XW>
+hipError_t launch_gemv8_cfg(const whk::GemvArgs& a, int fw, hipStream_t stream) {
+  if (a.R <= 8) return launch_gemv8_nrt<PRO, GS, KS, CSm, XW, 1>(a, fw, stream);
+  // 16-wave workgroups have 128 VGPRs per lane: 3 row tiles of x fragments (60) + the weights (20) fit, 6 would spill
+  if constexpr (GS * KS + XW < 16) {
+    if (a.R > 24) return launch_gemv8_nrt<PRO, GS, KS, CSm, XW, 6>(a, fw, stream);
+  }
+  return launch_gemv8_nrt<PRO, GS, KS, CSm, XW, 3>(a, fw, stream);
 }
 
 // features per workgroup: spread N over all 256 CUs when that leaves >= 4 features per workgroup, never more than 8 per slot
@@ -1100,8 +1153,14 @@ namespace whk {
 hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream) {
   if (a.R <= 0) return hipErrorInvalidValue;
   if (dtype == 1) {
-    // the decode step of up to 8 rows per tile (and the few-row prefill): MFMA diagonal form
-    if (a.R <= 48 && !(a.R > 8 && a.K % 128 == 0 && a.K <= 5120 && (a.K / 32 <= 40 || a.pro == whk::PRO_PLAIN))) {
+    // the decode step (and the few-row prefill, and beam-search rows): MFMA diagonal form
+    // More rows (beam search: 8 clips x 5 beams = 40): every workgroup reads ALL x rows, so beyond 8 rows the x
+    // fragments (40 rows x K) outweigh its share of the weights; measured at 40 rows, large-v3 (profiles/r02_beam_*):
+    // the 24 / 48-row forms of gemv8 take 6.5 / 8.6 / 14.3 / 11.4 / 14.9 / 18.4 us (out, cq, cout, qkv, fc1, fc2) against
+    // 4.8 / 7.9 / 11.2 / 14.9 / 11.7 / 11.3 us for the 16-row LDS-staged MFMA tiles below — those keep the job wherever
+    // they apply; gemv8's row blocks serve the remaining shapes (row counts 9..96 outside the 16-row form's limits).
+    const bool rows16 = a.R > 8 && a.variant <= 0 && a.K % 128 == 0 && a.K <= 5120 && (a.K / 32 <= 40 || a.pro == whk::PRO_PLAIN);
+    if (a.R <= 96 && !rows16) {
       const hipError_t e = launch_gemv8(a, stream);
       if (e != hipErrorNotSupported) return e;
     }
