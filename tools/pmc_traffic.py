@@ -1,4 +1,4 @@
-"""profiles/r01_pmc_fetch_size.csv + r01_pmc_write_size.csv (tools/prof_summary.py --pmc) -> r01_pmc_traffic.json:
+"""profiles/rNN_pmc_fetch_size.csv + rNN_pmc_write_size.csv (tools/prof_summary.py --pmc) -> rNN_pmc_traffic.json:
 HBM bytes per launch of the decode-step kernels.  FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled per
 /opt/skills/guides/MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of 16 B/lane streaming reads at 64 B);
 WRITE_SIZE is uncalibrated and kept raw.  Usage: python tools/pmc_traffic.py fetch.csv write.csv out.json"""
@@ -11,9 +11,13 @@ import sys
 PATTERNS = {
     "attn_decode_cross": r"attn_decode_kernelIDF16_Li16ELi4ELb0E.*grid=\(768,20,8\)",
     "attn_decode_self": r"attn_decode_kernelIDF16_Li8ELi8ELb1E.*grid=\(512,20,8\)",
-    "gemv_qkv": r"gemv_kernelIDF16_Li8ELi8ELi1ELi5ELb0ELi8ELi2ELb0E.*grid=\(122880,1,1\)",
-    "gemv_fc1": r"gemv_kernelIDF16_Li8ELi8ELi1ELi5ELb0ELi16ELi4ELb0E.*grid=\(163840,1,1\)",
-    "gemv_fc2": r"gemv_kernelIDF16_Li8ELi8ELi0ELi6ELb0ELi16ELi1ELb0E.*grid=\(163840,1,1\)",
+    # gemv8_kernel<PRO, GS, KS, NU, CSm, XW, NRT> (round 2): LN = 1, PLAIN = 0, COMBINE = 2
+    "gemv_qkv": r"gemv8_kernel<1, 2, 4, 5, 1, 8, 1>",
+    "gemv_fc1": r"gemv8_kernel<1, 3, 4, 5, 1, 4, 1>",
+    "gemv_fc2": r"gemv8_kernel<0, 1, 16, 5, 1, 0, 1>",
+    "gemv_out": r"gemv8_kernel<0, 1, 4, 5, 1, 0, 1>",
+    "gemv_cq": r"gemv8_kernel<1, 1, 4, 5, 1, 8, 1>",
+    "gemv_cout": r"gemv8_kernel<2, 1, 4, 5, 3, 8, 1>",
     "gemv_logits": r"gemv_stream_kernelIDF16_",
 }
 

@@ -224,16 +224,31 @@ __global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f
           if (key >= T) sacc[kb][r] = WH_NEG_INF;
         }
     }
-    // ---- online softmax (lane owns query lane&31; partner lane^32 holds the other 16 keys per block)
-    float mx = sacc[0][0];
+    // ---- online softmax (lane owns query lane&31; partner lane^32 holds the other 16 keys per block).
+    // The loop is bound by the vector ALU, not by the matrix cores (16 MFMAs against ~170 VALU instructions per 32 x 64
+    // score tile), so the non-exp half is trimmed: 3-input maxima, and the accumulator rescale (32 multiplies + the
+    // bookkeeping around it) is DEFERRED — the running reference maximum only moves when some query of the wave has
+    // outgrown it by more than 2^DEFER (exp2 domain); until then p = exp2(s - m_ref) <= 2^DEFER stays well inside fp16
+    // and fp32 ranges and the result is mathematically unchanged (softmax is invariant to the reference point).
+    constexpr float DEFER = 6.0f;
+    float mx = __builtin_fmaxf(__builtin_fmaxf(sacc[0][0], sacc[0][1]), sacc[0][2]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
+    for (int r = 3; r + 1 < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, sacc[0][r]), sacc[0][r + 1]);   // v_max3_f32
+    mx = fmaxf(mx, sacc[0][15]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
+    for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, sacc[1][r]), sacc[1][r + 1]);
     { float pa, pb; lane_swap32(mx, pa, pb); mx = fmaxf(pa, pb); }   // partner half (lane ^ 32) without LDS
-    const float m_new = fmaxf(m_run, mx);          // finite: key 0 of every tile is valid
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * SCALE_LOG2E);
-    const float mc = m_new * SCALE_LOG2E;
+    // m_run is kept in the exp2 domain (already multiplied by SCALE_LOG2E); -inf before the first tile
+    const float mxs = mx * SCALE_LOG2E;
+    if (__any(mxs > m_run + DEFER)) {              // wave-uniform: rare after the first tiles
+      const float m_new = fmaxf(m_run, mxs);       // finite: key 0 of every tile is valid
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 0 on the first tile (m_run = -inf)
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+      m_run = m_new;
+    }
+    const float mc = m_run;
     float psum = 0.f;
     half8v pf[2][2];
 #pragma unroll
@@ -244,10 +259,7 @@ __global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f
         psum += p;
         pf[kb][r >> 3][r & 7] = (half_t)p;
       }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+    l_run += psum;
 
     // ---- O^T += V^T · P^T
 #pragma unroll

@@ -278,15 +278,29 @@ __global__ __launch_bounds__(256) void greedy_final_kernel(whk::SampleArgs a, in
   }
 }
 
-__global__ __launch_bounds__(256) void no_speech_kernel(const float* __restrict__ logits, int64_t row_stride,
-                                                        int V, int no_speech, float* __restrict__ out) {
-  __shared__ float sh_m[4], sh_s[4];
+// softmax(logits at <|startoftranscript|>)[no_speech] per row (decoding.py:689-693).  One workgroup of 1024 threads per
+// row; every thread requests 8 logits before it folds any of them (the first version walked the row with one dependent
+// L2 round trip per 256 entries: 72 us for 51866 entries; this form takes a handful of round trips).
+__global__ __launch_bounds__(1024) void no_speech_kernel(const float* __restrict__ logits, int64_t row_stride,
+                                                         int V, int no_speech, float* __restrict__ out) {
+  __shared__ float sh_m[16], sh_s[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* x = logits + (int64_t)blockIdx.x * row_stride;
   float m = WH_NEG_INF, s = 0.f;
-  for (int v = tid; v < V; v += 256) {
-    const float xv = x[v];
-    if (xv > m) { s = s * expf(m - xv) + 1.0f; m = xv; } else s += expf(xv - m);
+  constexpr int UN = 8;
+  for (int v0 = 0; v0 < V; v0 += 1024 * UN) {
+    float xv[UN];
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+      int v = v0 + j * 1024 + tid; if (v > V - 1) v = V - 1;       // branch-free loads, masked at use
+      xv[j] = x[v];
+    }
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+      if (v0 + j * 1024 + tid < V) {
+        if (xv[j] > m) { s = s * expf(m - xv[j]) + 1.0f; m = xv[j]; } else s += expf(xv[j] - m);
+      }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -298,9 +312,10 @@ __global__ __launch_bounds__(256) void no_speech_kernel(const float* __restrict_
   if (lane == 0) { sh_m[wave] = m; sh_s[wave] = s; }
   __syncthreads();
   if (tid == 0) {
-    float M = fmaxf(fmaxf(sh_m[0], sh_m[1]), fmaxf(sh_m[2], sh_m[3]));
+    float M = sh_m[0];
+    for (int w = 1; w < 16; ++w) M = fmaxf(M, sh_m[w]);
     float S = 0.f;
-    for (int w = 0; w < 4; ++w) S += sh_s[w] * expf(sh_m[w] - M);
+    for (int w = 0; w < 16; ++w) S += (sh_m[w] == WH_NEG_INF) ? 0.f : sh_s[w] * expf(sh_m[w] - M);
     out[blockIdx.x] = expf(x[no_speech] - M) / S;
   }
 }
@@ -332,7 +347,7 @@ hipError_t launch_greedy_sample(const SampleArgs& a, hipStream_t stream) {
 
 hipError_t launch_no_speech(const float* logits, int64_t row_stride, int R, int V, int no_speech,
                             float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(no_speech_kernel, dim3(R), dim3(256), 0, stream, logits, row_stride, V, no_speech, out);
+  hipLaunchKernelGGL(no_speech_kernel, dim3(R), dim3(1024), 0, stream, logits, row_stride, V, no_speech, out);
   return hipGetLastError();
 }
 
