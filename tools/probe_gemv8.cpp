@@ -1,8 +1,9 @@
 // tools/probe_gemv8.cpp — developer probe (not part of the product): the six decode-step projections of one large-v3
 // decoder layer (R = 8 rows, fp16), each as a chain of 64 dependent launches replayed from a hipGraph, rotating over 8
 // layer copies (HBM-cold).  Reports us per link and, with -DWH_PROBE, the s_memtime phase medians per workgroup:
-//   0 entry | 1 loads issued | 2 prologue arithmetic done | 3 fragments shared | 4 MFMA + diagonal sum + LDS write |
-//   5 barrier | 6 epilogue stores issued
+//   thread 0 of the workgroup (a prologue wave when the kernel has them, else weight wave 0):
+//   0 entry | 1 own loads issued | 2 prologue arithmetic done, fragments written | 3 barrier, fragments read |
+//   4 MFMAs + diagonal sum + partial sums written | 5 barrier | 6 epilogue stores issued
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DWH_PROBE -I include tools/probe_gemv8.cpp -o tools/probe_gemv8
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -82,7 +83,7 @@ int main(int argc, char** argv) {
     std::vector<long long> p((size_t)nwg * 8);
     CK(hipMemcpy(p.data(), d_probe, p.size() * 8, hipMemcpyDeviceToHost));
     printf("%-26s %-6s %6.2f us/link | phases:", c.name, variant == 99 ? "dot2" : "mfma8", best * 1e3f / N);
-    const int npt = (c.pro == whk::PRO_LN && variant != 99) ? 8 : 7;
+    const int npt = 7;
     for (int i = 1; i < npt; ++i) {
       std::vector<long long> d;
       for (int w = 0; w < nwg; ++w) d.push_back(p[(size_t)w * 8 + i] - p[(size_t)w * 8 + i - 1]);
