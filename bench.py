@@ -380,6 +380,8 @@ def cpu_baseline(args, dims, init, suppress, tok, audio_np, sd, hip_row0):
                       f"steps (fp32, torch CPU, {cores} threads)"}
     # parity of the benchmarked engine: the oracle's tokens for clip 0 against row 0 of the HIP pass
     want = dec["tokens"][0, len(init):].tolist()
+    if hip_row0 is None:                       # tools/cpu_baseline_only.py: no HIP pass to compare with
+        return base, None
     got = hip_row0[: len(want)]
     t = oracle.first_divergence(got, want)
     parity = {"steps": len(want), "tokens_equal": t is None, "first_divergence": t, "margin": None,
