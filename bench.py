@@ -263,7 +263,7 @@ def main():
     task.close()
 
     # ---- the same workload through the public drop-in surface ----------------------------------------------------
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:      # single-GPU runs only: the scaling runs stay short
         wmodel = Whisper(ModelDimensions(**dims_dict(dims)), {}, device=device)
         wmodel.adopt_engine(torch.float16, model)
         opts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=N, suppress_tokens=[-1, tok.eot])
@@ -329,8 +329,9 @@ def main():
         out["parity"] = parity
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()                      # rank 0 measures its kernel table after the timed region: leave together
         dist.destroy_process_group()
 
 
