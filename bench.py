@@ -62,6 +62,8 @@ def parse():
     p.add_argument("--beam-steps", type=int, default=64)
     p.add_argument("--word-timestamps", dest="word_timestamps", action="store_true", default=True)
     p.add_argument("--no-word-timestamps", dest="word_timestamps", action="store_false")
+    p.add_argument("--no-other-configs", dest="other_configs", action="store_false", default=True,
+                   help="skip the base x 1 and turbo x 32 (+ word timestamps) legs of the extras")
     p.add_argument("--cpu-steps", type=int, default=12, help="decode steps timed on the CPU baseline")
     p.add_argument("--cpu-repeats", type=int, default=3)
     p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = all usable cores)")
@@ -321,6 +323,13 @@ def main():
             log(f"word timestamps: {wms:.1f} ms per batch of {B} clips")
         out["extras"] = extras
         wmodel = None
+        # BASELINE configs[1] (base, 1 clip, greedy) and configs[4] (turbo, 32 clips, greedy + word timestamps) at their own
+        # model dims, through the public API; weights generated on the device
+        if args.other_configs and args.model == "large-v3":
+            task_bytes = model.task_cache_bytes
+            model.drop_cached_tasks()
+            extras["other_configs"] = other_configs(device, N)
+            model.task_cache_bytes = task_bytes
 
     # ---- CPU baseline: the oracle (fp32 torch-CPU restatement of the reference) on this box's host cores ----
     if want_cpu:
@@ -333,6 +342,50 @@ def main():
     if dist is not None:
         dist.barrier()                      # rank 0 measures its kernel table after the timed region: leave together
         dist.destroy_process_group()
+
+
+def other_configs(device, N):
+    """BASELINE.json configs[1] / configs[4] shapes on this GPU (never the headline): audio-s/s through
+    log_mel_spectrogram + decode() [+ find_alignment_batch], fixed N steps per clip, synthetic weights of those dims."""
+    import whisper_amd
+    from whisper_amd import hip
+    from whisper_amd.model import ModelDimensions, Whisper
+    from whisper_amd.synthetic import dims_dict, dims_for, synthetic_state_dict
+    from whisper_amd.timing import find_alignment_batch
+    from whisper_amd.tokenizer import get_tokenizer
+    res = {}
+    for name, batch, words in (("base", 1, False), ("turbo", 32, True)):
+        dims = dims_for(name)
+        sd = synthetic_state_dict(dims, seed=0, device=device)
+        eng = hip.HipModel(dims, hip.WH_F16, hip.pack_weights(sd, dims, hip.WH_F16, device))
+        del sd
+        m = Whisper(ModelDimensions(**dims_dict(dims)), {}, device=device)
+        m.adopt_engine(torch.float16, eng)
+        tok = get_tokenizer(True, num_languages=dims.n_vocab - 51765 - 1, language="en", task="transcribe")
+        audio = synth_audio(batch, 0, device)
+        opts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=N, suppress_tokens=[-1, tok.eot])
+
+        def one():
+            mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
+            r = whisper_amd.decode(m, mel, opts)
+            if words:
+                text = [[t for t in x.tokens if t < tok.eot][:200] for x in r]
+                find_alignment_batch(m, tok, text, mel.half(), [3000] * batch)
+            return r
+        one()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            one()
+        torch.cuda.synchronize(device)
+        ms = (time.perf_counter() - t0) / 2 * 1e3
+        key = f"{name}_x{batch}" + ("_word_timestamps" if words else "")
+        res[key] = {"ms_per_pass": round(ms, 2), "audio_s_per_s": round(30.0 * batch / (ms * 1e-3), 1), "steps": N}
+        log(f"other config {key}: {ms:.1f} ms per pass = {30.0 * batch / (ms * 1e-3):.0f} audio-s/s")
+        eng.drop_cached_tasks()
+        m = eng = None
+        torch.cuda.empty_cache()
+    return res
 
 
 def cpu_baseline(args, dims, init, suppress, tok, audio_np, sd, hip_row0):

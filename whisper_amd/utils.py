@@ -1,5 +1,7 @@
-"""Small host-side helpers shared by the decoding / transcribe mirrors (reference: whisper/utils.py:24-82).
-The file writers of the reference (utils.py:85-318) are outside the hot-path scope."""
+"""Host-side helpers shared by the decoding / transcribe mirrors (reference: whisper/utils.py:24-82) and the result
+writers `get_writer` / `WriteTXT` / `WriteVTT` / `WriteSRT` / `WriteTSV` / `WriteJSON` (reference utils.py:85-318;
+SURVEY.md §8f rank 4: byte-identical output, tests/test_writers.py).  The argparse CLI and `whisper.normalizers` are
+deliberately not part of this package (README.md)."""
 from __future__ import annotations
 
 import os
