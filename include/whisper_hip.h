@@ -97,7 +97,8 @@ typedef struct wh_model_weights {
 #define WH_WEIGHTS_DEC_LN_FOLDED 1u
 
 typedef struct wh_model wh_model;   /* opaque: dims + copies of the pointer tables */
-typedef struct wh_task wh_task;     /* opaque: per-DecodingTask KV caches + workspace carve-up */
+typedef struct wh_task wh_task;     /* opaque: per-DecodingTask KV caches + workspace carve-up.  One call at a time per
+                                     * handle: a second thread entering while a call runs gets WH_ERR_STATE (enforced) */
 
 /* ---- library ------------------------------------------------------------------------------ */
 int wh_abi_version(void);

@@ -240,3 +240,52 @@ def test_fused_greedy_step_count_edges(micro, gpu_device, n_steps):
         assert np.allclose(sum_lp.cpu().numpy(), np.array(want["sum_logprobs"]), atol=2e-3)
     finally:
         task.close()
+
+
+def test_task_handle_refuses_concurrent_callers(micro, gpu_device):
+    """handles are not thread-safe (include/whisper_hip.h); this is enforced: while one thread is inside a call on a
+    task (here: a long fused greedy decode), a second thread calling into the SAME task gets 'invalid call sequence'
+    instead of corrupting it; afterwards the task works as before"""
+    import threading
+    dims, sd, om, models = micro["micro.en"]
+    model = models[hip.WH_F16]
+    from whisper_amd.tokenizer import get_tokenizer
+    tok = get_tokenizer(False)
+    init = list(tok.sot_sequence)
+    task = hip.HipTask(model, 2, 1, 8)
+    try:
+        task.set_audio(_feats(om, dims, 2).to(gpu_device, torch.float16).contiguous())
+        mask = torch.zeros(dims.n_vocab, dtype=torch.uint8, device=gpu_device)
+        mask[tok.eot] = 1
+        params = hip.GreedyParams(sample_begin=len(init), max_steps=400, n_ctx=dims.n_text_ctx, eot=tok.eot,
+                                  timestamp_begin=tok.timestamp_begin, no_timestamps=tok.no_timestamps,
+                                  max_initial_timestamp_index=50, suppress_blank=1, blank_token=tok.encode(" ")[0],
+                                  suppress_mask=mask.data_ptr())
+        tokens = torch.zeros(2, len(init) + 401, dtype=torch.int64, device=gpu_device)
+        tokens[:, :len(init)] = torch.tensor(init, device=gpu_device)
+        seen = []
+
+        def intruder():
+            import time
+            t_end = time.time() + 20
+            while hip.lib().wh_task_position(task.handle) <= 0 and time.time() < t_end:      # unguarded query: wait until
+                pass                                                                         # the decode is inside its call
+            while "n" not in done and time.time() < t_end:
+                rc = hip.lib().wh_task_reset(task.handle, None)
+                if rc != 0:
+                    seen.append(rc)
+                    return
+        th = threading.Thread(target=intruder)
+        done = {}
+
+        def decode():
+            done["n"] = task.greedy(tokens, params, 0, -1)[0]
+        td = threading.Thread(target=decode)
+        td.start(); th.start(); td.join(); th.join()
+        assert seen == [4], seen                                   # WH_ERR_STATE while the decode held the handle
+        assert done["n"] == len(init) + 400
+        task.reset()
+        task.set_audio(_feats(om, dims, 2).to(gpu_device, torch.float16).contiguous())
+        assert task.prefill(tokens[:, :len(init)].contiguous()).shape == (2, len(init), dims.n_vocab)
+    finally:
+        task.close()

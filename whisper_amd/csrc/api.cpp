@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -277,6 +278,7 @@ struct wh_task {
   int* h_lag;              // host copy
   bool lag_on;
   bool needs_reset;        // created, position counter / lag not zeroed yet
+  std::atomic<int> busy;   // handles are not thread-safe: a second thread entering while a call runs gets WH_ERR_STATE
   int64_t* step_tokens;
   float* samp_part;        // greedy sampler stage-1 partials
   void* beam_scratch;      // beam search partials / candidates (G > 1)
@@ -285,6 +287,17 @@ struct wh_task {
   int cross_splits, self_splits;
   size_t total;
 };
+
+// One call at a time per task handle (include/whisper_hip.h: "not thread-safe per handle"), enforced instead of only
+// documented: the second caller is refused, nothing is corrupted.
+struct TaskGuard {
+  wh_task* t; bool ok;
+  explicit TaskGuard(wh_task* task) : t(task), ok(false) {
+    if (t) { int expected = 0; ok = t->busy.compare_exchange_strong(expected, 1); }
+  }
+  ~TaskGuard() { if (t && ok) t->busy.store(0); }
+};
+#define TASK_ENTER(task) TaskGuard _guard(task); if ((task) && !_guard.ok) return WH_ERR_STATE
 
 // key-range splits of the decode attention: enough for the register-resident tile to hold a split
 // (attn_decode_capacity) and enough workgroups (>= ~640) to cover the 256 CUs with loads in flight
@@ -364,6 +377,7 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
   // no device work here: the position counter and the lag array are zeroed by the first wh_task_reset, which the
   // caller issues on the stream the workspace is valid on
   t->needs_reset = true;
+  t->busy.store(0);
   *out = t;
   return WH_OK;
 }
@@ -378,7 +392,12 @@ extern "C" void wh_task_destroy(wh_task* t) {
 
 extern "C" int wh_task_position(const wh_task* t) { return t ? t->pos : -1; }
 
+static int task_reset_impl(wh_task* t, void* stream_);
 extern "C" int wh_task_reset(wh_task* t, void* stream_) {
+  TASK_ENTER(t);
+  return task_reset_impl(t, stream_);
+}
+static int task_reset_impl(wh_task* t, void* stream_) {
   if (!t) return WH_ERR_ARG;
   hipStream_t s = (hipStream_t)stream_;
   HIPCHK(hipMemsetAsync(t->d_pos, 0, 4, s));     // stream-ordered: no host or device-wide synchronisation
@@ -397,10 +416,11 @@ extern "C" int wh_task_reset(wh_task* t, void* stream_) {
 // id; causality keeps them out of the real positions and the decode steps overwrite their cache slots), and every
 // later step appends row r at position - lag[r].  Cleared by wh_task_reset.
 extern "C" int wh_task_set_lag(wh_task* t, const int32_t* lag, void* stream) {
+  TASK_ENTER(t);
   if (!t) return WH_ERR_ARG;
   if (t->pos != 0) return WH_ERR_STATE;
   if (t->flags & WH_TASK_CAPTURE_Q) return WH_ERR_STATE;      // captured queries are indexed by the common position
-  if (t->needs_reset) { const int rc = wh_task_reset(t, stream); if (rc != WH_OK) return rc; }
+  if (t->needs_reset) { const int rc = task_reset_impl(t, stream); if (rc != WH_OK) return rc; }
   bool any = false;
   for (int r = 0; r < t->R; ++r) {
     const int v = lag ? lag[r] : 0;
@@ -415,8 +435,9 @@ extern "C" int wh_task_set_lag(wh_task* t, const int32_t* lag, void* stream) {
 }
 
 extern "C" int wh_task_set_audio(wh_task* t, const void* features, void* stream_) {
+  TASK_ENTER(t);
   if (!t || !features) return WH_ERR_ARG;
-  if (t->needs_reset) { const int rc = wh_task_reset(t, stream_); if (rc != WH_OK) return rc; }
+  if (t->needs_reset) { const int rc = task_reset_impl(t, stream_); if (rc != WH_OK) return rc; }
   hipStream_t s = (hipStream_t)stream_;
   const wh_model* m = t->m;
   const wh_dims& d = m->d;
@@ -591,6 +612,7 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
 
 extern "C" int wh_task_prefill(wh_task* t, const int64_t* tokens, int64_t token_stride, int T0,
                                const int32_t* sel_pos, int n_sel, float* logits_out, void* stream) {
+  TASK_ENTER(t);
   if (!t || !tokens) return WH_ERR_ARG;
   if (!sel_pos) n_sel = T0;
   return prefill_impl(t, tokens, token_stride, T0, sel_pos, n_sel, logits_out, t->m->d.n_vocab, (hipStream_t)stream);
@@ -713,6 +735,7 @@ static int step_run(wh_task* t, hipStream_t s) {
 
 extern "C" int wh_task_step(wh_task* t, const int64_t* last_tokens, int64_t token_stride, float* logits_out,
                             void* stream_) {
+  TASK_ENTER(t);
   if (!t || !last_tokens || !logits_out) return WH_ERR_ARG;
   hipStream_t s = (hipStream_t)stream_;
   HIPCHK(launch_gather_tokens(last_tokens, token_stride, t->R, t->step_tokens, s));
@@ -724,6 +747,7 @@ extern "C" int wh_task_step(wh_task* t, const int64_t* last_tokens, int64_t toke
 }
 
 extern "C" int wh_task_rearrange(wh_task* t, const int32_t* source_indices, void* stream_) {
+  TASK_ENTER(t);
   if (!t || !source_indices) return WH_ERR_ARG;
   hipStream_t s = (hipStream_t)stream_;
   const wh_dims& d = t->m->d;
@@ -761,6 +785,7 @@ extern "C" int wh_task_rearrange(wh_task* t, const int32_t* source_indices, void
 extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* tokens, int64_t token_stride,
                               int sot_index, int no_speech_token, float* sum_logprobs, float* no_speech_probs,
                               int32_t* n_tokens_out, void* stream_) {
+  TASK_ENTER(t);
   if (!t || !p || !tokens || !sum_logprobs || !n_tokens_out) return WH_ERR_ARG;
   hipStream_t s = (hipStream_t)stream_;
   const wh_dims& d = t->m->d;
@@ -825,6 +850,7 @@ extern "C" int wh_task_beam(wh_task* t, const wh_beam_params* bp, int64_t* token
                             int no_speech_token, float* sum_logprobs, float* no_speech_probs, int64_t* fin_tokens,
                             int32_t* fin_len, float* fin_scores, int32_t* fin_count, int32_t* n_tokens_out,
                             void* stream_) {
+  TASK_ENTER(t);
   if (!t || !bp || !tokens || !sum_logprobs || !fin_tokens || !fin_len || !fin_scores || !fin_count || !n_tokens_out)
     return WH_ERR_ARG;
   hipStream_t s = (hipStream_t)stream_;
@@ -1002,6 +1028,7 @@ static int bench_issue(wh_task* t, int kind, int iters, double* bytes_per_launch
 // host's launch rate instead).  kind 0 = the whole step (257 launches + the counter reset), captured the same way.
 extern "C" int wh_task_bench_kernel(wh_task* t, int kind, int iters, double* bytes_per_launch, float* ms_per_launch,
                                     void* stream_) {
+  TASK_ENTER(t);
   if (!t || iters <= 0 || !ms_per_launch) return WH_ERR_ARG;
   if (!t->audio_set || t->pos <= 0) return WH_ERR_STATE;
   hipStream_t s = (hipStream_t)stream_;
@@ -1037,6 +1064,7 @@ extern "C" int wh_task_bench_kernel(wh_task* t, int kind, int iters, double* byt
 // ---- word timestamps ---------------------------------------------------------------------------------
 extern "C" int wh_task_cross_qk(wh_task* t, int row, const int32_t* layers, const int32_t* heads, int n_pairs,
                                 int tok_begin, int n_tok, float* out, void* stream_) {
+  TASK_ENTER(t);
   if (!t || !layers || !heads || !out || n_pairs <= 0) return WH_ERR_ARG;
   if (!t->qcap) return WH_ERR_STATE;
   const wh_dims& d = t->m->d;
@@ -1073,6 +1101,7 @@ extern "C" int wh_task_align_batch(wh_task* t, const int32_t* layers, const int3
                                    const int32_t* n_tok, const int32_t* n_frames, int width, int row_begin, float qk_scale,
                                    float* cost_out, int8_t* trace_out, int64_t trace_stride, void* scratch,
                                    size_t scratch_bytes, void* stream_) {
+  TASK_ENTER(t);
   if (!t || !layers || !heads || !n_tok || !n_frames || !cost_out || !trace_out || !scratch || n_pairs <= 0) return WH_ERR_ARG;
   if (!t->qcap) return WH_ERR_STATE;
   if (width <= 0 || (width & 1) == 0 || width > 63 || row_begin < 0) return WH_ERR_ARG;
