@@ -95,6 +95,13 @@ typedef struct wh_model_weights {
  *   projections then normalise in registers without reading gamma / beta.  decoder.ln (tied to the token embedding)
  *   and the encoder are never folded.  whisper_amd.hip.pack_weights does this for WH_F16 blobs. */
 #define WH_WEIGHTS_DEC_LN_FOLDED 1u
+/* WH_WEIGHTS_ENC_QK_SCALED (WH_F16 only): in every ENCODER block the query and key rows of qkv_w (rows [0, 2 n_state))
+ *   and the query part of qkv_b are multiplied by sqrt(0.125 * log2 e) = 0.42466..., so that k.q is already the base-2
+ *   exponent of the softmax: whisper/model.py:118-121 scales q and k by d_head ** -0.25 each (0.125 on the product),
+ *   and exp(x) = 2 ** (x log2 e).  The encoder's flash-attention kernel then exponentiates the score accumulators as
+ *   they are.  Without the flag the kernel multiplies by 0.125 log2 e itself.  whisper_amd.hip.pack_weights sets it
+ *   for WH_F16 blobs; the decoder's attention is never pre-scaled. */
+#define WH_WEIGHTS_ENC_QK_SCALED 2u
 
 typedef struct wh_model wh_model;   /* opaque: dims + copies of the pointer tables */
 typedef struct wh_task wh_task;     /* opaque: per-DecodingTask KV caches + workspace carve-up.  One call at a time per

@@ -235,7 +235,7 @@ extern "C" int wh_encode(const wh_model* m, const void* mel, int mel_is_f16, int
       HIPCHK(launch_gemm(g, m->dtype, 0, B, s));
       HIPCHK(launch_attn_flash_f16(w.qkv, 2 * D, (int64_t)T * 2 * D, (const char*)w.qkv + (size_t)D * es, 2 * D,
                                    (int64_t)T * 2 * D, w.vt, VT_LD, (int64_t)D * VT_LD, w.att, D,
-                                   (int64_t)T * D, B, H, T, s));
+                                   (int64_t)T * D, B, H, T, (m->w.flags & WH_WEIGHTS_ENC_QK_SCALED) ? 1 : 0, s));
     } else {
       HIPCHK(gemm(m, w.xn, D, L.qkv_w, D, w.qkv, 3 * D, M, 3 * D, L.qkv_b, 0, nullptr, 0, false, s));
       AttnArgs a; memset(&a, 0, sizeof(a));

@@ -137,6 +137,12 @@ constexpr int FQ = FW * 32;          // queries per workgroup (32 per wave)
 #ifndef WH_FLASH_WAVES_PER_SIMD
 #define WH_FLASH_WAVES_PER_SIMD 2
 #endif
+// PRESCALED: q and k arrive multiplied by sqrt(0.125 * log2 e) each (WH_WEIGHTS_ENC_QK_SCALED: the factor sits in the
+// encoder's query / key projection weights), so K·Q^T is already the exp2 argument.  The score accumulators then
+// start at -m_ref instead of 0 and p = exp2(acc) needs no multiply-subtract, and the row sums are taken from the fp16
+// P two at a time (v_dot2_f32_f16).  Per 32 x 64 score tile that leaves 32 v_exp + 16 v_cvt_pk + 16 v_dot2 + 16 v_max3
+// on the vector ALU (the bound of this loop) where the unscaled form has 32 v_fma + 32 v_add instead of the v_dot2.
+template <bool PRESCALED>
 __global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f16_kernel(
     const half_t* __restrict__ q, int64_t q_ld, int64_t q_bs, const half_t* __restrict__ k, int64_t k_ld,
     int64_t k_bs, const half_t* __restrict__ vt, int64_t vt_ld, int64_t vt_bs, half_t* __restrict__ out,
@@ -163,20 +169,40 @@ __global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f
   float16v oacc[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
-  float m_run = WH_NEG_INF, l_run = 0.f;
+  float m_run = PRESCALED ? 0.f : WH_NEG_INF, l_run = 0.f;
 
   const int nkt = (T + 63) / 64;
-  // staging: thread handles units u = tid, tid + threads, ... of each 512-unit tile
+  // staging: thread handles units u = tid, tid + threads, ... of each 512-unit tile.  Addresses are a uniform base
+  // that advances with the tile (scalar ALU) plus a per-thread 32-bit offset that never changes: no vector
+  // arithmetic per tile except on the last, ragged one, whose key rows are clamped.
   constexpr int SJ = 512 / (FW * 64);
   uint4v kreg[SJ], vreg[SJ];
-  auto gload = [&](int kt) {
+  uint32_t koff[SJ], voff[SJ];
 #pragma unroll
-    for (int j = 0; j < SJ; ++j) {
-      const int u = tid + FW * 64 * j;
-      const int row = u >> 3, cu = u & 7;
-      int key = kt * 64 + row; if (key > T - 1) key = T - 1;
-      kreg[j] = *(const uint4v*)(kp + (int64_t)key * k_ld + cu * 8);
-      vreg[j] = *(const uint4v*)(vp + (int64_t)row * vt_ld + kt * 64 + cu * 8);
+  for (int j = 0; j < SJ; ++j) {
+    const int u = tid + FW * 64 * j;
+    const int row = u >> 3, cu = u & 7;
+    koff[j] = (uint32_t)((row * k_ld + cu * 8) * 2);
+    voff[j] = (uint32_t)((row * vt_ld + cu * 8) * 2);
+  }
+  auto gload = [&](int kt) {
+    const char* kb = (const char*)kp + (int64_t)kt * 64 * k_ld * 2;
+    const char* vb = (const char*)vp + (int64_t)kt * 128;
+    if (kt * 64 + 64 <= T) {
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        kreg[j] = *(const uint4v*)(kb + koff[j]);
+        vreg[j] = *(const uint4v*)(vb + voff[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        const int u = tid + FW * 64 * j;
+        const int row = u >> 3, cu = u & 7;
+        int key = kt * 64 + row; if (key > T - 1) key = T - 1;
+        kreg[j] = *(const uint4v*)(kp + (int64_t)key * k_ld + cu * 8);
+        vreg[j] = *(const uint4v*)(vb + voff[j]);
+      }
     }
   };
   auto lstore = [&](int buf) {
@@ -205,17 +231,21 @@ __global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f
     float16v sacc[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      const float s0 = PRESCALED ? -m_run : 0.f;   // (a separate C operand holding -m_run measured slower than these v_mov)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+      for (int i = 0; i < 16; ++i) sacc[kb][i] = s0;
       const int krow = kb * 32 + (lane & 31);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        // (requesting all eight K fragments / all eight V^T fragments up front costs 17 VGPRs, i.e. the third wave per
+        // SIMD, and measured 10 % slower than this read-wait-multiply order)
         const half8v kf = *(const half8v*)(sK + swz_byte(krow, 2 * s + hi));
         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
       }
     }
     // ---- mask tail keys (only the last tile can be ragged)
     if (kt == nkt - 1 && (T & 63) != 0) {
+      asm volatile("" ::: "memory");                 // keeps this a branch (if-converted it is 31 v_cndmask on EVERY tile)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -225,11 +255,11 @@ __global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f
         }
     }
     // ---- online softmax (lane owns query lane&31; partner lane^32 holds the other 16 keys per block).
-    // The loop is bound by the vector ALU, not by the matrix cores (16 MFMAs against ~170 VALU instructions per 32 x 64
-    // score tile), so the non-exp half is trimmed: 3-input maxima, and the accumulator rescale (32 multiplies + the
-    // bookkeeping around it) is DEFERRED — the running reference maximum only moves when some query of the wave has
-    // outgrown it by more than 2^DEFER (exp2 domain); until then p = exp2(s - m_ref) <= 2^DEFER stays well inside fp16
-    // and fp32 ranges and the result is mathematically unchanged (softmax is invariant to the reference point).
+    // The loop is bound by the vector ALU, not by the matrix cores, so the non-exp half is trimmed: 3-input maxima,
+    // and the accumulator rescale (32 multiplies + the bookkeeping around it) is DEFERRED — the running reference
+    // maximum only moves when some query of the wave has outgrown it by more than 2^DEFER (exp2 domain); until then
+    // p = exp2(s - m_ref) <= 2^DEFER stays well inside fp16 and fp32 ranges and the result is mathematically
+    // unchanged (softmax is invariant to the reference point).
     constexpr float DEFER = 6.0f;
     float mx = __builtin_fmaxf(__builtin_fmaxf(sacc[0][0], sacc[0][1]), sacc[0][2]);
 #pragma unroll
@@ -238,28 +268,45 @@ __global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f
 #pragma unroll
     for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, sacc[1][r]), sacc[1][r + 1]);
     { float pa, pb; lane_swap32(mx, pa, pb); mx = fmaxf(pa, pb); }   // partner half (lane ^ 32) without LDS
-    // m_run is kept in the exp2 domain (already multiplied by SCALE_LOG2E); -inf before the first tile
-    const float mxs = mx * SCALE_LOG2E;
-    if (__any(mxs > m_run + DEFER)) {              // wave-uniform: rare after the first tiles
-      const float m_new = fmaxf(m_run, mxs);       // finite: key 0 of every tile is valid
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 0 on the first tile (m_run = -inf)
-      l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
-      m_run = m_new;
-    }
-    const float mc = m_run;
-    float psum = 0.f;
     half8v pf[2][2];
+    if constexpr (PRESCALED) {
+      // mx is already relative to the reference (the accumulators started at -m_run); key 0 of every tile is valid,
+      // so it is finite.  The first tile always sets the reference.
+      if (kt == 0 || __any(mx > DEFER)) {            // wave-uniform: rare after the first tiles
+        const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][r], SCALE_LOG2E, -mc));   // v_exp_f32
-        psum += p;
-        pf[kb][r >> 3][r & 7] = (half_t)p;
+        for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; sacc[0][i] -= delta; sacc[1][i] -= delta; }
+        l_run *= alpha;
+        m_run += delta;
       }
-    l_run += psum;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pf[kb][r >> 3][r & 7] = (half_t)__builtin_amdgcn_exp2f(sacc[kb][r]);   // v_exp_f32
+    } else {
+      // m_run is kept in the exp2 domain (already multiplied by SCALE_LOG2E); -inf before the first tile
+      const float mxs = mx * SCALE_LOG2E;
+      if (__any(mxs > m_run + DEFER)) {              // wave-uniform: rare after the first tiles
+        const float m_new = fmaxf(m_run, mxs);       // finite: key 0 of every tile is valid
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 0 on the first tile (m_run = -inf)
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+        m_run = m_new;
+      }
+      const float mc = m_run;
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][r], SCALE_LOG2E, -mc));   // v_exp_f32
+          psum += p;
+          pf[kb][r >> 3][r & 7] = (half_t)p;
+        }
+      l_run += psum;
+    }
 
     // ---- O^T += V^T · P^T
 #pragma unroll
@@ -276,13 +323,29 @@ __global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s2], oacc[dt], 0, 0, 0);
         }
     }
+    if constexpr (PRESCALED) {
+      // row sums of the fp16 P by v_dot2_f32_f16, two scores per instruction (a third "V^T" tile of ones on the
+      // matrix cores does the same for 4 MFMAs and 16 more VGPRs: measured 1-3 % slower)
+      const half_t one = (half_t)1.0f;
+      const half2v one2 = {one, one};
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int e = 0; e < 8; e += 2)
+            l_run = __builtin_amdgcn_fdot2(half2v{pf[kb][s2][e], pf[kb][s2][e + 1]}, one2, l_run, false);
+    }
 
     if (kt + 1 < nkt) lstore(cur ^ 1);
     __syncthreads();
   }
 
-  float l_a, l_b; lane_swap32(l_run, l_a, l_b);
-  const float l_tot = l_a + l_b;
+  float l_tot;
+  {
+    float l_a, l_b; lane_swap32(l_run, l_a, l_b);
+    l_tot = l_a + l_b;
+  }
   const float inv = 1.0f / l_tot;
   if (qrow < T) {
     half_t* op = out + (int64_t)b * o_bs + (int64_t)qrow * o_ld + h * 64;
@@ -656,10 +719,14 @@ hipError_t launch_attn_generic(const AttnArgs& a, int batch, int dtype, hipStrea
 
 hipError_t launch_attn_flash_f16(const void* q, int64_t q_ld, int64_t q_bs, const void* k, int64_t k_ld,
                                  int64_t k_bs, const void* vt, int64_t vt_ld, int64_t vt_bs, void* out,
-                                 int64_t o_ld, int64_t o_bs, int B, int H, int T, hipStream_t stream) {
+                                 int64_t o_ld, int64_t o_bs, int B, int H, int T, int prescaled, hipStream_t stream) {
   dim3 grid((T + FQ - 1) / FQ, H, B), block(FW * 64);
-  hipLaunchKernelGGL(attn_flash_f16_kernel, grid, block, 0, stream, (const half_t*)q, q_ld, q_bs,
-                     (const half_t*)k, k_ld, k_bs, (const half_t*)vt, vt_ld, vt_bs, (half_t*)out, o_ld, o_bs, T);
+  if (prescaled)
+    hipLaunchKernelGGL(attn_flash_f16_kernel<true>, grid, block, 0, stream, (const half_t*)q, q_ld, q_bs,
+                       (const half_t*)k, k_ld, k_bs, (const half_t*)vt, vt_ld, vt_bs, (half_t*)out, o_ld, o_bs, T);
+  else
+    hipLaunchKernelGGL(attn_flash_f16_kernel<false>, grid, block, 0, stream, (const half_t*)q, q_ld, q_bs,
+                       (const half_t*)k, k_ld, k_bs, (const half_t*)vt, vt_ld, vt_bs, (half_t*)out, o_ld, o_bs, T);
   return hipGetLastError();
 }
 

@@ -32,7 +32,8 @@ struct GemmArgs {
   const float* res; int64_t ldr; int64_t r_bs; int res_mod;  // fp32 residual, row index m % res_mod if res_mod>0
   int act;                                      // 0 none, 1 exact GELU
   int M, N, K;
-  int tiles_m, tiles_n;                         // filled by the launcher
+  int tiles_m, tiles_n, persistent;             // filled by the launcher
+  WH_PROBE_FIELD
 };
 hipError_t launch_gemm(const GemmArgs& a, int dtype, int out_f32, int batch, hipStream_t stream);
 
@@ -76,10 +77,11 @@ struct AttnArgs {
 };
 // generic (any Tq/Tk, VALU) attention, used for fp32 parity mode and decoder prefill
 hipError_t launch_attn_generic(const AttnArgs& a, int batch, int dtype, hipStream_t stream);
-// MFMA flash attention for the encoder (fp16 only): q,k [B][T][..] rows, vt = V transposed [B][H*64][ldv]
+// MFMA flash attention for the encoder (fp16 only): q,k [B][T][..] rows, vt = V transposed [B][H*64][ldv];
+// prescaled: q and k each carry sqrt(0.125 * log2 e) already (WH_WEIGHTS_ENC_QK_SCALED)
 hipError_t launch_attn_flash_f16(const void* q, int64_t q_ld, int64_t q_bs, const void* k, int64_t k_ld,
                                  int64_t k_bs, const void* vt, int64_t vt_ld, int64_t vt_bs, void* out,
-                                 int64_t o_ld, int64_t o_bs, int B, int H, int T, hipStream_t stream);
+                                 int64_t o_ld, int64_t o_bs, int B, int H, int T, int prescaled, hipStream_t stream);
 // single-query decode attention with split-K partials
 struct DecAttnArgs {
   const void* q; int64_t q_ld;                    // [R][H*64]

@@ -18,6 +18,9 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwhisper
 WH_F32, WH_F16 = 0, 1
 WH_TASK_CAPTURE_Q = 1
 WH_WEIGHTS_DEC_LN_FOLDED = 1
+WH_WEIGHTS_ENC_QK_SCALED = 2
+# sqrt(0.125 * log2 e): with it in both the query and the key projection, K.Q^T is the exp2 argument of the softmax
+ENC_QK_SCALE = (0.125 * 1.4426950408889634) ** 0.5
 MEL_SCRATCH_BYTES = 2048
 
 
@@ -168,10 +171,15 @@ def _fold_ln(w: torch.Tensor, b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.T
     return wf * ln_w.float().to(wf.device)[None, :], b.float().to(wf.device) + wf @ ln_b.float().to(wf.device)
 
 
-def _block_pieces(sd: Dict[str, torch.Tensor], prefix: str, cross: bool, D: int, fold: bool = False):
+def _block_pieces(sd: Dict[str, torch.Tensor], prefix: str, cross: bool, D: int, fold: bool = False,
+                  qk_scale: float = 1.0):
     """yield (field, tensor, is_matrix) for one ResidualAttentionBlock (whisper/model.py:142-171).
     fold (decoder blocks of the fp16 engine): the three LayerNorms' weight / bias are folded into the projection
-    that consumes them and replaced by (1, 0) — WH_WEIGHTS_DEC_LN_FOLDED in include/whisper_hip.h."""
+    that consumes them and replaced by (1, 0) — WH_WEIGHTS_DEC_LN_FOLDED in include/whisper_hip.h.
+    qk_scale (encoder blocks of the fp16 engine): the self-attention query and key projections (weight rows and the
+    query bias; the key has none) are multiplied by it — WH_WEIGHTS_ENC_QK_SCALED.  whisper/model.py:118-121 scales
+    q and k by n_state_head ** -0.25 each; here both carry sqrt(0.125 * log2 e) instead and the attention kernel
+    exponentiates K.Q^T with v_exp_f32 (base 2) directly."""
     z = torch.zeros(D, dtype=torch.float32)
     g = lambda k: sd[prefix + k]
     one = lambda: torch.ones(D, dtype=torch.float32)
@@ -179,6 +187,11 @@ def _block_pieces(sd: Dict[str, torch.Tensor], prefix: str, cross: bool, D: int,
     qkv_b = torch.cat([g("attn.query.bias").float().cpu(), z, g("attn.value.bias").float().cpu()], 0)
     if fold:
         qkv_w, qkv_b = _fold_ln(qkv_w, qkv_b, g("attn_ln.weight"), g("attn_ln.bias"))
+    if qk_scale != 1.0:
+        qkv_w = qkv_w.float().clone()
+        qkv_w[: 2 * D] *= qk_scale
+        qkv_b = qkv_b.clone()
+        qkv_b[: 2 * D] *= qk_scale
     yield "attn_ln_w", one() if fold else g("attn_ln.weight"), False
     yield "attn_ln_b", z if fold else g("attn_ln.bias"), False
     yield "qkv_w", qkv_w, True
@@ -216,6 +229,12 @@ def _conv_as_gemm(w: torch.Tensor, k_pad: int) -> torch.Tensor:
     return out
 
 
+def scales_encoder_qk(dtype: int) -> bool:
+    """fp16 blobs carry ENC_QK_SCALE in the encoder's query / key projections (the MFMA flash-attention kernel is the
+    only reader of those activations); the fp32 strict-parity engine keeps the reference's operation order."""
+    return dtype == WH_F16
+
+
 def folds_decoder_ln(dtype: int) -> bool:
     """The fp16 engine's blobs carry the decoder LayerNorm affine parameters folded into the projections (the decode
     GEMV then normalises its x fragments in registers without touching gamma / beta); the fp32 strict-parity engine
@@ -223,7 +242,8 @@ def folds_decoder_ln(dtype: int) -> bool:
     return dtype == WH_F16
 
 
-def model_pieces(sd: Dict[str, torch.Tensor], dims, fold_dec_ln: bool = False) -> List[Tuple[str, torch.Tensor, bool]]:
+def model_pieces(sd: Dict[str, torch.Tensor], dims, fold_dec_ln: bool = False,
+                 scale_enc_qk: bool = False) -> List[Tuple[str, torch.Tensor, bool]]:
     D = dims.n_audio_state
     kc1 = _align(3 * dims.n_mels, 64)
     out = [
@@ -240,7 +260,7 @@ def model_pieces(sd: Dict[str, torch.Tensor], dims, fold_dec_ln: bool = False) -
         ("dec_ln_b", sd["decoder.ln.bias"], False),
     ]
     for i in range(dims.n_audio_layer):
-        for f, t, mat in _block_pieces(sd, f"encoder.blocks.{i}.", False, D):
+        for f, t, mat in _block_pieces(sd, f"encoder.blocks.{i}.", False, D, qk_scale=ENC_QK_SCALE if scale_enc_qk else 1.0):
             out.append((f"enc.{i}.{f}", t, mat))
     for i in range(dims.n_text_layer):
         for f, t, mat in _block_pieces(sd, f"decoder.blocks.{i}.", True, dims.n_text_state, fold=fold_dec_ln):
@@ -292,7 +312,7 @@ def pack_weights(sd: Dict[str, torch.Tensor], dims, dtype: int, device: torch.de
     layout, total = blob_layout(dims, dtype)
     blob = torch.zeros(total, dtype=torch.uint8, device=device)
     tdt = torch.float16 if dtype == WH_F16 else torch.float32
-    for name, t, mat in model_pieces(sd, dims, fold_dec_ln=folds_decoder_ln(dtype)):
+    for name, t, mat in model_pieces(sd, dims, fold_dec_ln=folds_decoder_ln(dtype), scale_enc_qk=scales_encoder_qk(dtype)):
         off, shape, mat2 = layout[name]
         assert mat == mat2 and tuple(t.shape) == tuple(shape), (name, t.shape, shape)
         dt = tdt if mat else torch.float32
@@ -328,7 +348,8 @@ class HipModel:
             setattr(w, f, addr(f))
         w.enc_layers = C.cast(self._enc, C.POINTER(LayerWeights))
         w.dec_layers = C.cast(self._dec, C.POINTER(LayerWeights))
-        w.flags = WH_WEIGHTS_DEC_LN_FOLDED if folds_decoder_ln(dtype) else 0
+        w.flags = (WH_WEIGHTS_DEC_LN_FOLDED if folds_decoder_ln(dtype) else 0) | (
+            WH_WEIGHTS_ENC_QK_SCALED if scales_encoder_qk(dtype) else 0)
         d = Dims(*[getattr(dims, n) for n, _ in Dims._fields_])
         h = C.c_void_p()
         check(lib().wh_model_create(C.byref(d), dtype, C.byref(w), C.byref(h)), "wh_model_create")
