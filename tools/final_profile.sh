@@ -12,3 +12,12 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w -- python $R/bench
 W=$(find /tmp/prof_w -name "*_results.db" | head -n 1); python $R/tools/prof_summary.py $W --pmc --csv $O/pmc_write_size.csv > $O/pmc_w.txt 2>&1
 python $R/tools/pmc_traffic.py $O/pmc_fetch_size.csv $O/pmc_write_size.csv $O/pmc_traffic.json
 tail -n 2 $O/smoke.log; tail -n 1 $O/bench.out | cut -c1-400; ls -la $O
+# encoder GEMM / flash-attention probe (same box, same run): general kernel, rows kernel, K-loop floor, phase stamps
+if [ -x $R/tools/probe_gemm ]; then
+  { echo "== general kernel only (WH_GEMM_DEV=1)"; WH_GEMM_DEV=1 timeout 90 $R/tools/probe_gemm;
+    echo "== rows kernel, one tile per workgroup (WH_GEMM_DEV=4)"; WH_GEMM_DEV=4 timeout 90 $R/tools/probe_gemm | head -n 3;
+    echo "== product dispatch"; timeout 90 $R/tools/probe_gemm;
+    [ -x $R/tools/probe_gemm_ne ] && { echo "== rows kernel, epilogue compiled out (-DWH_GEMM_PROBE_NOEPI)"; timeout 90 $R/tools/probe_gemm_ne | head -n 3; }
+    [ -x $R/tools/probe_gemm_p ] && { echo "== phase stamps (-DWH_PROBE): 1 first K tile landed, 2 K loop done, 3 ring free, 5 stores issued, 7 next tile's first K tile landed"; timeout 90 $R/tools/probe_gemm_p | head -n 6; }
+  } > $O/probe_gemm.txt 2>&1
+fi
