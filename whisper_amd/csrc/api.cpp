@@ -263,8 +263,10 @@ struct wh_task {
   int B, G, R, Tmax, flags;
   int pos;                 // host mirror of *d_pos
   bool audio_set;
-  int steps_eager;         // decode steps launched without a graph (first one warms up attributes)
-  hipGraph_t graph; hipGraphExec_t graph_exec;
+  // the decode step exists in two captured forms: [0] starts with the token embedding of `step_tokens` (host-driven
+  // steps, beam search), [1] starts at layer 0 because the greedy sampler of the previous step already wrote x
+  int steps_eager[2];      // decode steps launched without a graph (first one warms up attributes)
+  hipGraph_t graph[2]; hipGraphExec_t graph_exec[2];
   // device buffers (carved from the caller's workspace)
   void* cross_kv;          // [L][B*Ta][2D]
   void* self_k; void* self_v;   // [L][R][n_ctx][D]
@@ -384,8 +386,10 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
 
 extern "C" void wh_task_destroy(wh_task* t) {
   if (!t) return;
-  if (t->graph_exec) (void)hipGraphExecDestroy(t->graph_exec);
-  if (t->graph) (void)hipGraphDestroy(t->graph);
+  for (int i = 0; i < 2; ++i) {
+    if (t->graph_exec[i]) (void)hipGraphExecDestroy(t->graph_exec[i]);
+    if (t->graph[i]) (void)hipGraphDestroy(t->graph[i]);
+  }
   free(t->h_lag);
   delete t;
 }
@@ -619,13 +623,14 @@ extern "C" int wh_task_prefill(wh_task* t, const int64_t* tokens, int64_t token_
 }
 
 // ---- one decode step (all kernels read the position from *d_pos: graph-replayable) ---------------
-static int step_launch(wh_task* t, hipStream_t s) {
+static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
   const wh_model* m = t->m;
   const wh_dims& d = m->d;
   const int D = d.n_text_state, H = d.n_text_head, C = d.n_text_ctx, Ta = d.n_audio_ctx, V = d.n_vocab;
   const int R = t->R;
   const size_t es = m->esize;
-  HIPCHK(launch_embed(t->step_tokens, 1, R, 1, m->w.tok_emb, m->w.dec_pos, t->d_pos, t->d_lag, D, V, t->x, m->dtype, s));
+  if (!embedded)
+    HIPCHK(launch_embed(t->step_tokens, 1, R, 1, m->w.tok_emb, m->w.dec_pos, t->d_pos, t->d_lag, D, V, t->x, m->dtype, s));
   for (int l = 0; l < d.n_text_layer; ++l) {
     const wh_layer_weights& L = m->dec[l];
     GemvArgs g;
@@ -710,24 +715,25 @@ static bool graphs_enabled() {
 }
 
 // runs one step from t->step_tokens into t->logits
-static int step_run(wh_task* t, hipStream_t s) {
+static int step_run(wh_task* t, hipStream_t s, bool embedded = false) {
   if (t->pos <= 0) return WH_ERR_STATE;
   if (t->pos + 1 > t->m->d.n_text_ctx) return WH_ERR_ARG;
   int rc;
-  if (t->graph_exec) {
-    HIPCHK(hipGraphLaunch(t->graph_exec, s));
-  } else if (s == nullptr || !graphs_enabled() || t->steps_eager < 1) {
-    rc = step_launch(t, s);
+  const int gi = embedded ? 1 : 0;
+  if (t->graph_exec[gi]) {
+    HIPCHK(hipGraphLaunch(t->graph_exec[gi], s));
+  } else if (s == nullptr || !graphs_enabled() || t->steps_eager[gi] < 1) {
+    rc = step_launch(t, s, embedded);
     if (rc != WH_OK) return rc;
-    t->steps_eager++;
+    t->steps_eager[gi]++;
   } else {
     HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    rc = step_launch(t, s);
-    hipError_t e = hipStreamEndCapture(s, &t->graph);
+    rc = step_launch(t, s, embedded);
+    hipError_t e = hipStreamEndCapture(s, &t->graph[gi]);
     if (rc != WH_OK) return rc;
     HIPCHK(e);
-    HIPCHK(hipGraphInstantiate(&t->graph_exec, t->graph, nullptr, nullptr, 0));
-    HIPCHK(hipGraphLaunch(t->graph_exec, s));
+    HIPCHK(hipGraphInstantiate(&t->graph_exec[gi], t->graph[gi], nullptr, nullptr, 0));
+    HIPCHK(hipGraphLaunch(t->graph_exec[gi], s));
   }
   t->pos += 1;
   return WH_OK;
@@ -813,6 +819,12 @@ extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* to
   sa.max_initial_ts = p->max_initial_timestamp_index; sa.suppress_blank = p->suppress_blank;
   sa.blank_token = p->blank_token; sa.suppress_mask = p->suppress_mask; sa.sum_logprobs = sum_logprobs;
   sa.step_tokens = t->step_tokens; sa.d_alive_step = t->d_alive; sa.partials = t->samp_part;
+  // the sampler also writes the next step's input row (token embedding + position): the step graph starts at layer 0
+  static const bool fused_embed = [] { const char* e = getenv("WH_NO_FUSED_EMBED"); return !(e && e[0] == '1'); }();   // A/B switch
+  if (fused_embed) {
+    sa.x_next = t->x; sa.tok_emb = t->m->w.tok_emb; sa.pos_emb = t->m->w.dec_pos; sa.D = d.n_text_state;
+    sa.emb_f16 = t->m->dtype == WH_F16 ? 1 : 0; sa.n_pos = d.n_text_ctx;
+  }
   if (p->temperature > 0.f) {
     sa.inv_temperature = 1.0f / p->temperature;
     sa.seed_lo = (uint32_t)(p->seed & 0xffffffffu); sa.seed_hi = (uint32_t)(p->seed >> 32);
@@ -824,7 +836,7 @@ extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* to
   sa.logits = t->logits; sa.logits_ld = V;
   bool done = false;
   while (steps < p->max_steps && ntok <= p->n_ctx && ntok <= d.n_text_ctx) {
-    rc = step_run(t, s);
+    rc = step_run(t, s, fused_embed);
     if (rc != WH_OK) return rc;
     HIPCHK(launch_greedy_sample(sa, s));
     ++ntok; ++steps;

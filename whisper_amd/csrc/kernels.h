@@ -150,6 +150,9 @@ struct SampleArgs {
   float* partials;            // scratch: greedy_sample_scratch_bytes(R, V)
   float inv_temperature;      // 0: arg-max; > 0: sample from softmax(logits / T) (Gumbel-max, counter-based noise)
   uint32_t seed_lo, seed_hi;
+  // optional: the final kernel also writes the next step's decoder input x_next[r][:] = tok_emb[token] + pos_emb[index of
+  // the token] (model.py:236-240), so the step that follows needs no embedding launch; skipped when x_next is null
+  float* x_next; const void* tok_emb; const float* pos_emb; int D, emb_f16, n_pos;
 };
 size_t greedy_sample_scratch_bytes(int R, int V);
 hipError_t launch_greedy_sample(const SampleArgs& a, hipStream_t stream);

@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void greedy_final_kernel(whk::SampleArgs a, in
   __shared__ float sh_m[2][4], sh_s[2][4];
   __shared__ int sh_i[2][4];
   __shared__ float sh_k[2][4], sh_x[2][4];
+  __shared__ int sh_next;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k = blockIdx.x;
   const int vl = load_agent_int(a.lag ? a.lag + k : a.d_ntok), vn = load_agent_int(a.d_ntok);
@@ -275,6 +276,24 @@ __global__ __launch_bounds__(256) void greedy_final_kernel(whk::SampleArgs a, in
     row[ntok] = next;
     if (a.step_tokens) a.step_tokens[k] = next;
     if (next != a.eot) *a.d_alive_step = ntok + lag;      // benign race: every writer stores the same value
+    sh_next = next;
+  }
+  if (a.x_next) {                             // the next step's input row: embedding of the token just chosen, at its index
+    __syncthreads();
+    int tok = sh_next;
+    if (tok < 0) tok = 0;
+    if (tok > a.V - 1) tok = a.V - 1;
+    if (ntok < a.n_pos) {
+      const float* pp = a.pos_emb + (int64_t)ntok * a.D;
+      float* xr = a.x_next + (int64_t)k * a.D;
+      if (a.emb_f16) {
+        const half_t* e = (const half_t*)a.tok_emb + (int64_t)tok * a.D;
+        for (int dd = tid; dd < a.D; dd += 256) xr[dd] = (float)e[dd] + pp[dd];
+      } else {
+        const float* e = (const float*)a.tok_emb + (int64_t)tok * a.D;
+        for (int dd = tid; dd < a.D; dd += 256) xr[dd] = e[dd] + pp[dd];
+      }
+    }
   }
 }
 
