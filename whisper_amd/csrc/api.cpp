@@ -269,6 +269,8 @@ struct wh_task {
   hipGraph_t graph[2]; hipGraphExec_t graph_exec[2];
   // device buffers (carved from the caller's workspace)
   void* cross_kv;          // [L][B*Ta][2D]
+  void* cross_vt;          // beam groups, fp16: [L][B][D][vt_ld], V transposed (row = head dim, column = key) for the
+  int vt_ld;               //   matrix-core group attention; vt_ld = splits x the kernel's rounded key chunk >= Ta
   void* self_k; void* self_v;   // [L][R][n_ctx][D]
   void* spare_k; void* spare_v; // beam reorder staging (G > 1)
   float* x; void* xn; void* qkv; void* att; void* h; void* qbuf;
@@ -321,6 +323,13 @@ static void task_carve(wh_task* t, void* base) {
   const size_t R = t->R, Mx = (size_t)t->R * t->Tmax, V = d.n_vocab, H = d.n_text_head;
   Carver c(base);
   t->cross_kv = c.take(L * t->B * Ta * 2 * D * es);
+  t->cross_vt = nullptr; t->vt_ld = 0;
+  if (t->G > 1 && m->dtype == WH_F16) {
+    const int S = pick_splits(t->R, d.n_text_head, d.n_audio_ctx, m->dtype);
+    const int chunk = (((int)Ta + S - 1) / S + 127) / 128 * 128;       // attn_decode_group_mfma_kernel's key chunk
+    t->vt_ld = S * chunk;
+    t->cross_vt = c.take(L * t->B * D * (size_t)t->vt_ld * es);
+  }
   t->self_k = c.take(L * R * C * D * es);
   t->self_v = c.take(L * R * C * D * es);
   t->spare_k = t->G > 1 ? c.take(R * C * D * es) : nullptr;
@@ -451,6 +460,21 @@ extern "C" int wh_task_set_audio(wh_task* t, const void* features, void* stream_
     const wh_layer_weights& L = m->dec[l];
     void* C = (char*)t->cross_kv + (size_t)l * M * 2 * D * es;
     HIPCHK(gemm(m, features, D, L.ckv_w, D, C, 2 * D, M, 2 * D, L.ckv_b, 0, nullptr, 0, false, s));
+  }
+  if (t->cross_vt) {
+    // V^T = W_v . X^T per audio (bias along rows), as in the encoder; the pad columns [Ta, vt_ld) only have to be finite
+    const size_t rows = (size_t)d.n_text_layer * t->B * D;
+    HIPCHK(hipMemset2DAsync((char*)t->cross_vt + (size_t)Ta * es, (size_t)t->vt_ld * es, 0, (size_t)(t->vt_ld - Ta) * es, rows, s));
+    for (int l = 0; l < d.n_text_layer; ++l) {
+      const wh_layer_weights& L = m->dec[l];
+      GemmArgs g; memset(&g, 0, sizeof(g));
+      g.A = (const char*)L.ckv_w + (size_t)D * D * es; g.lda = D; g.a_bs = 0;
+      g.W = features; g.ldw = D; g.w_bs = (int64_t)Ta * D;
+      g.C = (char*)t->cross_vt + (size_t)l * t->B * D * t->vt_ld * es; g.ldc = t->vt_ld; g.c_bs = (int64_t)D * t->vt_ld;
+      g.bias = L.ckv_b + D; g.bias_on_m = 1;
+      g.M = D; g.N = Ta; g.K = D;
+      HIPCHK(launch_gemm(g, m->dtype, 0, t->B, s));
+    }
   }
   t->audio_set = true;
   return WH_OK;
@@ -674,6 +698,9 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
       a.v = (char*)cross_layer(t, l) + (size_t)D * es; a.v_ld = 2 * D; a.v_bs = a.k_bs;
       a.H = H; a.R = R; a.kv_group = t->G; a.Tk = Ta; a.splits = t->cross_splits;
       a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
+      if (t->cross_vt) {
+        a.vt = (char*)t->cross_vt + (size_t)l * t->B * D * t->vt_ld * es; a.vt_ld = t->vt_ld; a.vt_bs = (int64_t)D * t->vt_ld;
+      }
       HIPCHK(launch_attn_decode(a, m->dtype, s));
     }
     memset(&g, 0, sizeof(g));

@@ -13,6 +13,7 @@
 //   cross_qk         raw scaled QK^T of chosen heads for word timestamps (whisper/timing.py:186-208)
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -650,6 +651,145 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_group_kernel(whk::DecA
 }
 
 // =============================================================================================
+// The same on the matrix cores (fp16).  With G beams against one K/V tile the vector-ALU form above does G dot
+// products, G softmax passes and G p.v accumulations per key — 24 us per launch at 40 rows against 11.7 us for the
+// 8-row greedy kernel that streams the same bytes.  Here the beams are the N dimension of v_mfma_f32_16x16x32_f16
+// (G <= 8 of 16 columns used):
+//   S[key][beam]   = K[key][:] . q[beam][:]     A = K rows as loaded (16 B per lane = 8 head dims of one key),
+//                                               B = q (8 head dims of one beam)
+//   O^T[d][beam]   = V^T[d][keys] . P^T[keys][beam]   A = V^T rows (16 B per lane = 8 KEYS of one head dim),
+//                                               B = P straight from the S accumulators: no LDS, no permute
+// The second product needs 8 consecutive keys per lane, the first hands a lane 4 consecutive ROWS of each 16-row
+// tile, so the two tiles of a 32-key block take the keys {0-3, 8-11, 16-19, 24-27} and {4-7, 12-15, 20-23, 28-31}:
+// lane (beam, g) then owns keys 8g..8g+7 of the block, which is exactly the B fragment of the second product (a
+// key row is its own 128-byte line either way, so the permutation costs nothing in the loads).  V^T comes from a
+// GEMM with swapped operands at set_audio (as in the encoder).  Everything a workgroup needs is requested up front:
+// one HBM round trip, as in the kernels above.  4 waves x NBLK blocks of 32 keys per (split, head, audio).
+// =============================================================================================
+template <int NBLK, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attn_decode_group_mfma_kernel(whk::DecAttnArgs a) {
+  pin_kernargs(a);
+  __shared__ float red_o[WAVES][16][64];
+  __shared__ float red_m[WAVES][16], red_l[WAVES][16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int S = a.splits, G = a.kv_group, Tk = a.Tk;
+  int chunk = (Tk + S - 1) / S;
+  chunk = (chunk + 127) / 128 * 128;                                  // (<= NBLK * WAVES * 32 keys: launcher)
+  const int k0 = s * chunk;
+  int k1 = k0 + chunk; if (k1 > Tk) k1 = Tk;
+  const int nkeys = k1 > k0 ? k1 - k0 : 0;
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int64_t hs = a.kv_hs ? a.kv_hs : 64;
+
+  // q: B operand of the first product, lane (beam, g) holds head dims 32 ks + 8 g .. + 7, pre-scaled (exact in fp16)
+  half8v qf[2];
+  {
+    const half_t* qp = (const half_t*)a.q + (int64_t)(b * G + (i16 < G ? i16 : G - 1)) * a.q_ld + h * 64 + g4 * 8;
+    qf[0] = scale_q(*(const half8v*)qp);
+    qf[1] = scale_q(*(const half8v*)(qp + 32));
+  }
+  asm volatile("" ::: "memory");
+  const half_t* kp = (const half_t*)a.k + (int64_t)b * a.k_bs + h * hs + g4 * 8;
+  const half_t* vp = (const half_t*)a.vt + (int64_t)b * a.vt_bs + (int64_t)(h * 64 + i16) * a.vt_ld + g4 * 8;
+  const int klast = nkeys > 0 ? k1 - 1 : 0;
+  const uint32_t ldk = (uint32_t)a.k_ld;
+  half8v kf[NBLK][2][2], vf[NBLK][4];
+#pragma unroll
+  for (int j = 0; j < NBLK; ++j) {
+    const int kb = k0 + (wave * NBLK + j) * 32;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      int key = kb + 8 * (i16 >> 2) + 4 * t + (i16 & 3);
+      if (key > klast) key = klast;                                   // masked below; the load stays in bounds
+      const half_t* kr = kp + (uint32_t)key * ldk;
+      kf[j][t][0] = __builtin_nontemporal_load((const half8v*)kr);
+      kf[j][t][1] = __builtin_nontemporal_load((const half8v*)(kr + 32));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NBLK; ++j) {
+    const int kb = k0 + (wave * NBLK + j) * 32;                          // < vt_ld: the rows are padded to S * chunk keys
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      vf[j][dt] = __builtin_nontemporal_load((const half8v*)(vp + (int64_t)(dt * 16) * a.vt_ld + kb));
+  }
+  // every request goes out before the first use: left alone, the scheduler hoists the first MFMAs (and the waits for
+  // their operands) in between the loads to save registers — several dependent round trips instead of one
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- scores: lane (beam, g) ends with keys kb + 8 g + {0..3} (tile 0) and + {4..7} (tile 1)
+  float4v sc[NBLK][2];
+  float mx = WH_NEG_INF;
+#pragma unroll
+  for (int j = 0; j < NBLK; ++j) {
+    const int kb = k0 + (wave * NBLK + j) * 32;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float4v c = {0.f, 0.f, 0.f, 0.f};
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[j][t][0], qf[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[j][t][1], qf[1], c, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (kb + 8 * g4 + 4 * t + e >= k1) c[e] = WH_NEG_INF;
+        mx = fmaxf(mx, c[e]);
+      }
+      sc[j][t] = c;
+    }
+  }
+  mx = across_groups16_max(mx);                                       // over g: this wave's keys, per beam
+  if (g4 == 0) red_m[wave][i16] = mx;
+  __syncthreads();
+  float M = red_m[0][i16];
+#pragma unroll
+  for (int w = 1; w < WAVES; ++w) M = fmaxf(M, red_m[w][i16]);
+
+  // ---- p = exp(s - M), row sums, and the second product with P taken from the accumulators as they are
+  float4v oacc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) oacc[dt] = float4v{0.f, 0.f, 0.f, 0.f};
+  float lsum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NBLK; ++j) {
+    half8v pf;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = (sc[j][t][e] == WH_NEG_INF) ? 0.f : __expf(sc[j][t][e] - M);
+        lsum += p;
+        pf[4 * t + e] = (half_t)p;
+      }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[j][dt], pf, oacc[dt], 0, 0, 0);
+  }
+  lsum = across_groups16_sum(lsum);
+  if (g4 == 0) red_l[wave][i16] = lsum;
+  // O^T[d][beam]: lane (beam, g) holds d = 16 dt + 4 g + e
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) *(float4v*)&red_o[wave][i16][dt * 16 + g4 * 4] = oacc[dt];
+  __syncthreads();
+  for (int t = tid; t < G * 64; t += WAVES * 64) {
+    const int g = t >> 6, d = t & 63;
+    float o = red_o[0][g][d], l = red_l[0][g], m = red_m[0][g];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) { o += red_o[w][g][d]; l += red_l[w][g]; m = fmaxf(m, red_m[w][g]); }
+    const int r = b * G + g;
+    if (S == 1) {
+      ((half_t*)a.out)[(int64_t)r * a.o_ld + h * 64 + d] = (half_t)(o / l);
+    } else {
+      const int64_t pi = ((int64_t)s * a.R + r) * a.H + h;
+      ((half_t*)a.part_o)[pi * 64 + d] = (half_t)(nkeys > 0 ? o / l : 0.f);
+      if (d == 0) {
+        a.part_ml[pi * 2 + 0] = nkeys > 0 ? m : WH_NEG_INF;
+        a.part_ml[pi * 2 + 1] = nkeys > 0 ? l : 0.f;
+      }
+    }
+  }
+}
+
+// =============================================================================================
 // cross QK capture
 // =============================================================================================
 template <typename T>
@@ -744,6 +884,17 @@ static hipError_t launch_attn_decode_t(const DecAttnArgs& a, hipStream_t stream)
     return hipGetLastError();
   }
   const int chunk = (a.Tk + a.splits - 1) / a.splits;
+  if constexpr (sizeof(T) == 2) {
+    static const bool no_mfma = [] { const char* e = getenv("WH_GROUP_ATTN_VALU"); return e && e[0] == '1'; }();   // A/B switch
+    if (a.vt && !no_mfma && a.kv_group > 1 && a.kv_group <= 8 && a.R % a.kv_group == 0 && chunk <= 512 &&
+        (int64_t)a.splits * ((chunk + 127) / 128 * 128) <= a.vt_ld) {
+      dim3 ggrid(a.splits, a.H, a.R / a.kv_group);
+      // 8 waves x 2 blocks and 4 waves x 4 blocks of 32 keys measured the same (232.8 vs 233.0 ms per 64-step beam pass)
+      if ((chunk + 127) / 128 <= 1) hipLaunchKernelGGL((attn_decode_group_mfma_kernel<1, 8>), ggrid, dim3(512), 0, stream, a);
+      else hipLaunchKernelGGL((attn_decode_group_mfma_kernel<2, 8>), ggrid, dim3(512), 0, stream, a);
+      return hipGetLastError();
+    }
+  }
   if (a.kv_group > 1 && a.kv_group <= 8 && a.R % a.kv_group == 0 && chunk <= 8 * 8 * KPW) {
     // beam groups: one workgroup per (split, head, audio) scores all beams against one K/V tile
     dim3 ggrid(a.splits, a.H, a.R / a.kv_group), gblock(8 * 64);

@@ -94,6 +94,9 @@ struct DecAttnArgs {
   int splits;                                     // key-range splits
   void* out; int64_t o_ld;                        // splits==1: normalized output, element type
   void* part_o; float* part_ml;                   // splits>1: [S][R][H][64] element type, normalised (o / l); (m, l) fp32 [S][R][H][2]
+  // beam groups, fp16: V transposed per audio, row h*64+d holds the keys of head dim d (row stride vt_ld >= the
+  // padded key count, pad columns finite).  With it the group kernel runs on the matrix cores; null: vector ALU form
+  const void* vt; int64_t vt_ld; int64_t vt_bs;
   WH_PROBE_FIELD
 };
 constexpr int DEC_ATTN_MAX_SPLITS = 16;
