@@ -280,6 +280,8 @@ struct wh_task {
   int* d_pos; int* d_alive; int* d_sel; int* d_src;
   int* d_lag;              // [R] ragged prompts: row r is lag[r] tokens shorter than the longest row (zeros otherwise)
   int* h_lag;              // host copy
+  int* h_poll;             // pinned host word the fused loops copy the completion counter into
+  hipEvent_t poll_event;   // recorded behind that copy: the loop waits for it two steps later, with work already queued
   bool lag_on;
   bool needs_reset;        // created, position counter / lag not zeroed yet
   std::atomic<int> busy;   // handles are not thread-safe: a second thread entering while a call runs gets WH_ERR_STATE
@@ -400,6 +402,8 @@ extern "C" void wh_task_destroy(wh_task* t) {
     if (t->graph[i]) (void)hipGraphDestroy(t->graph[i]);
   }
   free(t->h_lag);
+  if (t->h_poll) (void)hipHostFree(t->h_poll);
+  if (t->poll_event) (void)hipEventDestroy(t->poll_event);
   delete t;
 }
 
@@ -862,21 +866,33 @@ extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* to
   int ntok = T0 + 1, steps = 1, alive = T0;
   sa.logits = t->logits; sa.logits_ld = V;
   bool done = false;
+  // Completion is polled every 8 tokens WITHOUT draining the queue: the counter is copied to pinned memory behind step
+  // k, an event is recorded, two more steps are queued, and only then does the host wait for the event — the GPU is
+  // two steps behind the host at that point and never idles for a launch.  At most two steps run past completion.
+  if (!t->h_poll) HIPCHK(hipHostMalloc((void**)&t->h_poll, ((size_t)t->B + 16) * 4, hipHostMallocDefault));
+  if (!t->poll_event) HIPCHK(hipEventCreateWithFlags(&t->poll_event, hipEventDisableTiming));
+  bool pending = false;
+  int ntok_at_copy = 0;
   while (steps < p->max_steps && ntok <= p->n_ctx && ntok <= d.n_text_ctx) {
     rc = step_run(t, s, fused_embed);
     if (rc != WH_OK) return rc;
     HIPCHK(launch_greedy_sample(sa, s));
     ++ntok; ++steps;
+    if (pending && (steps & 7) == 2) {
+      HIPCHK(hipEventSynchronize(t->poll_event));
+      pending = false;
+      if (*t->h_poll < ntok_at_copy - 1) { done = true; break; }
+    }
     if ((steps & 7) == 0) {
-      HIPCHK(hipMemcpyAsync(&alive, t->d_alive, 4, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
-      if (alive < ntok - 1) { done = true; break; }
+      HIPCHK(hipMemcpyAsync(t->h_poll, t->d_alive, 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipEventRecord(t->poll_event, s));
+      pending = true; ntok_at_copy = ntok;
     }
   }
-  if (!done) {
-    HIPCHK(hipMemcpyAsync(&alive, t->d_alive, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-  }
+  HIPCHK(hipMemcpyAsync(t->h_poll, t->d_alive, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  alive = *t->h_poll;
+  (void)done;
   // the sampler that appended token index c ran with ntok == c; "completed" first holds at c = alive + 1
   int final_len = alive + 2;
   if (final_len > ntok) final_len = ntok;
@@ -948,24 +964,29 @@ extern "C" int wh_task_beam(wh_task* t, const wh_beam_params* bp, int64_t* token
   rc = update(t->logits + (size_t)(n_sel - 1) * V, (int64_t)n_sel * V, 1);
   if (rc != WH_OK) return rc;
   int ntok = T0 + 1, steps = 1;
-  std::vector<int> flags((size_t)B);
-  auto all_done = [&]() -> int {       // 1 / 0, or -1 after a HIP error
-    hipError_t e = hipMemcpyAsync(flags.data(), done[cur], (size_t)B * 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { g_last_hip = e; return -1; }
-    for (int b = 0; b < B; ++b) if (!flags[b]) return 0;
-    return 1;
-  };
+  // completion flags are polled every 8 steps without draining the queue (see wh_task_greedy): snapshot behind step k,
+  // wait for it two steps later.  Once every segment is done an update leaves the state untouched, so the extra steps
+  // change nothing.
+  if (!t->h_poll) HIPCHK(hipHostMalloc((void**)&t->h_poll, ((size_t)t->B + 16) * 4, hipHostMallocDefault));
+  if (!t->poll_event) HIPCHK(hipEventCreateWithFlags(&t->poll_event, hipEventDisableTiming));
+  bool pending = false;
   while (steps < p->max_steps && ntok <= p->n_ctx && ntok <= d.n_text_ctx) {
     rc = step_run(t, s);
     if (rc != WH_OK) return rc;
     rc = update(t->logits, V, 0);
     if (rc != WH_OK) return rc;
     ++ntok; ++steps;
-    if ((steps & 7) == 0) {
-      const int fin = all_done();
-      if (fin < 0) return WH_ERR_HIP;
+    if (pending && (steps & 7) == 2) {
+      HIPCHK(hipEventSynchronize(t->poll_event));
+      pending = false;
+      bool fin = true;
+      for (int b = 0; b < B; ++b) fin = fin && t->h_poll[b] != 0;
       if (fin) break;
+    }
+    if ((steps & 7) == 0) {
+      HIPCHK(hipMemcpyAsync(t->h_poll, done[cur], (size_t)B * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipEventRecord(t->poll_event, s));
+      pending = true;
     }
   }
   int applied = 0;
