@@ -34,10 +34,12 @@ def _feats(dims, B, seed):
 
 
 @pytest.mark.parametrize("dt,tol", [(hip.WH_F32, 1e-3), (hip.WH_F16, 6e-2)])
-@pytest.mark.parametrize("B,G,T0", [(8, 1, 3), (2, 5, 4), (1, 1, 9), (5, 1, 2), (8, 5, 3)])
+@pytest.mark.parametrize("B,G,T0", [(8, 1, 3), (2, 5, 4), (1, 1, 9), (5, 1, 2), (8, 5, 3), (17, 1, 2), (3, 7, 2), (48, 1, 2)])
 def test_wide_prefill_and_steps(wide, gpu_device, dt, tol, B, G, T0):
     """teacher-forced logits at every position: prefill (GEMM path) + 5 steps (GEMV path, hipGraph from the 2nd)
-    vs the oracle's KV-cache decoder.  fp32: |dlogit| < 1e-3 (north_star bar); fp16 engine: 6e-2."""
+    vs the oracle's KV-cache decoder.  fp32: |dlogit| < 1e-3 (north_star bar); fp16 engine: 6e-2.  Row counts: <= 8
+    (MFMA diagonal GEMV), 10 (16-row tiles), 17 / 21 / 40 / 48 (48-row LayerNorm projections + 16-row tiles for the rest;
+    40 = 8 x 5 also takes the matrix-core beam-group cross attention)."""
     dims, sd, om, models = wide
     model = models[dt]
     R = B * G

@@ -1146,6 +1146,172 @@ hipError_t launch_gemv8(const whk::GemvArgs& a, hipStream_t stream) {
   return hipErrorNotSupported;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 17..48 rows (beam search: 8 clips x 5 beams = 40) behind a LayerNorm: ALL rows in one workgroup.
+// The 16-row tiles above put three row blocks on grid.y, so every 16 output features are handled by three workgroups
+// that each repeat a LayerNorm prologue and re-read the weights: 960 workgroups for FC1, 3.75 rounds per CU,
+// 14.9 us.  Here a 16-wave workgroup normalises all 48 rows once (3 per wave, in registers, fp16 into a bank-swizzled
+// LDS tile of 48 x K <= 123 KB), then the waves split into NFT feature tiles x 16 / NFT slices of K and run
+// 3 MFMAs (row tiles) per weight fragment; partial sums meet in LDS (aliasing the x tile).  One workgroup per 16 or 32
+// features: a single round on 256 CUs.  LayerNorm affine parameters must be folded into W (WH_WEIGHTS_DEC_LN_FOLDED).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NFT>      // feature tiles of 16 per workgroup (1 or 2)
+__global__ __launch_bounds__(1024) void gemv_rows48_kernel(whk::GemvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  pin_kernargs(a);
+  constexpr int WAVES = 16, RT = 48, KSP = WAVES / NFT, J = 5, NU = (40 + KSP - 1) / KSP;   // K <= 1280: 40 steps of 32
+  const int K = a.K, nks = K / 32;
+  half_t* xs = (half_t*)smem;                                   // [48][K], 16-byte unit u of row r stored at u ^ (r & 15)
+  float* red = (float*)smem;                                    // [KSP][NFT][3][16 rows][16 features], after the MFMAs
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ft = wave % NFT, ksp = wave / NFT;
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int n0 = blockIdx.x * (NFT * 16);
+  const int R = a.R;
+
+  // ---- requests: the three fp32 rows of this wave first (L2), then its weight fragments (HBM)
+  float4v v[3][J];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int r = wave + WAVES * i;
+    const float* src = a.xf + (int64_t)(r < R ? r : 0) * a.xf_ld;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      int k = (j * 64 + lane) * 4; if (k > K - 4) k = K - 4;           // branch-free; masked at use
+      v[i][j] = *(const float4v*)(src + k);
+    }
+  }
+  ISSUE_FENCE();
+  half8v w[NU];
+  {
+    int n = n0 + ft * 16 + i16; if (n > a.N - 1) n = a.N - 1;
+    const half_t* base = (const half_t*)a.W + (int64_t)n * K + g4 * 8;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      int st = ksp + KSP * u; if (st > nks - 1) st = nks - 1;          // clamped: skipped below
+      w[u] = __builtin_nontemporal_load((const half8v*)(base + st * 32));
+    }
+  }
+  ISSUE_FENCE();
+  int e_pos = 0;
+  if (a.epi == whk::EPI_QKV) e_pos = load_agent_int(a.d_pos);
+  float e_bias[(NFT * 768 + 1023) / 1024];           // the bias of this thread's outputs, requested now
+#pragma unroll
+  for (int q = 0; q < (NFT * 768 + 1023) / 1024; ++q) {
+    const int o = tid + q * 1024;
+    int n = n0 + ((o >> 8) / 3) * 16 + (o & 15); if (n > a.N - 1) n = a.N - 1;
+    e_bias[q] = a.bias ? a.bias[n] : 0.f;
+  }
+
+  // ---- LayerNorm (two-pass, a wave owns whole rows), fp16 into the swizzled tile
+  {
+    const float invK = 1.0f / (float)K;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int r = wave + WAVES * i;
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const float t = (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
+        sum += ((j * 64 + lane) * 4 < K) ? t : 0.f;
+      }
+      const float mean = wave_sum(sum) * invK;
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        if ((j * 64 + lane) * 4 < K) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = v[i][j][e] - mean; ss = __builtin_fmaf(d, d, ss); }
+        }
+      }
+      const float rstd = r < R ? rsqrtf(wave_sum(ss) * invK + 1e-5f) : 0.f;     // rows beyond R become zeros
+      half_t* xr = xs + (size_t)r * K;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int k = (j * 64 + lane) * 4;
+        if (k < K)
+          Pack4<half_t>::store(xr + ((((k >> 3) ^ (r & 15)) << 3) | (k & 7)), (v[i][j][0] - mean) * rstd,
+                               (v[i][j][1] - mean) * rstd, (v[i][j][2] - mean) * rstd, (v[i][j][3] - mean) * rstd);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- out[feature][row] += W fragment . x fragments of the three row tiles
+  float4v acc[3];
+#pragma unroll
+  for (int rt = 0; rt < 3; ++rt) acc[rt] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int st = ksp + KSP * u;
+    if (st < nks) {
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt) {
+        const half8v xf = *(const half8v*)(xs + (size_t)(rt * 16 + i16) * K + (((st * 4 + g4) ^ i16) << 3));
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u], xf, acc[rt], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                                              // every wave is done with the x tile: `red` takes its place
+  // lane (row j = i16, feature group g4) holds features 4 g4 + e of row j
+#pragma unroll
+  for (int rt = 0; rt < 3; ++rt) *(float4v*)(red + ((((ksp * NFT + ft) * 3 + rt) * 16 + i16) * 16 + g4 * 4)) = acc[rt];
+  __syncthreads();
+
+  // ---- epilogue: NFT x 3 x 16 x 16 outputs over 1024 threads
+#pragma unroll
+  for (int q = 0; q < (NFT * 768 + 1023) / 1024; ++q) {
+    const int o = tid + q * 1024;
+    if (o >= NFT * 768) continue;
+    const int f = o & 15, j = (o >> 4) & 15, rt = (o >> 8) % 3, oft = (o >> 8) / 3;
+    const int row = rt * 16 + j, n = n0 + oft * 16 + f;
+    if (row >= R || n >= a.N) continue;
+    float val = e_bias[q];
+#pragma unroll
+    for (int k = 0; k < KSP; ++k) val += red[((((k * NFT + oft) * 3 + rt) * 16 + j) * 16) + f];
+    const int64_t rr = row;
+    switch (a.epi) {
+      case whk::EPI_STORE: ((half_t*)a.y)[rr * a.y_ld + n] = (half_t)val; break;
+      case whk::EPI_GELU: ((half_t*)a.y)[rr * a.y_ld + n] = (half_t)gelu_erf(val); break;
+      case whk::EPI_QKV: {
+        const int D = a.D;
+        if (n < D) ((half_t*)a.y)[rr * a.y_ld + n] = (half_t)val;
+        else {
+          const int64_t pos = e_pos - (a.lag ? a.lag[row] : 0);
+          if (n < 2 * D) ((half_t*)a.kcache)[rr * a.cache_bs + pos * D + (n - D)] = (half_t)val;
+          else ((half_t*)a.vcache)[rr * a.cache_bs + pos * D + (n - 2 * D)] = (half_t)val;
+        }
+      } break;
+      default: break;
+    }
+  }
+  if (a.bump && blockIdx.x == 0 && tid == 0) atomicAdd(a.bump, a.bump_by);
+}
+
+// applies to: fp16, LayerNorm prologue with folded affine part, 17..48 rows, K a multiple of 256 up to 1280,
+// store / GELU / QKV epilogues
+bool rows48_applies(const whk::GemvArgs& a) {
+  static const bool off = [] { const char* e = getenv("WH_NO_ROWS48"); return e && e[0] == '1'; }();   // A/B switch (tools)
+  // measured at 40 rows, large-v3 (rocprof, real beam step): FC1 14.9 -> 11.4 us, QKV 11.7 -> 11.4 us; the D x D
+  // cross-attention query got slower (7.9 -> 8.6 us: 80 workgroups each normalising all 48 rows), so N >= 2048 only
+  return !off && a.R > 16 && a.R <= 48 && a.pro == whk::PRO_LN && a.ln_folded && a.K % 256 == 0 && a.K <= 1280 &&
+         a.N >= 2048 && a.variant <= 0 && (a.epi == whk::EPI_STORE || a.epi == whk::EPI_GELU || a.epi == whk::EPI_QKV);
+}
+
+hipError_t launch_rows48(const whk::GemvArgs& a, hipStream_t stream) {
+  const size_t lds = (size_t)48 * a.K * 2 > 49152 ? (size_t)48 * a.K * 2 : 49152;     // x tile, later the partial sums
+  static bool attr2 = false;
+  if (!attr2) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemv_rows48_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr2 = true;
+  }
+  hipLaunchKernelGGL((gemv_rows48_kernel<2>), dim3((a.N + 31) / 32), dim3(1024), lds, stream, a);   // 32 features per workgroup
+  return hipGetLastError();
+}
+
 }  // namespace
 
 namespace whk {
@@ -1159,6 +1325,7 @@ hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream) {
     // the 24 / 48-row forms of gemv8 take 6.5 / 8.6 / 14.3 / 11.4 / 14.9 / 18.4 us (out, cq, cout, qkv, fc1, fc2) against
     // 4.8 / 7.9 / 11.2 / 14.9 / 11.7 / 11.3 us for the 16-row LDS-staged MFMA tiles below — those keep the job wherever
     // they apply; gemv8's row blocks serve the remaining shapes (row counts 9..96 outside the 16-row form's limits).
+    if (rows48_applies(a)) return launch_rows48(a, stream);
     const bool rows16 = a.R > 8 && a.variant <= 0 && a.K % 128 == 0 && a.K <= 5120 && (a.K / 32 <= 40 || a.pro == whk::PRO_PLAIN);
     if (a.R <= 96 && !rows16) {
       const hipError_t e = launch_gemv8(a, stream);
