@@ -1312,6 +1312,144 @@ hipError_t launch_rows48(const whk::GemvArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The tied logits projection (V x D, 133 MB at large-v3) for 17..48 rows.  The 16-row tiles put 3 row blocks on
+// grid.y and each streams the whole matrix: 106 us per launch at 40 rows.  Here the 48-row x tile is normalised once
+// per workgroup (decoder.ln is never folded: gamma / beta go through LDS) and every WAVE then owns whole 16-feature
+// tiles: it walks all of K itself in two batches of 20 weight fragments, 3 MFMAs (row tiles) per fragment, and stores
+// its fp32 logits straight from the accumulators — no cross-wave reduction, the matrix is read once.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void gemv_rows48_stream_kernel(whk::GemvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  pin_kernargs(a);
+  constexpr int WAVES = 16, J = 5, NB = 20;                     // K <= 1280: 40 steps of 32 in two batches
+  const int K = a.K, nks = K / 32;
+  half_t* xs = (half_t*)smem;                                   // [48][K], 16-byte unit u of row r stored at u ^ (r & 15)
+  float* gb = (float*)(smem + (size_t)48 * K * 2);              // gamma [K], beta [K]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int R = a.R;
+  const int ntiles = (a.N + 15) / 16;
+
+  float4v v[3][J];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int r = wave + WAVES * i;
+    const float* src = a.xf + (int64_t)(r < R ? r : 0) * a.xf_ld;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      int k = (j * 64 + lane) * 4; if (k > K - 4) k = K - 4;           // branch-free; masked at use
+      v[i][j] = *(const float4v*)(src + k);
+    }
+  }
+  for (int k = tid * 4; k < K; k += 4096) {
+    *(float4v*)(gb + k) = *(const float4v*)(a.ln_w + k);
+    *(float4v*)(gb + K + k) = *(const float4v*)(a.ln_b + k);
+  }
+  __syncthreads();
+  {
+    const float invK = 1.0f / (float)K;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int r = wave + WAVES * i;
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const float t = (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
+        sum += ((j * 64 + lane) * 4 < K) ? t : 0.f;
+      }
+      const float mean = wave_sum(sum) * invK;
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        if ((j * 64 + lane) * 4 < K) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = v[i][j][e] - mean; ss = __builtin_fmaf(d, d, ss); }
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(ss) * invK + 1e-5f);
+      half_t* xr = xs + (size_t)r * K;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int k = (j * 64 + lane) * 4;
+        if (k < K) {
+          const float4v w4 = *(const float4v*)(gb + k), b4 = *(const float4v*)(gb + K + k);
+          half_t* dst = xr + ((((k >> 3) ^ (r & 15)) << 3) | (k & 7));
+          if (r < R)
+            Pack4<half_t>::store(dst, (v[i][j][0] - mean) * rstd * w4[0] + b4[0], (v[i][j][1] - mean) * rstd * w4[1] + b4[1],
+                                 (v[i][j][2] - mean) * rstd * w4[2] + b4[2], (v[i][j][3] - mean) * rstd * w4[3] + b4[3]);
+          else
+            Pack4<half_t>::store(dst, 0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
+    int n = tile * 16 + i16; if (n > a.N - 1) n = a.N - 1;
+    const half_t* base = (const half_t*)a.W + (int64_t)n * K + g4 * 8;
+    float4v acc[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) acc[rt] = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int st0 = 0; st0 < nks; st0 += NB) {
+      half8v w[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        int st = st0 + u; if (st > nks - 1) st = nks - 1;
+        w[u] = __builtin_nontemporal_load((const half8v*)(base + st * 32));
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int st = st0 + u;
+        if (st < nks) {
+#pragma unroll
+          for (int rt = 0; rt < 3; ++rt) {
+            const half8v xf = *(const half8v*)(xs + (size_t)(rt * 16 + i16) * K + (((st * 4 + g4) ^ i16) << 3));
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u], xf, acc[rt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // lane (row j = i16, feature group g4) holds features 16 tile + 4 g4 + e of rows 16 rt + j
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+      const int row = rt * 16 + i16;
+      if (row < R) {
+        float* y = (float*)a.y + (int64_t)row * a.y_ld + tile * 16 + g4 * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (tile * 16 + g4 * 4 + e < a.N) y[e] = acc[rt][e];
+      }
+    }
+  }
+  if (a.bump && blockIdx.x == 0 && tid == 0) atomicAdd(a.bump, a.bump_by);
+}
+
+// fp16, LayerNorm prologue, fp32 output without bias, 17..48 rows, K a multiple of 256 up to 1280, a long N
+bool rows48_stream_applies(const whk::GemvArgs& a) {
+  static const bool off = [] { const char* e = getenv("WH_NO_ROWS48"); return e && e[0] == '1'; }();   // A/B switch (tools)
+  return !off && a.R > 16 && a.R <= 48 && a.pro == whk::PRO_LN && a.epi == whk::EPI_F32 && !a.bias && a.K % 256 == 0 &&
+         a.K <= 1280 && a.N >= 16384 && a.variant <= 0;
+}
+
+hipError_t launch_rows48_stream(const whk::GemvArgs& a, hipStream_t stream) {
+  const size_t lds = (size_t)48 * a.K * 2 + (size_t)2 * a.K * 4;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemv_rows48_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  const int ntiles = (a.N + 15) / 16;
+  int wgs = (ntiles + 15) / 16;                        // one 16-feature tile per wave ...
+  if (wgs > 256) wgs = 256;                            // ... or several when there are more tiles than 256 x 16 waves
+  hipLaunchKernelGGL(gemv_rows48_stream_kernel, dim3(wgs), dim3(1024), lds, stream, a);
+  return hipGetLastError();
+}
+
 }  // namespace
 
 namespace whk {
@@ -1326,6 +1464,7 @@ hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream) {
     // 4.8 / 7.9 / 11.2 / 14.9 / 11.7 / 11.3 us for the 16-row LDS-staged MFMA tiles below — those keep the job wherever
     // they apply; gemv8's row blocks serve the remaining shapes (row counts 9..96 outside the 16-row form's limits).
     if (rows48_applies(a)) return launch_rows48(a, stream);
+    if (rows48_stream_applies(a)) return launch_rows48_stream(a, stream);
     const bool rows16 = a.R > 8 && a.variant <= 0 && a.K % 128 == 0 && a.K <= 5120 && (a.K / 32 <= 40 || a.pro == whk::PRO_PLAIN);
     if (a.R <= 96 && !rows16) {
       const hipError_t e = launch_gemv8(a, stream);
