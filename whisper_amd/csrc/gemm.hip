@@ -112,6 +112,25 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(whk::GemmArgs p
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
+  // bias of this lane's outputs, requested before the K loop (fetched after it, the epilogue starts with a dependent
+  // round trip: 5 us per 256x256 tile in the phase probe): 4 consecutive n per tn, or one value per tm
+  float4v bpre[FN];
+  float bmpre[FM];
+#pragma unroll
+  for (int tn = 0; tn < FN; ++tn) {
+    bpre[tn] = float4v{0.f, 0.f, 0.f, 0.f};
+    const int n = n0 + wn * (FN * 16) + tn * 16 + (lane >> 4) * 4;
+    if (p.bias && !p.bias_on_m) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bpre[tn][e] = p.bias[n + e < p.N ? n + e : p.N - 1];
+    }
+  }
+#pragma unroll
+  for (int tm = 0; tm < FM; ++tm) {
+    const int m = m0 + wm * (FM * 16) + tm * 16 + (lane & 15);
+    bmpre[tm] = (p.bias && p.bias_on_m) ? p.bias[m < p.M ? m : p.M - 1] : 0.f;
+  }
+
   const int nk = p.K / BKE;
   auto stage = [&](int buf, int kt) {
     char* sA = smem + buf * STAGE_BYTES + (wave * IA) * 1024;
@@ -165,19 +184,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(whk::GemmArgs p
     const int m = m0 + wm * (FM * 16) + tm * 16 + (lane & 15);
     if (m >= p.M) continue;
     const int rm = (p.res_mod > 0) ? (m % p.res_mod) : m;
-    const float bm = (p.bias && p.bias_on_m) ? p.bias[m] : 0.f;
+    const float bm = bmpre[tm];
 #pragma unroll
     for (int tn = 0; tn < FN; ++tn) {
       const int n = n0 + wn * (FN * 16) + tn * 16 + (lane >> 4) * 4;
       if (n >= p.N) continue;
       float4v v = acc[tn][tm];
-      if (p.bias) {
-        if (p.bias_on_m) { v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm; }
-        else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
-        }
-      }
+      v += bpre[tn];
+      v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
       if (p.act == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
