@@ -82,6 +82,28 @@ def test_wide_encoder(wide, gpu_device, dt, tol):
     assert (got - want).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("name,B,tol", [("base", 8, 8e-3), ("small", 3, 8e-3)])
+def test_encoder_mid_widths(gpu_device, name, B, tol):
+    """AudioEncoder (fp16 engine) at the widths between the micro models and large-v3, all layers, vs the oracle on the
+    same mel.  These are the shapes that exercise the fp16 row GEMM kernel away from D = 1280: K = 512 / 768 (8 / 12 K
+    steps, an even count is required), persistent launches (base x 8: fc1 has 47 x 8 = 376 tiles) next to one-shot
+    ones, edge tiles (B * 1500 rows is not a multiple of 256), the batched V^T GEMM with N = 1500, and the pre-scaled
+    flash attention with 8 / 12 heads.  Tolerance: measured 2.5e-3 max / 3.3e-4 rms on outputs of magnitude <= 5.1
+    (fp16 weights and activations through 6 / 12 layers against fp32); asserted at 8e-3 / 1e-3."""
+    dims = oracle.dims_for(name)
+    sd = oracle.synthetic_state_dict(dims, seed=5)
+    om = oracle.OracleModel(dims, sd)
+    model = hip.HipModel(dims, hip.WH_F16, hip.pack_weights(sd, dims, hip.WH_F16, gpu_device))
+    g = torch.Generator().manual_seed(11)
+    mel = torch.randn(B, dims.n_mels, 3000, generator=g) * 0.4 - 0.3
+    want = om.encoder(mel)
+    got = model.encode(mel.to(gpu_device)).float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max().item()
+    rms = ((got - want) ** 2).mean().sqrt().item()
+    assert err < tol and rms < tol / 8, (err, rms)
+
+
 def _greedy_setup(dims, n_steps, gpu_device, suppress_eot):
     from whisper_amd.tokenizer import get_tokenizer
     tok = get_tokenizer(True, num_languages=dims.n_vocab - 51765 - 1, language="en", task="transcribe")

@@ -402,8 +402,8 @@ class HipModel:
             if getattr(self, "handle", None):
                 lib().wh_model_destroy(self.handle)
                 self.handle = None
-        except (HipError, RuntimeError, OSError, AttributeError, TypeError):
-            pass        # interpreter shutdown
+        except Exception:   # noqa: BLE001 — interpreter shutdown: module globals (even HipError) may already be None
+            pass
 
     # -- AudioEncoder.forward ----------------------------------------------------------------------
     def encode(self, mel: torch.Tensor) -> torch.Tensor:
@@ -481,8 +481,8 @@ class HipTask:
     def __del__(self):
         try:
             self.destroy()
-        except (HipError, RuntimeError, OSError, AttributeError, TypeError):
-            pass        # interpreter shutdown: the library or torch may already be gone
+        except Exception:   # noqa: BLE001 — interpreter shutdown: module globals (even HipError) may already be None
+            pass            # (the library or torch may already be gone)
 
     def _enter(self):
         torch.cuda.set_device(self.model.device)       # the C ABI launches on the calling thread's current device
