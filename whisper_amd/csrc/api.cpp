@@ -289,6 +289,7 @@ struct wh_task {
   float* samp_part;        // greedy sampler stage-1 partials
   void* beam_scratch;      // beam search partials / candidates (G > 1)
   int* beam_flags;         // [2][B] completion flags + [1] applied-update counter
+  int* beam_lcp;           // [B][8][8] shared-history lengths of the rows of a segment + [R] first position to copy
   void* qcap;              // [L][R*Tcap][D] captured cross-attention queries
   int cross_splits, self_splits;
   size_t total;
@@ -357,6 +358,7 @@ static void task_carve(wh_task* t, void* base) {
   t->samp_part = (float*)c.take(greedy_sample_scratch_bytes((int)R, (int)V));
   t->beam_scratch = t->G > 1 ? c.take(beam_scratch_bytes((int)R, (int)V)) : nullptr;
   t->beam_flags = t->G > 1 ? (int*)c.take((2 * (size_t)t->B + 1) * 4) : nullptr;
+  t->beam_lcp = t->G > 1 ? (int*)c.take(((size_t)t->B * 64 + R) * 4) : nullptr;
   t->qcap = (t->flags & WH_TASK_CAPTURE_Q) ? c.take(L * R * C * D * es) : nullptr;
   t->total = align_up(c.off, 256);
 }
@@ -804,7 +806,7 @@ extern "C" int wh_task_rearrange(wh_task* t, const int32_t* source_indices, void
   for (int i = 0; i < t->R && in_group; ++i) in_group = source_indices[i] / t->G == i / t->G;
   if (in_group) {
     HIPCHK(launch_permute_groups(t->self_k, t->self_v, d.n_text_layer, (int64_t)t->R * row_bytes, t->B, t->G, row_bytes,
-                                 used_bytes, t->d_src, s));
+                                 used_bytes, t->d_src, nullptr, 0, s));
     return WH_OK;
   }
   for (int l = 0; l < d.n_text_layer; ++l) {
@@ -945,6 +947,14 @@ extern "C" int wh_task_beam(wh_task* t, const wh_beam_params* bp, int64_t* token
   a.fin_tok = fin_tokens; a.fin_len = fin_len; a.fin_score = fin_scores; a.fin_count = fin_count;
   a.max_candidates = bp->max_candidates;
   a.src = t->d_src; a.step_tokens = t->step_tokens; a.d_applied = d_applied;
+  // shared-history bookkeeping for the cache permutation (beams that descend from one ancestor hold the same K/V up to
+  // the point where they split: those positions are never copied).  "Everything so far" to start with: all beams of a
+  // segment hold the same prompt.  Not used with ragged prompts (positions are row-local there).
+  static const bool lcp_on = [] { const char* e = getenv("WH_BEAM_FULL_PERMUTE"); return !(e && e[0] == '1'); }();   // A/B switch
+  if (lcp_on && !t->lag_on) {
+    a.lcp = t->beam_lcp; a.copy_from = t->beam_lcp + (size_t)B * 64;
+    HIPCHK(hipMemsetAsync(t->beam_lcp, 0x7f, (size_t)B * 64 * 4, s));
+  }
 
   const size_t es = t->m->esize;
   const int64_t row_bytes = (int64_t)d.n_text_ctx * d.n_text_state * es;
@@ -957,7 +967,8 @@ extern "C" int wh_task_beam(wh_task* t, const wh_beam_params* bp, int64_t* token
     cur ^= 1;
     // rearrange_kv_cache (decoding.py:172-176): new beam i continues the cache of row src[i]
     HIPCHK(launch_permute_groups(t->self_k, t->self_v, d.n_text_layer, (int64_t)R * row_bytes, B, G, row_bytes,
-                                 (int64_t)t->pos * d.n_text_state * es, t->d_src, s));
+                                 (int64_t)t->pos * d.n_text_state * es, t->d_src, a.copy_from,
+                                 (int64_t)d.n_text_state * es, s));
     return WH_OK;
   };
 

@@ -290,6 +290,7 @@ __global__ __launch_bounds__(64) void beam_update_kernel(whk::BeamArgs a, int B)
   __shared__ int kept[8], nfin_list[NC_MAX];
   __shared__ int sh_n[3];               // candidates in order, kept, newly finished
   __shared__ int sh_frozen;
+  __shared__ int sh_lcp[64], sh_src[8];
   const int tid = threadIdx.x;
   const int au = blockIdx.x;
   const int G = a.G, K = a.K;
@@ -307,11 +308,12 @@ __global__ __launch_bounds__(64) void beam_update_kernel(whk::BeamArgs a, int B)
       const int64_t* s = a.tokens_in + (int64_t)(r0 + g) * a.token_stride;
       int64_t* d = a.tokens_out + (int64_t)(r0 + g) * a.token_stride;
       for (int t = tid; t < len; t += 64) d[t] = s[t];
-      if (tid == 0) a.src[r0 + g] = r0 + g;
+      if (tid == 0) { a.src[r0 + g] = r0 + g; if (a.copy_from) a.copy_from[r0 + g] = 0; }
     }
     if (tid == 0) a.done_next[au] = 1;
     return;
   }
+  if (a.lcp) sh_lcp[tid] = a.lcp[au * 64 + tid];
 
   const int N = G * K;
   for (int c = tid; c < N; c += 64) {
@@ -377,6 +379,24 @@ __global__ __launch_bounds__(64) void beam_update_kernel(whk::BeamArgs a, int B)
     }
   }
   __syncthreads();                 // every score has been read before the sums are replaced
+  if (a.lcp) {
+    // Shared history.  Rows i and j of this segment hold identical K/V at their first lcp[i][j] cache positions.  The
+    // new row i continues old row s_i = src[i]: it only has to copy the positions from lcp_old[i][s_i] on (below that
+    // its own bytes are already those of s_i), and new rows i, j share what their sources shared — everything so far
+    // if they have the same source.  Rows that were not kept hold nothing anyone relies on: 0.
+    if (tid < 8) sh_src[tid] = tid < nkept ? csrc[kept[tid]] - r0 : -1;
+    __syncthreads();
+    const int i = tid >> 3, j = tid & 7;
+    const int si = sh_src[i], sj = sh_src[j];
+    int v = 0;
+    if (si >= 0 && sj >= 0) { v = si == sj ? len : sh_lcp[si * 8 + sj]; if (v > len) v = len; }
+    a.lcp[au * 64 + tid] = v;
+    if (j == 0 && i < G) {
+      int cf = 0;
+      if (si >= 0) { cf = si == i ? len : sh_lcp[i * 8 + si]; if (cf > len) cf = len; }
+      a.copy_from[r0 + i] = cf;
+    }
+  }
   if (tid < nkept) a.sum_logprobs[r0 + tid] = score[kept[tid]];
   if (tid == 0) {
     a.fin_count[au] = count;

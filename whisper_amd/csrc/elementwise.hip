@@ -161,17 +161,24 @@ __global__ void gather_cache_kernel(const uint4v* __restrict__ src, uint4v* __re
 template <int GMAX>
 __global__ __launch_bounds__(256) void permute_group_kernel(uint4v* __restrict__ k_base, uint4v* __restrict__ v_base,
                                                             int64_t layer_units, int64_t row_units, int64_t used_units,
-                                                            const int* __restrict__ src_idx, int G) {
+                                                            const int* __restrict__ src_idx, int G,
+                                                            const int* __restrict__ copy_from, int pos_units) {
   const int audio = blockIdx.y, lz = blockIdx.z;
   uint4v* base = ((lz & 1) ? v_base : k_base) + (int64_t)(lz >> 1) * layer_units + (int64_t)audio * G * row_units;
   int src[GMAX];
+  int64_t first[GMAX];                      // first 16-byte unit row g has to take from its source
 #pragma unroll
-  for (int g = 0; g < GMAX; ++g) src[g] = g < G ? src_idx[audio * G + g] - audio * G : 0;
-  bool identity = true;
+  for (int g = 0; g < GMAX; ++g) {
+    src[g] = g < G ? src_idx[audio * G + g] - audio * G : 0;
+    first[g] = (g < G && copy_from) ? (int64_t)copy_from[audio * G + g] * pos_units : 0;
+  }
+  int64_t begin = used_units;
 #pragma unroll
-  for (int g = 0; g < GMAX; ++g) identity = identity && (g >= G || src[g] == g);
-  if (identity) return;                     // nothing moves in this segment (uniform: decided from src_idx alone)
-  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < used_units; u += (int64_t)gridDim.x * 256) {
+  for (int g = 0; g < GMAX; ++g)
+    if (g < G && src[g] != g && first[g] < begin) begin = first[g];
+  if (begin >= used_units) return;          // nothing moves in this segment (uniform: decided from the index arrays alone)
+  begin = begin / 256 * 256;
+  for (int64_t u = begin + (int64_t)blockIdx.x * 256 + threadIdx.x; u < used_units; u += (int64_t)gridDim.x * 256) {
     uint4v val[GMAX];
 #pragma unroll
     for (int g = 0; g < GMAX; ++g)
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(256) void permute_group_kernel(uint4v* __restrict__
         uint4v v = val[0];
 #pragma unroll
         for (int j = 1; j < GMAX; ++j) v = (src[g] == j) ? val[j] : v;
-        if (src[g] != g) base[(int64_t)g * row_units + u] = v;
+        if (src[g] != g && u >= first[g]) base[(int64_t)g * row_units + u] = v;
       }
     }
   }
@@ -259,14 +266,16 @@ hipError_t launch_gather_cache(const void* src, void* dst, const int* src_idx, i
 }
 
 hipError_t launch_permute_groups(void* k_base, void* v_base, int n_layers, int64_t layer_bytes, int n_audio, int G,
-                                 int64_t row_bytes, int64_t used_bytes, const int* src_idx, hipStream_t stream) {
+                                 int64_t row_bytes, int64_t used_bytes, const int* src_idx, const int* copy_from,
+                                 int64_t pos_bytes, hipStream_t stream) {
   if (used_bytes <= 0) return hipSuccess;
-  if (G > 8) return hipErrorInvalidValue;
+  if (G > 8 || (copy_from && (pos_bytes <= 0 || pos_bytes % 16))) return hipErrorInvalidValue;
   const int64_t used_units = used_bytes / 16;
   int bx = (int)((used_units + 255) / 256);
   if (bx > 64) bx = 64;
   hipLaunchKernelGGL(permute_group_kernel<8>, dim3(bx, n_audio, n_layers * 2), dim3(256), 0, stream, (uint4v*)k_base,
-                     (uint4v*)v_base, layer_bytes / 16, row_bytes / 16, used_units, src_idx, G);
+                     (uint4v*)v_base, layer_bytes / 16, row_bytes / 16, used_units, src_idx, G, copy_from,
+                     (int)(pos_bytes / 16));
   return hipGetLastError();
 }
 

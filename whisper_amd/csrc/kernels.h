@@ -58,9 +58,11 @@ hipError_t launch_gather_rows(const float* x, const int* sel, int n_sel, int D, 
 hipError_t launch_gather_cache(const void* src, void* dst, const int* src_idx, int R, int64_t row_bytes,
                                int64_t used_bytes, hipStream_t stream);
 // in-place beam reorder of every layer's self-attention K and V cache in one launch; src_idx[i] must lie in the
-// beam group of row i (groups of G consecutive rows), G <= 8
+// beam group of row i (groups of G consecutive rows), G <= 8.  copy_from (may be null): row i only needs the cache
+// positions >= copy_from[i] of its source — below that the two rows already hold the same bytes (pos_bytes per position)
 hipError_t launch_permute_groups(void* k_base, void* v_base, int n_layers, int64_t layer_bytes, int n_audio, int G,
-                                 int64_t row_bytes, int64_t used_bytes, const int* src_idx, hipStream_t stream);
+                                 int64_t row_bytes, int64_t used_bytes, const int* src_idx, const int* copy_from,
+                                 int64_t pos_bytes, hipStream_t stream);
 hipError_t launch_add_int(int* p, int v, hipStream_t stream);
 
 // ---- attention.hip -------------------------------------------------------------------------
@@ -181,6 +183,10 @@ struct BeamArgs {
   int64_t* fin_tok; int* fin_len; float* fin_score; int* fin_count;   // [B][max_candidates][stride], [B][mc], [B][mc], [B]
   int max_candidates;
   int* src;                                 // [R] out: row whose KV cache the new beam continues
+  // optional (both or neither): lcp [B][8][8] in/out = number of leading cache positions at which two rows of a segment
+  // hold identical K/V (initialise every entry to INT_MAX-like: "everything so far"); copy_from [R] out = first position
+  // row r has to take from src[r] (below it the bytes are already the same)
+  int* lcp; int* copy_from;
   int64_t* step_tokens;                     // [R] out: next step's input tokens
   const int* done_prev; int* done_next;     // [B] completion flags written by the previous / this update
   int* d_applied;                           // number of updates applied (not frozen)
