@@ -137,6 +137,10 @@ int wh_encode(const wh_model *m, const void *mel, int mel_is_f16, int batch, voi
 /* ---- decoding task: PyTorchInference + kv_cache — whisper/decoding.py:144-176, model.py:310-341 */
 /* flags for wh_task_create */
 enum { WH_TASK_CAPTURE_Q = 1 };   /* keep cross-attention queries of every layer (word timestamps) */
+/* The workspace holds the cross-attention K/V of n_audio segments, the self-attention cache of n_audio * n_group rows
+ * and the step buffers.  WH_F16 tasks with n_group > 1 (beam search) additionally hold a transposed copy of the
+ * cross-attention V per layer (the matrix-core form of the beam-group attention reads it): + n_text_layer * n_audio *
+ * n_text_state * 1536 * 2 bytes at n_audio_ctx = 1500.  wh_task_workspace_bytes accounts for all of it. */
 size_t wh_task_workspace_bytes(const wh_model *m, int n_audio, int n_group, int max_prefill_tokens,
                                int flags);
 int wh_task_create(const wh_model *m, int n_audio, int n_group, int max_prefill_tokens, int flags,
