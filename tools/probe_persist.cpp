@@ -53,6 +53,27 @@ __device__ bool grid_barrier(Sync* s, unsigned gen, int grp, int members, int ng
   return ok;
 }
 
+// The same barrier without fences, for the tuned form: the caller has already made its stores visible (sc1 write-through
+// stores + a counted vmcnt wait that leaves the run-ahead loads in flight); the poll result is consumed before
+// `buffer_inv sc1` invalidates the non-coherent lines, so no wait on the vector-memory counter is needed here either.
+__device__ bool grid_barrier_nofence(Sync* s, unsigned gen, int grp, int members, int ngroups) {
+  const unsigned prev = __hip_atomic_fetch_add(&s->grp_cnt[grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool ok = true;
+  if (prev == gen * members + members - 1) {
+    const unsigned p2 = __hip_atomic_fetch_add(&s->top_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p2 == gen * ngroups + ngroups - 1) __hip_atomic_store(&s->top_gen, gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (ld_agent(&s->top_gen) < gen + 1) { if (++spins > 20000000) { ok = false; break; } }
+    __hip_atomic_store(&s->grp_gen[grp], gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    int spins = 0;
+    while (ld_agent(&s->grp_gen[grp]) < gen + 1) { if (++spins > 20000000) { ok = false; break; } }
+  }
+  asm volatile("buffer_inv sc1" ::: "memory");
+  if (!ok) atomicExch(&s->abort_flag, 1u);
+  return ok;
+}
+
 // A phase in the form of the real kernels: the 4 waves of a workgroup own whole features (wave w: features w, w + 4, ...),
 // the 64 lanes of a wave split K in 16-byte units, partial sums meet by a wave reduction.  FW = features per
 // workgroup, K = reduction length; FPW x UPL weight units of 16 bytes per lane, all requested up front.
@@ -75,7 +96,7 @@ __device__ __forceinline__ void issue_weights_t(const half_t* W, int wg, half8v*
     }
   }
 }
-template <int FW, int K>
+template <int FW, int K, bool SC1>
 __device__ __forceinline__ void phase_body_t(int wg, const half8v* w, const half_t* x, int xld, half_t* y, int yld, half_t* xs) {
   typedef Shape<FW, K> S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -110,7 +131,14 @@ __device__ __forceinline__ void phase_body_t(int wg, const half8v* w, const half
       float v = acc[0];
 #pragma unroll
       for (int r = 1; r < ROWS; ++r) v = lane == r ? acc[r] : v;
-      y[(size_t)lane * yld + wg * FW + f] = (half_t)(v * scale);
+      half_t* dst = y + (size_t)lane * yld + wg * FW + f;
+      const half_t hv = (half_t)(v * scale);
+      if (SC1) {                                       // write-through to the coherence point: visible once acknowledged
+        const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, hv);
+        asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(dst), "v"(bits) : "memory");
+      } else {
+        *dst = hv;
+      }
     }
   }
 }
@@ -122,12 +150,22 @@ __device__ __forceinline__ void issue_weights(const half_t* W, int ph, int wg, h
     default: issue_weights_t<5, D>(W, wg, w); break;
   }
 }
+template <bool SC1 = false>
 __device__ __forceinline__ void phase_body(int ph, int wg, const half8v* w, const half_t* x, int xld, half_t* y, int yld, half_t* xs) {
   switch (ph) {
-    case 0: phase_body_t<15, D>(wg, w, x, xld, y, yld, xs); break;
-    case 4: phase_body_t<20, D>(wg, w, x, xld, y, yld, xs); break;
-    case 5: phase_body_t<5, 4 * D>(wg, w, x, xld, y, yld, xs); break;
-    default: phase_body_t<5, D>(wg, w, x, xld, y, yld, xs); break;
+    case 0: phase_body_t<15, D, SC1>(wg, w, x, xld, y, yld, xs); break;
+    case 4: phase_body_t<20, D, SC1>(wg, w, x, xld, y, yld, xs); break;
+    case 5: phase_body_t<5, 4 * D, SC1>(wg, w, x, xld, y, yld, xs); break;
+    default: phase_body_t<5, D, SC1>(wg, w, x, xld, y, yld, xs); break;
+  }
+}
+// wait until this wave's stores are acknowledged while the `ph` weight requests issued after them stay in flight
+__device__ __forceinline__ void wait_stores_keep_weights(int ph) {
+  switch (ph) {
+    case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Shape<15, D>::NU) : "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Shape<20, D>::NU) : "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Shape<5, 4 * D>::NU) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Shape<5, D>::NU) : "memory"); break;
   }
 }
 
@@ -160,6 +198,32 @@ __global__ __launch_bounds__(NT) void persistent_kernel(const half_t* const* Wl,
     if (RUNAHEAD) issue_weights(Wl[p + 1], (p + 1) % NPH, wg, w);   // in flight across the barrier
     __syncthreads();                                   // every thread's y stores are issued
     if (threadIdx.x == 0) sh_ok = grid_barrier(s, (unsigned)p, grp, NWG / 8, 8) ? 1 : 0;
+    __syncthreads();
+    if (!sh_ok) return;
+  }
+}
+
+// tuned form: sc1 stores, counted wait, fence-free barrier, run-ahead weights kept in flight across it
+__global__ __launch_bounds__(NT) void persistent_tuned_kernel(const half_t* const* Wl, int layers, half_t* buf0, half_t* buf1, Sync* s) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* xs = (half_t*)smem;
+  __shared__ int sh_ok;
+  const int wg = blockIdx.x, grp = wg & 7;
+  half8v w[MAXU];
+  const int total = layers * NPH;
+  issue_weights(Wl[0], 0, wg, w);
+  for (int p = 0; p < total; ++p) {
+    const int ph = p % NPH;
+    const half_t* x = (p & 1) ? buf1 : buf0;
+    half_t* y = (p & 1) ? buf0 : buf1;
+    phase_body<true>(ph, wg, w, x, 4 * D, y, 4 * D, xs);
+    if (p + 1 == total) break;
+    asm volatile("" ::: "memory");
+    issue_weights(Wl[p + 1], (p + 1) % NPH, wg, w);
+    asm volatile("" ::: "memory");
+    wait_stores_keep_weights((p + 1) % NPH);
+    __syncthreads();                                   // every wave's y stores are acknowledged
+    if (threadIdx.x == 0) sh_ok = grid_barrier_nofence(s, (unsigned)p, grp, NWG / 8, 8) ? 1 : 0;
     __syncthreads();
     if (!sh_ok) return;
   }
@@ -216,13 +280,15 @@ int main() {
            best * 1e3 / LAYERS, best * 1e3 / (LAYERS * NPH), bytes_layer * LAYERS / (best * 1e-3) * 1e-12);
   }
   // ---- persistent forms
-  for (int ra = 0; ra < 2; ++ra) {
+  CK(hipFuncSetAttribute((const void*)persistent_tuned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int ra = 0; ra < 3; ++ra) {
     float best = 1e30f; unsigned aborted = 0;
     for (int rep = 0; rep < 6; ++rep) {
       CK(hipMemcpyAsync(buf0, hx.data(), hx.size() * 2, hipMemcpyHostToDevice, st));
       CK(hipMemsetAsync(d_sync, 0, sizeof(Sync), st));
       CK(hipEventRecord(e0, st));
-      if (ra) hipLaunchKernelGGL(persistent_kernel<true>, dim3(NWG), dim3(NT), lds, st, (const half_t* const*)d_Wl, LAYERS, buf0, buf1, d_sync);
+      if (ra == 2) hipLaunchKernelGGL(persistent_tuned_kernel, dim3(NWG), dim3(NT), lds, st, (const half_t* const*)d_Wl, LAYERS, buf0, buf1, d_sync);
+      else if (ra) hipLaunchKernelGGL(persistent_kernel<true>, dim3(NWG), dim3(NT), lds, st, (const half_t* const*)d_Wl, LAYERS, buf0, buf1, d_sync);
       else hipLaunchKernelGGL(persistent_kernel<false>, dim3(NWG), dim3(NT), lds, st, (const half_t* const*)d_Wl, LAYERS, buf0, buf1, d_sync);
       CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep > 0 && ms < best) best = ms;
@@ -233,7 +299,7 @@ int main() {
     for (int r = 0; r < ROWS; ++r)
       for (int n = 0; n < D; ++n) { const double dd = fabs((double)(float)got[(size_t)r * 4 * D + n] - (double)(float)ref[(size_t)r * 4 * D + n]); if (dd > worst) worst = dd; }
     printf("one persistent launch, %s: %7.2f us per layer (%.2f us per phase incl. barrier)%s   max |y - chain| %.1e\n",
-           ra ? "weights requested before the barrier" : "weights requested after the barrier ", best * 1e3 / LAYERS,
+           ra == 2 ? "run-ahead, sc1 stores, no fences     " : ra ? "weights requested before the barrier" : "weights requested after the barrier ", best * 1e3 / LAYERS,
            best * 1e3 / (LAYERS * NPH), aborted ? "  [A SPIN RAN OUT]" : "", worst);
   }
   return 0;
