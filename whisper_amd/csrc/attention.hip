@@ -710,10 +710,14 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_group_mfma_kernel(whk:
   }
 #pragma unroll
   for (int j = 0; j < NBLK; ++j) {
-    const int kb = k0 + (wave * NBLK + j) * 32;                          // < vt_ld: the rows are padded to S * chunk keys
+    // the rows are padded to S * chunk keys; a block that lies wholly beyond this split's keys (chunk < WAVES * NBLK * 32)
+    // has P = 0 everywhere and is pointed at the last 8 columns of the row, so that what it multiplies by 0 is finite
+    // and inside the row
+    int col = k0 + (wave * NBLK + j) * 32 + g4 * 8;
+    if (col > (int)a.vt_ld - 8) col = (int)a.vt_ld - 8;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-      vf[j][dt] = __builtin_nontemporal_load((const half8v*)(vp + (int64_t)(dt * 16) * a.vt_ld + kb));
+      vf[j][dt] = __builtin_nontemporal_load((const half8v*)(vp - g4 * 8 + (int64_t)(dt * 16) * a.vt_ld + col));
   }
   // every request goes out before the first use: left alone, the scheduler hoists the first MFMAs (and the waits for
   // their operands) in between the loads to save registers — several dependent round trips instead of one
