@@ -370,7 +370,8 @@ def other_configs(device, N):
             r = whisper_amd.decode(m, mel, opts)
             if words:
                 text = [[t for t in x.tokens if t < tok.eot][:200] for x in r]
-                find_alignment_batch(m, tok, text, mel.half(), [3000] * batch)
+                find_alignment_batch(m, tok, text, mel.half(), [3000] * batch,
+                                     audio_features=torch.stack([x.audio_features for x in r]))   # as transcribe() does
             return r
         one()
         torch.cuda.synchronize(device)

@@ -257,6 +257,12 @@ def test_find_alignment_batch_equals_single(setup, gpu_device):
     al = find_alignment_batch(model, tok, [G[f"{key}_align_tokens"].tolist()], mel[None].float(), [3000])[0]
     assert np.abs(np.array([w.start for w in al]) - G[f"{key}_align_start"]).max() < 1e-6
     assert np.abs(np.array([w.end for w in al]) - G[f"{key}_align_end"]).max() < 1e-6
+    # with the encoder output handed in (what transcribe() does with DecodingResult.audio_features): nothing changes
+    feats = model.encoder(mels.float())
+    again = find_alignment_batch(model, tok, texts, mels.float(), frames, audio_features=feats)
+    assert again == got
+    assert find_alignment(model, tok, texts[3], mels[3].float(), frames[3], audio_features=feats[3]) == \
+        find_alignment(model, tok, texts[3], mels[3].float(), frames[3])
 
 
 def test_transcribe_golden(setup):

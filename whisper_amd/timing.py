@@ -69,14 +69,19 @@ class WordTiming:
 
 
 def find_alignment(model: "Whisper", tokenizer: Tokenizer, text_tokens: List[int], mel: torch.Tensor,
-                   num_frames: int, *, medfilt_width: int = 7, qk_scale: float = 1.0) -> List[WordTiming]:
+                   num_frames: int, *, medfilt_width: int = 7, qk_scale: float = 1.0,
+                   audio_features: Optional[torch.Tensor] = None) -> List[WordTiming]:
+    """reference timing.py:163-242.  `audio_features` (extension): the encoder output of this window, (1500, D), as
+    returned in DecodingResult.audio_features — the reference re-runs the encoder on `mel` here (timing.py:199); passing
+    the features the decode already computed skips that pass, with identical results."""
     if len(text_tokens) == 0:
         return []
     n_sot = len(tokenizer.sot_sequence)
     tokens = torch.tensor([*tokenizer.sot_sequence, tokenizer.no_timestamps, *text_tokens, tokenizer.eot],
                           device=model.device)
     with torch.no_grad():
-        features = model.encoder(mel.unsqueeze(0))
+        features = model.encoder(mel.unsqueeze(0)) if audio_features is None else audio_features.reshape(
+            1, model.dims.n_audio_ctx, model.dims.n_audio_state)
         engine = model.engine(features.dtype)
         task = engine.acquire_task(1, 1, max(int(tokens.numel()), 8), capture_q=True)
         try:
@@ -116,9 +121,11 @@ ALIGN_BATCH_SCRATCH_BYTES = 6 << 30      # bound on the QK / softmax slabs of on
 
 
 def find_alignment_batch(model: "Whisper", tokenizer: Tokenizer, text_tokens: List[List[int]], mel: torch.Tensor,
-                         num_frames: List[int], *, medfilt_width: int = 7, qk_scale: float = 1.0) -> List[List[WordTiming]]:
+                         num_frames: List[int], *, medfilt_width: int = 7, qk_scale: float = 1.0,
+                         audio_features: Optional[torch.Tensor] = None) -> List[List[WordTiming]]:
     """`find_alignment` for every clip of a batch — mel (B, n_mels, 3000), one token list and frame count per clip —
-    with identical results, clip by clip (BASELINE configs[4]: word timestamps over a batch).  One encoder pass, ONE
+    with identical results, clip by clip (BASELINE configs[4]: word timestamps over a batch).  One encoder pass (none
+    when `audio_features` (B, 1500, D), the DecodingResult.audio_features of the same windows, is passed), ONE
     teacher-forced decoder pass over all clips (rows padded on the right; causal attention keeps the padding out of the
     real positions), one launch each for the alignment heads' QK, softmax, z-norm, median, head mean and DTW
     (wh_task_align_batch, a workgroup per clip for the DTW wavefront); only the back-trace walk is host code."""
@@ -141,7 +148,7 @@ def find_alignment_batch(model: "Whisper", tokenizer: Tokenizer, text_tokens: Li
             n_tok = [len(r) for r in rows]
             Tmax = max(n_tok)
             tokens = torch.tensor([r + [tokenizer.eot] * (Tmax - len(r)) for r in rows], device=model.device)
-            features = model.encoder(mel[ids])
+            features = model.encoder(mel[ids]) if audio_features is None else audio_features[ids]
             engine = model.engine(features.dtype)
             task = engine.acquire_task(len(ids), 1, max(Tmax, 8), capture_q=True)
             try:

@@ -61,9 +61,11 @@ class _AlignRequest:
     """what a file's state machine yields when it needs the word alignment of the window it just decoded; the driver
     answers with find_alignment's result (one file) or one row of find_alignment_batch (many files)"""
 
-    def __init__(self, text_tokens: List[int], mel: torch.Tensor, num_frames: int, tokenizer, language: str, task: str):
+    def __init__(self, text_tokens: List[int], mel: torch.Tensor, num_frames: int, tokenizer, language: str, task: str,
+                 audio_features: Optional[torch.Tensor] = None):
         self.text_tokens, self.mel, self.num_frames = text_tokens, mel, num_frames
         self.tokenizer, self.language, self.task = tokenizer, language, task
+        self.audio_features = audio_features       # encoder output of this window from the decode (no second pass)
 
 
 class _Transcriber:
@@ -128,7 +130,7 @@ class _Transcriber:
             while True:
                 if isinstance(request, _AlignRequest):
                     request = walk.send(find_alignment(self.model, request.tokenizer, request.text_tokens, request.mel,
-                                                       request.num_frames))
+                                                       request.num_frames, audio_features=request.audio_features))
                 else:
                     request = walk.send(self.decode_with_fallback(request))
         except StopIteration as stop:
@@ -282,7 +284,8 @@ class _Transcriber:
                     # the alignment itself (encoder + teacher-forced pass + DTW) is the driver's job: it may batch the
                     # requests of many files
                     alignment = yield _AlignRequest(alignment_text_tokens(current_segments, tokenizer), mel_segment,
-                                                    segment_size, tokenizer, language, task)
+                                                    segment_size, tokenizer, language, task,
+                                                    audio_features=getattr(result, "audio_features", None))
                     add_word_timestamps(
                         segments=current_segments, model=model, tokenizer=tokenizer, mel=mel_segment,
                         num_frames=segment_size, prepend_punctuations=self.prepend_punctuations,
@@ -520,10 +523,15 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, max_acti
                     chunk = members[at: at + batch_size]
                     reqs = [aligns[i] for i in chunk]
                     if len(chunk) == 1:          # alone: exactly the call `transcribe` makes
-                        answers = [find_alignment(model, reqs[0].tokenizer, reqs[0].text_tokens, reqs[0].mel, reqs[0].num_frames)]
+                        answers = [find_alignment(model, reqs[0].tokenizer, reqs[0].text_tokens, reqs[0].mel, reqs[0].num_frames,
+                                                  audio_features=reqs[0].audio_features)]
                     else:
+                        feats = None
+                        if all(r.audio_features is not None for r in reqs):
+                            feats = torch.stack([r.audio_features for r in reqs])
                         answers = find_alignment_batch(model, reqs[0].tokenizer, [r.text_tokens for r in reqs],
-                                                       torch.stack([r.mel for r in reqs]), [r.num_frames for r in reqs])
+                                                       torch.stack([r.mel for r in reqs]), [r.num_frames for r in reqs],
+                                                       audio_features=feats)
                     for i, answer in zip(chunk, answers):
                         advance(i, answer)
             admit()
