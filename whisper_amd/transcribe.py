@@ -98,6 +98,10 @@ class _Transcriber:
             result = self.model.decode(segment, self._options_for(t))
             if not self._needs_retry(result):
                 break
+            feats = getattr(result, "audio_features", None)
+            if torch.is_tensor(feats) and feats.shape[-2:] == (self.model.dims.n_audio_ctx, self.model.dims.n_audio_state):
+                segment = feats             # the retry decodes the same window: hand it the encoder output (decode()
+                                            # accepts encoded features, reference decoding.py:655-662) — no second pass
         return result
 
     def _needs_retry(self, result: DecodingResult) -> bool:
@@ -541,6 +545,7 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, max_acti
         rung = {i: 0 for i in pending}
         todo = sorted(pending)
         answers = {}
+        encoded = {}
         while todo:
             groups = {}
             for i in todo:
@@ -551,15 +556,21 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, max_acti
                 shared = replace(workers[members[0]]._options_for(t), prompt=None)
                 prompts = {i: workers[i].decode_options.get("prompt") for i in members}
                 for chunk in _prompt_batches(model, shared, prompts, members, batch_size):
+                    # a window on a higher rung has been encoded already: its retry takes the features
+                    inputs = [encoded.get(i, pending[i]) for i in chunk]
+                    if len({tuple(x.shape) for x in inputs}) > 1:
+                        inputs = [pending[i] for i in chunk]
                     if len(chunk) == 1:        # alone: exactly the call `transcribe` makes
-                        decoded = [model.decode(pending[chunk[0]], workers[chunk[0]]._options_for(t))]
+                        decoded = [model.decode(inputs[0], workers[chunk[0]]._options_for(t))]
                     else:
-                        decoded = model.decode(torch.stack([pending[i] for i in chunk]), shared,
-                                               prompts=[prompts[i] for i in chunk])
+                        decoded = model.decode(torch.stack(inputs), shared, prompts=[prompts[i] for i in chunk])
                     for i, result in zip(chunk, decoded):
                         if workers[i]._needs_retry(result) and rung[i] + 1 < len(workers[i].temperatures):
                             rung[i] += 1
                             todo.append(i)
+                            feats = getattr(result, "audio_features", None)
+                            if torch.is_tensor(feats) and feats.shape[-2:] == (model.dims.n_audio_ctx, model.dims.n_audio_state):
+                                encoded[i] = feats
                         else:
                             answers[i] = result
             todo.sort()
