@@ -374,6 +374,7 @@ def other_configs(device, N):
                                      audio_features=torch.stack([x.audio_features for x in r]))   # as transcribe() does
             return r
         one()
+        one()                               # two warm-up passes: the first timed pass was still 1.5-2 x slower after one
         torch.cuda.synchronize(device)
         times = []
         for _ in range(3):                  # median of three passes (a 54 ms pass is easily disturbed by a host hiccup)
