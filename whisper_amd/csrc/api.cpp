@@ -470,7 +470,8 @@ extern "C" int wh_task_set_audio(wh_task* t, const void* features, void* stream_
   if (t->cross_vt) {
     // V^T = W_v . X^T per audio (bias along rows), as in the encoder; the pad columns [Ta, vt_ld) only have to be finite
     const size_t rows = (size_t)d.n_text_layer * t->B * D;
-    HIPCHK(hipMemset2DAsync((char*)t->cross_vt + (size_t)Ta * es, (size_t)t->vt_ld * es, 0, (size_t)(t->vt_ld - Ta) * es, rows, s));
+    if (t->vt_ld > Ta)
+      HIPCHK(hipMemset2DAsync((char*)t->cross_vt + (size_t)Ta * es, (size_t)t->vt_ld * es, 0, (size_t)(t->vt_ld - Ta) * es, rows, s));
     for (int l = 0; l < d.n_text_layer; ++l) {
       const wh_layer_weights& L = m->dec[l];
       GemmArgs g; memset(&g, 0, sizeof(g));
