@@ -556,6 +556,48 @@ def test_transcribe_word_timestamp_seeking_matches_reference(ref, monkeypatch):
         assert len(ma.calls) >= 4 and any("words" in s for s in ra["segments"])
 
 
+def test_transcribe_reuses_the_windows_encoder_output(monkeypatch):
+    """Two places where the reference encodes a window again and this package does not: the temperature-fallback retry
+    (transcribe.py:184-224 calls decode() on the mel every time) is handed DecodingResult.audio_features of the first
+    attempt — decode() accepts encoded input (decoding.py:655-662) — and the word aligner receives the same tensor
+    through `audio_features=` instead of running the encoder on the mel (timing.py:199)."""
+    import oracle
+    import whisper_amd  # noqa: F401
+    mine_tr = sys.modules["whisper_amd.transcribe"]
+    from whisper_amd import decoding as mine
+    from whisper_amd.tokenizer import get_tokenizer
+    tk = get_tokenizer(True, num_languages=99, language="en", task="transcribe")
+    TB = tk.timestamp_begin
+    hello = tk.encode(" hello there")
+    fm = _fake_model(True)
+    feats = torch.arange(fm.dims.n_audio_ctx * fm.dims.n_audio_state, dtype=torch.float32).reshape(
+        fm.dims.n_audio_ctx, fm.dims.n_audio_state)
+    seen_inputs, seen_align = [], []
+
+    class M:
+        dims, is_multilingual, num_languages, device = fm.dims, True, 99, fm.device
+
+        def decode(self, segment, options):
+            seen_inputs.append((tuple(segment.shape), options.temperature))
+            bad = len(seen_inputs) == 1                     # the first attempt fails the compression-ratio test
+            return mine.DecodingResult(audio_features=feats, language="en", tokens=[TB, *hello, TB + 300],
+                                       text=" hello there", avg_logprob=-0.3, no_speech_prob=0.01,
+                                       temperature=options.temperature, compression_ratio=3.0 if bad else 1.2)
+
+    def aligner(model, tokenizer, text_tokens, mel, num_frames, **kw):
+        seen_align.append(kw.get("audio_features"))
+        return []
+    monkeypatch.setattr(mine_tr, "find_alignment", aligner)
+    filt = oracle.mel_filterbank(80)
+    monkeypatch.setattr(mine_tr, "log_mel_spectrogram", lambda a, n_mels=80, padding=0, device=None: oracle.log_mel_spectrogram(a, filt, padding=padding))
+    audio = (np.random.default_rng(0).standard_normal(16000 * 8) * 0.01).astype(np.float32)
+    r = mine_tr.transcribe(M(), audio, language="en", fp16=False, temperature=(0.0, 0.4), word_timestamps=True)
+    assert r["text"].strip() == "hello there"
+    assert seen_inputs[0] == ((80, 3000), 0.0)                                   # the mel window
+    assert seen_inputs[1] == ((fm.dims.n_audio_ctx, fm.dims.n_audio_state), 0.4)  # the retry: encoded features
+    assert len(seen_align) == 1 and seen_align[0] is feats
+
+
 def test_detect_language_host_logic_matches_reference(ref):
     """decoding.py:18-77: given the same logits at the <|startoftranscript|> position, the language mask, arg-max and
     probability dictionaries equal the reference's (v2 = 99 and v3 = 100 languages; single and batched inputs;
