@@ -287,6 +287,7 @@ struct wh_task {
   std::atomic<int> busy;   // handles are not thread-safe: a second thread entering while a call runs gets WH_ERR_STATE
   int64_t* step_tokens;
   float* samp_part;        // greedy sampler stage-1 partials
+  int* samp_state;         // [R][4] timestamp-rule state of the fused greedy loop
   void* beam_scratch;      // beam search partials / candidates (G > 1)
   int* beam_flags;         // [2][B] completion flags + [1] applied-update counter
   int* beam_lcp;           // [B][8][8] shared-history lengths of the rows of a segment + [R] first position to copy
@@ -356,6 +357,7 @@ static void task_carve(wh_task* t, void* base) {
   t->d_lag = (int*)c.take(R * 4);
   t->step_tokens = (int64_t*)c.take(R * 8);
   t->samp_part = (float*)c.take(greedy_sample_scratch_bytes((int)R, (int)V));
+  t->samp_state = (int*)c.take(R * 16);
   t->beam_scratch = t->G > 1 ? c.take(beam_scratch_bytes((int)R, (int)V)) : nullptr;
   t->beam_flags = t->G > 1 ? (int*)c.take((2 * (size_t)t->B + 1) * 4) : nullptr;
   t->beam_lcp = t->G > 1 ? (int*)c.take(((size_t)t->B * 64 + R) * 4) : nullptr;
@@ -853,6 +855,8 @@ extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* to
   sa.max_initial_ts = p->max_initial_timestamp_index; sa.suppress_blank = p->suppress_blank;
   sa.blank_token = p->blank_token; sa.suppress_mask = p->suppress_mask; sa.sum_logprobs = sum_logprobs;
   sa.step_tokens = t->step_tokens; sa.d_alive_step = t->d_alive; sa.partials = t->samp_part;
+  sa.row_state = t->samp_state;
+  HIPCHK(hipMemsetAsync(t->samp_state, 0, (size_t)R * 16, s));
   // the sampler also writes the next step's input row (token embedding + position): the step graph starts at layer 0
   static const bool fused_embed = [] { const char* e = getenv("WH_NO_FUSED_EMBED"); return !(e && e[0] == '1'); }();   // A/B switch
   if (fused_embed) {

@@ -158,6 +158,10 @@ struct SampleArgs {
   // optional: the final kernel also writes the next step's decoder input x_next[r][:] = tok_emb[token] + pos_emb[index of
   // the token] (model.py:236-240), so the step that follows needs no embedding launch; skipped when x_next is null
   float* x_next; const void* tok_emb; const float* pos_emb; int D, emb_f16, n_pos;
+  // optional: per-row timestamp-rule state kept by the final kernel, {last sampled token is a timestamp, the one before
+  // it is, value of the last sampled timestamp + 1 (0 = none), unused}, zeroed before the first sample of a sequence.
+  // With it the partial kernel does not walk the row's sampled tokens (three dependent round trips per step).
+  int* row_state;
 };
 size_t greedy_sample_scratch_bytes(int R, int V);
 hipError_t launch_greedy_sample(const SampleArgs& a, hipStream_t stream);

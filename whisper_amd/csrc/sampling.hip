@@ -106,17 +106,22 @@ __global__ __launch_bounds__(256) void greedy_partial_kernel(whk::SampleArgs a, 
   const int TB = a.timestamp_begin;       // < 0: timestamp rules disabled (without_timestamps)
   const bool ts_rules = TB >= 0;
 
-  if (tid == 0) sh_last_ts = -1;
-  __syncthreads();
-  if (ts_rules) {
-    for (int t = tid; t < L; t += 256)
-      if (row[sample_begin + t] >= TB) atomicMax(&sh_last_ts, t);
-  }
-  __syncthreads();
-
   bool last_ts = false, pen_ts = false;
   int ts_lo = 0, ts_hi = 0;              // forbidden timestamp interval [ts_lo, ts_hi)
-  if (ts_rules) {
+  if (ts_rules && a.row_state) {
+    // the final kernel of the previous step left what the rules need about this row's sampled tokens
+    const int s0 = load_agent_int(a.row_state + 4 * k), s1 = load_agent_int(a.row_state + 4 * k + 1),
+              s2 = load_agent_int(a.row_state + 4 * k + 2);
+    last_ts = (L >= 1) && uniform(s0) != 0;
+    pen_ts = (L < 2) || uniform(s1) != 0;
+    const int tv = uniform(s2);
+    if (tv > 0) { ts_lo = TB; ts_hi = (last_ts && !pen_ts) ? tv - 1 : tv; }
+  } else if (ts_rules) {
+    if (tid == 0) sh_last_ts = -1;
+    __syncthreads();
+    for (int t = tid; t < L; t += 256)
+      if (row[sample_begin + t] >= TB) atomicMax(&sh_last_ts, t);
+    __syncthreads();
     last_ts = (L >= 1) && (row[ntok - 1] >= TB);
     pen_ts = (L < 2) || (row[ntok - 2] >= TB);
     if (sh_last_ts >= 0) {
@@ -277,6 +282,13 @@ __global__ __launch_bounds__(256) void greedy_final_kernel(whk::SampleArgs a, in
     if (a.step_tokens) a.step_tokens[k] = next;
     if (next != a.eot) *a.d_alive_step = ntok + lag;      // benign race: every writer stores the same value
     sh_next = next;
+    if (a.row_state && ts_rules) {                         // what the next step's timestamp rules need about this row
+      int* st = a.row_state + 4 * k;
+      const bool is_ts = next >= a.timestamp_begin;
+      st[1] = st[0];
+      st[0] = is_ts ? 1 : 0;
+      if (is_ts) st[2] = next + 1;
+    }
   }
   if (a.x_next) {                             // the next step's input row: embedding of the token just chosen, at its index
     __syncthreads();
