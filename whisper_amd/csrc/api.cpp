@@ -282,8 +282,6 @@ struct wh_task {
   int* h_lag;              // host copy
   int* h_poll;             // pinned host word the fused loops copy the completion counter into
   hipEvent_t poll_event;   // recorded behind that copy: the loop waits for it two steps later, with work already queued
-  hipStream_t pf_stream;   // experiment WH_PREFETCH: second branch of the step graph that touches the next layer's bytes
-  hipEvent_t* pf_events;   // [n_text_layer + 1] fork events + the join event
   bool lag_on;
   bool needs_reset;        // created, position counter / lag not zeroed yet
   std::atomic<int> busy;   // handles are not thread-safe: a second thread entering while a call runs gets WH_ERR_STATE
@@ -410,11 +408,6 @@ extern "C" void wh_task_destroy(wh_task* t) {
   free(t->h_lag);
   if (t->h_poll) (void)hipHostFree(t->h_poll);
   if (t->poll_event) (void)hipEventDestroy(t->poll_event);
-  if (t->pf_events) {
-    for (int i = 0; i <= t->m->d.n_text_layer; ++i) (void)hipEventDestroy(t->pf_events[i]);
-    free(t->pf_events);
-  }
-  if (t->pf_stream) (void)hipStreamDestroy(t->pf_stream);
   delete t;
 }
 
@@ -671,44 +664,9 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
   const size_t es = m->esize;
   if (!embedded)
     HIPCHK(launch_embed(t->step_tokens, 1, R, 1, m->w.tok_emb, m->w.dec_pos, t->d_pos, t->d_lag, D, V, t->x, m->dtype, s));
-  // EXPERIMENT, off by default (WH_PREFETCH = bit mask: 1 next layer's weights, 2 its cross K/V, 4 streaming-hint loads;
-  // WH_PREFETCH_WGS workgroups, default 256): a second branch per layer that touches what the NEXT layer will stream so
-  // that it sits in the Infinity Cache when the chain reaches it.  Read per capture so that one process can A/B it.
-  int pf = 0, pf_wgs = 256;
-  if (s != nullptr) {
-    const char* e = getenv("WH_PREFETCH"); pf = e ? atoi(e) : 0;
-    const char* w = getenv("WH_PREFETCH_WGS"); if (w && atoi(w) > 0) pf_wgs = atoi(w);
-  }
-  if (pf && !t->pf_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&t->pf_stream, hipStreamNonBlocking));
-    t->pf_events = (hipEvent_t*)calloc((size_t)d.n_text_layer + 1, sizeof(hipEvent_t));
-    if (!t->pf_events) return WH_ERR_ARG;
-    for (int i = 0; i <= d.n_text_layer; ++i) HIPCHK(hipEventCreateWithFlags(&t->pf_events[i], hipEventDisableTiming));
-  }
   for (int l = 0; l < d.n_text_layer; ++l) {
     const wh_layer_weights& L = m->dec[l];
     GemvArgs g;
-    if (pf) {
-      const int nl = (l + 1) % d.n_text_layer;      // the last layer's branch touches layer 0 for the next step
-      const wh_layer_weights& N = m->dec[nl];
-      TouchArgs ta; memset(&ta, 0, sizeof(ta));
-      ta.nt = (pf & 4) ? 1 : 0;
-      const int64_t dd = (int64_t)D * D * (int64_t)es / 16;
-      if (pf & 1) {
-        ta.p[ta.n] = N.qkv_w; ta.units[ta.n++] = 3 * dd;
-        ta.p[ta.n] = N.out_w; ta.units[ta.n++] = dd;
-        ta.p[ta.n] = N.cq_w; ta.units[ta.n++] = dd;
-      }
-      if (pf & 2) { ta.p[ta.n] = cross_layer(t, nl); ta.units[ta.n++] = (int64_t)t->B * Ta * 2 * D * (int64_t)es / 16; }
-      if (pf & 1) {
-        ta.p[ta.n] = N.cout_w; ta.units[ta.n++] = dd;
-        ta.p[ta.n] = N.fc1_w; ta.units[ta.n++] = 4 * dd;
-        ta.p[ta.n] = N.fc2_w; ta.units[ta.n++] = 4 * dd;
-      }
-      HIPCHK(hipEventRecord(t->pf_events[l], s));
-      HIPCHK(hipStreamWaitEvent(t->pf_stream, t->pf_events[l], 0));
-      HIPCHK(launch_touch(ta, pf_wgs, t->pf_stream));
-    }
     // LN -> QKV, K/V appended in place at *d_pos
     memset(&g, 0, sizeof(g));
     g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.attn_ln_w; g.ln_b = L.attn_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
@@ -782,10 +740,6 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
     g.epi = EPI_F32; g.y = t->logits; g.y_ld = V;
     g.bump = t->d_pos; g.bump_by = 1;         // the last kernel of the step advances the position counter
     HIPCHK(launch_gemv(g, m->dtype, s));
-  }
-  if (pf) {                                   // join the branch: the step (and a capture) ends on `s`
-    HIPCHK(hipEventRecord(t->pf_events[d.n_text_layer], t->pf_stream));
-    HIPCHK(hipStreamWaitEvent(s, t->pf_events[d.n_text_layer], 0));
   }
   return WH_OK;
 }

@@ -197,26 +197,6 @@ __global__ __launch_bounds__(256) void permute_group_kernel(uint4v* __restrict__
 
 __global__ void add_int_kernel(int* p, int v) { *p += v; }
 
-// EXPERIMENT (api.cpp, WH_PREFETCH): touches up to 8 byte ranges so that they sit in the 256 MB Infinity Cache when the
-// decode chain reaches them.  Every lane keeps 8 x 16 B requests in flight; nothing is written.
-__global__ __launch_bounds__(256) void touch_kernel(whk::TouchArgs a) {
-  const int64_t T = (int64_t)gridDim.x * 256, g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  for (int i = 0; i < a.n; ++i) {
-    const uint4v* src = (const uint4v*)a.p[i];
-    const int64_t n = a.units[i];
-    for (int64_t u = g; u < n; u += T * 8) {
-      uint4v v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        int64_t k = u + j * T; if (k > n - 1) k = n - 1;
-        v[j] = a.nt ? __builtin_nontemporal_load(src + k) : src[k];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(v[j][0]));
-    }
-  }
-}
-
 }  // namespace
 
 namespace whk {
@@ -301,12 +281,6 @@ hipError_t launch_permute_groups(void* k_base, void* v_base, int n_layers, int64
 
 hipError_t launch_add_int(int* p, int v, hipStream_t stream) {
   hipLaunchKernelGGL(add_int_kernel, dim3(1), dim3(1), 0, stream, p, v);
-  return hipGetLastError();
-}
-
-hipError_t launch_touch(const TouchArgs& a, int workgroups, hipStream_t stream) {
-  if (a.n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(touch_kernel, dim3(workgroups), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -64,9 +64,6 @@ hipError_t launch_permute_groups(void* k_base, void* v_base, int n_layers, int64
                                  int64_t row_bytes, int64_t used_bytes, const int* src_idx, const int* copy_from,
                                  int64_t pos_bytes, hipStream_t stream);
 hipError_t launch_add_int(int* p, int v, hipStream_t stream);
-// experiment: read-only touch of byte ranges (16-byte units) from a second graph branch
-struct TouchArgs { const void* p[8]; int64_t units[8]; int n; int nt; };
-hipError_t launch_touch(const TouchArgs& a, int workgroups, hipStream_t stream);
 
 // ---- attention.hip -------------------------------------------------------------------------
 struct AttnArgs {
