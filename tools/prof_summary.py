@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 rocpd sqlite database (kernel trace): per-kernel calls / total / avg / min / max.
 
-  python tools/prof_summary.py gpurun_out/prof/x_results.db [--csv out.csv] [--grid]
+  python tools/prof_summary.py gpurun_out/prof/x_results.db [--csv out.csv] [--grid | --pmc | --gaps]
 rocprofv3 in this image writes `*_results.db` by default; `--output-format csv` gives kernel_stats.csv directly.
 """
 import re
@@ -29,9 +29,28 @@ def pmc_summary(c, out_csv):
     print(txt)
 
 
+def gaps_summary(c, out_csv):
+    """idle time between consecutive kernels (next.start - prev.end), grouped by the (previous, next) kernel pair:
+    what a launch boundary costs inside a graph, between a graph and an eager launch, ..."""
+    rows = c.execute("select name, start, end from kernels order by start").fetchall()
+    pairs = {}
+    for (n0, _, e0), (n1, s1, _) in zip(rows, rows[1:]):
+        pairs.setdefault((short(n0)[:48], short(n1)[:48]), []).append((s1 - e0) / 1e3)
+    out = ["previous,next,count,median_gap_us,avg_gap_us,total_gap_ms"]
+    for (a, b), g in sorted(pairs.items(), key=lambda kv: -sum(kv[1])):
+        g.sort()
+        out.append(f'"{a}","{b}",{len(g)},{g[len(g) // 2]:.2f},{sum(g) / len(g):.2f},{sum(g) / 1e3:.3f}')
+    txt = "\n".join(out)
+    if out_csv:
+        open(out_csv, "w").write(txt + "\n")
+    print(txt)
+
+
 def main():
     db = sys.argv[1]
     c = sqlite3.connect(db)
+    if "--gaps" in sys.argv:
+        return gaps_summary(c, sys.argv[sys.argv.index("--csv") + 1] if "--csv" in sys.argv else None)
     if "--pmc" in sys.argv:
         return pmc_summary(c, sys.argv[sys.argv.index("--csv") + 1] if "--csv" in sys.argv else None)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]

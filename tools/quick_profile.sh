@@ -7,5 +7,6 @@ rm -rf /tmp/prof_q
 rocprofv3 --kernel-trace --stats -d /tmp/prof_q -o q -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline "$@" > $R/gpurun_out/${TAG}_prof.log 2>&1
 K=$(find /tmp/prof_q -name "*_results.db" | head -n 1)
 python $R/tools/prof_summary.py $K --grid --csv $R/gpurun_out/${TAG}_kernel_stats.csv > /dev/null 2>&1
+python $R/tools/prof_summary.py $K --gaps --csv $R/gpurun_out/${TAG}_gaps.csv > /dev/null 2>&1
 grep -E "timed|value" $R/gpurun_out/${TAG}_prof.log | cut -c1-200
 head -n 24 $R/gpurun_out/${TAG}_kernel_stats.csv | cut -c1-170
