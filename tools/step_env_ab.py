@@ -1,6 +1,9 @@
 # In-process A/B of decode-step switches that api.cpp reads per call / per capture: one process, one model, a fresh task
 # (fresh step graphs) per variant, large-v3 x 8 rows, 224 greedy steps; token ids compared with the first variant.
-#   python tools/step_env_ab.py base WH_SAMPLER_EAGER=1 base
+#   python tools/step_env_ab.py base SOME_SWITCH=1 base
+# The product's own switches (tools/README.md) are read once per process: for those run the script once per setting
+# (`WH_GEMV_DOT2=1 python tools/step_env_ab.py base`).
+# (WH_SAMPLER_EAGER of profiles/r02_probe_sampler_in_graph.txt existed in the library of commit dc21f41 only)
 # (the WH_PREFETCH experiment of profiles/r02_probe_prefetch.txt ran through an earlier form of this script on the
 #  library of commit 9ffca92, variants `0 1 2 3 7 3:128 3:512 0` = WH_PREFETCH[:WH_PREFETCH_WGS]; that switch was removed)
 import sys, os, time
@@ -10,7 +13,7 @@ from whisper_amd import hip
 from whisper_amd.synthetic import dims_for, synthetic_state_dict
 from whisper_amd.tokenizer import get_tokenizer
 dev = torch.device("cuda:0")
-variants = sys.argv[1:] or ["base", "WH_SAMPLER_EAGER=1", "base"]
+variants = sys.argv[1:] or ["base", "base"]
 B, N = 8, 224
 dims = dims_for("large-v3")
 sd = synthetic_state_dict(dims, seed=0, device=dev)

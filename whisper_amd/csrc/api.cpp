@@ -263,14 +263,10 @@ struct wh_task {
   int B, G, R, Tmax, flags;
   int pos;                 // host mirror of *d_pos
   bool audio_set;
-  // the decode step exists in four captured forms: [0] starts with the token embedding of `step_tokens` (host-driven
-  // steps, beam search); [1] starts at layer 0 because the greedy sampler of the previous step already wrote x;
-  // [2] / [3] are [1] followed by the two sampler launches (arg-max / temperature form) — the fused greedy loop replays
-  // one graph per token, and a call with other sampler arguments rewrites the two nodes' parameters, not the graph
-  int steps_eager[4];      // decode steps launched without a graph (first one warms up attributes)
-  hipGraph_t graph[4]; hipGraphExec_t graph_exec[4];
-  hipGraphNode_t samp_node[4][2];   // the sampler's kernel nodes in forms [2], [3]
-  SampleArgs samp_args[4];          // the arguments those nodes currently hold
+  // the decode step exists in two captured forms: [0] starts with the token embedding of `step_tokens` (host-driven
+  // steps, beam search), [1] starts at layer 0 because the greedy sampler of the previous step already wrote x
+  int steps_eager[2];      // decode steps launched without a graph (first one warms up attributes)
+  hipGraph_t graph[2]; hipGraphExec_t graph_exec[2];
   // device buffers (carved from the caller's workspace)
   void* cross_kv;          // [L][B*Ta][2D]
   void* cross_vt;          // beam groups, fp16: [L][B][D][vt_ld], V transposed (row = head dim, column = key) for the
@@ -405,7 +401,7 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
 
 extern "C" void wh_task_destroy(wh_task* t) {
   if (!t) return;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 2; ++i) {
     if (t->graph_exec[i]) (void)hipGraphExecDestroy(t->graph_exec[i]);
     if (t->graph[i]) (void)hipGraphDestroy(t->graph[i]);
   }
@@ -754,65 +750,24 @@ static bool graphs_enabled() {
   return v == 1;
 }
 
-// gives the sampler nodes of captured form `gi` the arguments `sa`
-static int sampler_nodes_update(wh_task* t, int gi, const SampleArgs& sa) {
-  SampleArgs a; memcpy(&a, &sa, sizeof(a));
-  int nchunk = greedy_sample_chunks(a.V);
-  void* kp[2] = {&a, &nchunk};
-  for (int i = 0; i < 2; ++i) {
-    hipKernelNodeParams p; memset(&p, 0, sizeof(p));
-    HIPCHK(hipGraphKernelNodeGetParams(t->samp_node[gi][i], &p));
-    p.kernelParams = kp; p.extra = nullptr;
-    HIPCHK(hipGraphExecKernelNodeSetParams(t->graph_exec[gi], t->samp_node[gi][i], &p));
-  }
-  memcpy(&t->samp_args[gi], &sa, sizeof(sa));
-  return WH_OK;
-}
-
-// runs one step from t->step_tokens into t->logits; with `sa` (fused greedy loop, embedded form only) the two sampler
-// launches over those logits follow in the same graph
-static int step_run(wh_task* t, hipStream_t s, bool embedded = false, const SampleArgs* sa = nullptr) {
+// runs one step from t->step_tokens into t->logits
+static int step_run(wh_task* t, hipStream_t s, bool embedded = false) {
   if (t->pos <= 0) return WH_ERR_STATE;
   if (t->pos + 1 > t->m->d.n_text_ctx) return WH_ERR_ARG;
   int rc;
-  const int gi = !embedded ? 0 : !sa ? 1 : sa->inv_temperature > 0.f ? 3 : 2;
+  const int gi = embedded ? 1 : 0;
   if (t->graph_exec[gi]) {
-    if (sa && memcmp(&t->samp_args[gi], sa, sizeof(*sa)) != 0) {
-      rc = sampler_nodes_update(t, gi, *sa);
-      if (rc != WH_OK) return rc;
-    }
     HIPCHK(hipGraphLaunch(t->graph_exec[gi], s));
   } else if (s == nullptr || !graphs_enabled() || t->steps_eager[gi] < 1) {
     rc = step_launch(t, s, embedded);
     if (rc != WH_OK) return rc;
-    if (sa) HIPCHK(launch_greedy_sample(*sa, s));
     t->steps_eager[gi]++;
   } else {
     HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     rc = step_launch(t, s, embedded);
-    hipError_t es = (rc == WH_OK && sa) ? launch_greedy_sample(*sa, s) : hipSuccess;
     hipError_t e = hipStreamEndCapture(s, &t->graph[gi]);
     if (rc != WH_OK) return rc;
-    HIPCHK(es);
     HIPCHK(e);
-    if (sa) {                                  // remember the sampler's two nodes
-      size_t n = 0;
-      HIPCHK(hipGraphGetNodes(t->graph[gi], nullptr, &n));
-      std::vector<hipGraphNode_t> nodes(n);
-      HIPCHK(hipGraphGetNodes(t->graph[gi], nodes.data(), &n));
-      int found = 0;
-      for (size_t i = 0; i < n; ++i) {
-        hipGraphNodeType ty;
-        HIPCHK(hipGraphNodeGetType(nodes[i], &ty));
-        if (ty != hipGraphNodeTypeKernel) continue;
-        hipKernelNodeParams p; memset(&p, 0, sizeof(p));
-        HIPCHK(hipGraphKernelNodeGetParams(nodes[i], &p));
-        const int kind = greedy_sample_kernel_kind(p.func);
-        if (kind) { t->samp_node[gi][kind - 1] = nodes[i]; found |= kind; }
-      }
-      if (found != 3) return WH_ERR_STATE;
-      memcpy(&t->samp_args[gi], sa, sizeof(*sa));
-    }
     HIPCHK(hipGraphInstantiate(&t->graph_exec[gi], t->graph[gi], nullptr, nullptr, 0));
     HIPCHK(hipGraphLaunch(t->graph_exec[gi], s));
   }
@@ -908,8 +863,6 @@ extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* to
     sa.x_next = t->x; sa.tok_emb = t->m->w.tok_emb; sa.pos_emb = t->m->w.dec_pos; sa.D = d.n_text_state;
     sa.emb_f16 = t->m->dtype == WH_F16 ? 1 : 0; sa.n_pos = d.n_text_ctx;
   }
-  const char* samp_eager = getenv("WH_SAMPLER_EAGER");           // read per call: one process can A/B it
-  const bool samp_in_graph = fused_embed && !(samp_eager && samp_eager[0] == '1');
   if (p->temperature > 0.f) {
     sa.inv_temperature = 1.0f / p->temperature;
     sa.seed_lo = (uint32_t)(p->seed & 0xffffffffu); sa.seed_hi = (uint32_t)(p->seed >> 32);
@@ -928,11 +881,9 @@ extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* to
   bool pending = false;
   int ntok_at_copy = 0;
   while (steps < p->max_steps && ntok <= p->n_ctx && ntok <= d.n_text_ctx) {
-    // one graph per token: the step and the sampler over its logits (A/B: WH_SAMPLER_EAGER=1 or WH_NO_FUSED_EMBED=1
-    // launch the two sampler kernels behind the step graph instead)
-    rc = step_run(t, s, fused_embed, samp_in_graph ? &sa : nullptr);
+    rc = step_run(t, s, fused_embed);
     if (rc != WH_OK) return rc;
-    if (!samp_in_graph) HIPCHK(launch_greedy_sample(sa, s));
+    HIPCHK(launch_greedy_sample(sa, s));
     ++ntok; ++steps;
     if (pending && (steps & 7) == 2) {
       HIPCHK(hipEventSynchronize(t->poll_event));

@@ -165,8 +165,6 @@ struct SampleArgs {
 };
 size_t greedy_sample_scratch_bytes(int R, int V);
 hipError_t launch_greedy_sample(const SampleArgs& a, hipStream_t stream);
-int greedy_sample_kernel_kind(const void* func);   // 1: stage-1 kernel, 2: decision kernel, 0: neither (graph node lookup)
-int greedy_sample_chunks(int V);                    // the second kernel argument of both
 hipError_t launch_no_speech(const float* logits_row0, int64_t row_stride, int R, int V, int no_speech,
                             float* out, hipStream_t stream);
 // dst[r] = src[r*stride]

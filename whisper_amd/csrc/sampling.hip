@@ -376,15 +376,6 @@ hipError_t launch_greedy_sample(const SampleArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// The fused greedy loop captures the two sampler launches behind the decode step (api.cpp::step_run); these two let it
-// find the nodes in the captured graph and give them new arguments without a re-capture.
-int greedy_sample_kernel_kind(const void* func) {
-  if (func == (const void*)greedy_partial_kernel<false> || func == (const void*)greedy_partial_kernel<true>) return 1;
-  if (func == (const void*)greedy_final_kernel<false> || func == (const void*)greedy_final_kernel<true>) return 2;
-  return 0;
-}
-int greedy_sample_chunks(int V) { return (V + SCHUNK - 1) / SCHUNK; }
-
 hipError_t launch_no_speech(const float* logits, int64_t row_stride, int R, int V, int no_speech,
                             float* out, hipStream_t stream) {
   hipLaunchKernelGGL(no_speech_kernel, dim3(R), dim3(1024), 0, stream, logits, row_stride, V, no_speech, out);
