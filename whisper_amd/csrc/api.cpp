@@ -713,7 +713,13 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
       HIPCHK(launch_attn_decode(a, m->dtype, s));
     }
     memset(&g, 0, sizeof(g));
-    if (t->cross_splits > 1) {
+    // 17+ rows (beam search): the projection runs as 16-row workgroups that would each merge their rows' partials
+    // again, so the merge is a launch of its own there (A/B: WH_NO_MERGE_KERNEL=1)
+    static const bool merge_kernel = [] { const char* e = getenv("WH_NO_MERGE_KERNEL"); return !(e && e[0] == '1'); }();
+    if (t->cross_splits > 1 && R > 16 && m->dtype == WH_F16 && merge_kernel) {   // the fp32 engine keeps one code path
+      HIPCHK(launch_merge_partials(t->part_o, t->part_ml, t->cross_splits, R, H, t->att, D, m->dtype, s));
+      g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D;
+    } else if (t->cross_splits > 1) {
       g.pro = PRO_COMBINE; g.part_o = t->part_o; g.part_ml = t->part_ml; g.splits = t->cross_splits; g.H = H;
     } else {
       g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D;

@@ -139,6 +139,9 @@ struct GemvArgs {
   WH_PROBE_FIELD
 };
 hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream);
+// PRO_COMBINE's merge of the decode-attention partials as a launch of its own ([rows][H*64] in the element type)
+hipError_t launch_merge_partials(const void* part_o, const float* part_ml, int splits, int R, int H, void* out,
+                                 int64_t o_ld, int dtype, hipStream_t stream);
 
 // ---- sampling.hip --------------------------------------------------------------------------
 struct SampleArgs {
