@@ -96,7 +96,10 @@ int main() {
   {  // encoder flash attention: B = 8, H = 20, T = 1500 (q,k row-major [T][2D], V^T [D][1536])
     const int B = 8, H = 20, T = 1500;
     half_t* qk = A; half_t* vt = W; half_t* o = C16;
-    for (int pre = 0; pre < 2; ++pre) {
+    std::vector<half_t> ref((size_t)B * T * D), got((size_t)B * T * D);
+    const int modes[4] = {2, 3, 1, 3};             // bit 0: pre-scaled q,k; bit 1: plain V^T tile layout (the product stores it in P order)
+    for (int mi = 0; mi < 4; ++mi) {
+      const int pre = modes[mi];
       float best = 1e30f;
       for (int rep = 0; rep < 6; ++rep) {
         CK(hipEventRecord(e0, st));
@@ -109,7 +112,19 @@ int main() {
         if (rep > 0 && t < best) best = t;
       }
       const double us = best * 1e3 / 10, tf = 4.0 * T * T * 64 * H * B / us * 1e-6;
-      printf("flash attention B=8 H=20 T=1500 %s %8.1f us  %7.1f TFLOP/s  (%.1f %% of 2500)\n", pre ? "prescaled q,k" : "unscaled q,k ", us, tf, tf / 25.0);
+      printf("flash attention B=8 H=20 T=1500 %s%s %8.1f us  %7.1f TFLOP/s  (%.1f %% of 2500)\n", (pre & 1) ? "prescaled q,k" : "unscaled q,k ",
+             (pre & 2) ? ", plain V^T tile" : "                 ", us, tf, tf / 25.0);
+      if (pre == 3 && mi == 1) CK(hipMemcpy(ref.data(), o, ref.size() * 2, hipMemcpyDeviceToHost));
+      if (pre == 1) {
+        CK(hipMemcpy(got.data(), o, got.size() * 2, hipMemcpyDeviceToHost));
+        size_t diff = 0, nan = 0; double mx = 0;
+        for (size_t i = 0; i < got.size(); ++i) {
+          const float a = (float)ref[i], b = (float)got[i];
+          if (a != a || b != b) { ++nan; continue; }
+          if (memcmp(&ref[i], &got[i], 2) != 0) { ++diff; if (fabs(a - b) > mx) mx = fabs(a - b); }
+        }
+        printf("  P-order V^T tile vs plain layout: %zu of %zu outputs differ (max |diff| %.3g), %zu NaN\n", diff, got.size(), mx, nan);
+      }
     }
   }
   return 0;

@@ -143,7 +143,14 @@ constexpr int FQ = FW * 32;          // queries per workgroup (32 per wave)
 // start at -m_ref instead of 0 and p = exp2(acc) needs no multiply-subtract, and the row sums are taken from the fp16
 // P two at a time (v_dot2_f32_f16).  Per 32 x 64 score tile that leaves 32 v_exp + 16 v_cvt_pk + 16 v_dot2 + 16 v_max3
 // on the vector ALU (the bound of this loop) where the unscaled form has 32 v_fma + 32 v_add instead of the v_dot2.
-template <bool PRESCALED>
+// VTP: the V^T tile is stored in LDS with the 4-key halves of neighbouring 16-byte units exchanged — unit 2m holds keys
+// {0-3, 8-11} of its 16-key group, unit 2m+1 keys {4-7, 12-15} — which is the order the score MFMA leaves P in, so a
+// lane's V^T fragment is ONE ds_read_b128 (4 LDS cycles, conflict-free under the row swizzle) instead of a
+// ds_read2_b64 (8 cycles; profiles/r02_pmc_lds.csv: a third of this kernel's LDS cycles were counted as conflicts).
+// The tile store becomes two ds_write_b64 per unit.  Pure data movement: the output is bit-identical to the plain
+// layout (tools/probe_gemm compares all 15.4 M outputs of the large-v3 shape), 143.9 -> 134.3 us per launch.
+// VTP = false keeps the plain layout for that comparison (launch mode bit 1).
+template <bool PRESCALED, bool VTP = true>
 __global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f16_kernel(
     const half_t* __restrict__ q, int64_t q_ld, int64_t q_bs, const half_t* __restrict__ k, int64_t k_ld,
     int64_t k_bs, const half_t* __restrict__ vt, int64_t vt_ld, int64_t vt_bs, half_t* __restrict__ out,
@@ -214,7 +221,12 @@ __global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f
       const int u = tid + FW * 64 * j;
       const int row = u >> 3, cu = u & 7;
       *(uint4v*)(sK + swz_byte(row, cu)) = kreg[j];
-      *(uint4v*)(sV + swz_byte(row, cu)) = vreg[j];
+      if constexpr (VTP) {
+        *(uint2v*)(sV + swz_byte(row, cu & ~1) + (cu & 1) * 8) = uint2v{vreg[j][0], vreg[j][1]};
+        *(uint2v*)(sV + swz_byte(row, cu | 1) + (cu & 1) * 8) = uint2v{vreg[j][2], vreg[j][3]};
+      } else {
+        *(uint4v*)(sV + swz_byte(row, cu)) = vreg[j];
+      }
     }
   };
 
@@ -318,9 +330,14 @@ __global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const int unit = kb * 4 + 2 * s2;
-          const half4v v0 = *(const half4v*)(sV + swz_byte(drow, unit) + hi * 8);
-          const half4v v1 = *(const half4v*)(sV + swz_byte(drow, unit + 1) + hi * 8);
-          const half8v vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          half8v vf;
+          if constexpr (VTP) {
+            vf = *(const half8v*)(sV + swz_byte(drow, unit + hi));
+          } else {
+            const half4v v0 = *(const half4v*)(sV + swz_byte(drow, unit) + hi * 8);
+            const half4v v1 = *(const half4v*)(sV + swz_byte(drow, unit + 1) + hi * 8);
+            vf = half8v{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          }
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s2], oacc[dt], 0, 0, 0);
         }
     }
@@ -865,12 +882,17 @@ hipError_t launch_attn_flash_f16(const void* q, int64_t q_ld, int64_t q_bs, cons
                                  int64_t k_bs, const void* vt, int64_t vt_ld, int64_t vt_bs, void* out,
                                  int64_t o_ld, int64_t o_bs, int B, int H, int T, int prescaled, hipStream_t stream) {
   dim3 grid((T + FQ - 1) / FQ, H, B), block(FW * 64);
-  if (prescaled)
-    hipLaunchKernelGGL(attn_flash_f16_kernel<true>, grid, block, 0, stream, (const half_t*)q, q_ld, q_bs,
-                       (const half_t*)k, k_ld, k_bs, (const half_t*)vt, vt_ld, vt_bs, (half_t*)out, o_ld, o_bs, T);
-  else
-    hipLaunchKernelGGL(attn_flash_f16_kernel<false>, grid, block, 0, stream, (const half_t*)q, q_ld, q_bs,
-                       (const half_t*)k, k_ld, k_bs, (const half_t*)vt, vt_ld, vt_bs, (half_t*)out, o_ld, o_bs, T);
+#define WH_FLASH_LAUNCH(P, V)                                                                                          \
+  hipLaunchKernelGGL((attn_flash_f16_kernel<P, V>), grid, block, 0, stream, (const half_t*)q, q_ld, q_bs,              \
+                     (const half_t*)k, k_ld, k_bs, (const half_t*)vt, vt_ld, vt_bs, (half_t*)out, o_ld, o_bs, T)
+  // prescaled: bit 0 = q, k carry the softmax scale; bit 1 (tools/probe_gemm only) = plain V^T tile layout in LDS
+  switch (prescaled & 3) {
+    case 0: WH_FLASH_LAUNCH(false, true); break;
+    case 1: WH_FLASH_LAUNCH(true, true); break;
+    case 2: WH_FLASH_LAUNCH(false, false); break;
+    default: WH_FLASH_LAUNCH(true, false); break;
+  }
+#undef WH_FLASH_LAUNCH
   return hipGetLastError();
 }
 
