@@ -266,76 +266,86 @@ def main():
 
     # ---- the same workload through the public drop-in surface ----------------------------------------------------
     if rank == 0 and world == 1 and not args.no_extras:      # single-GPU runs only: the scaling runs stay short
-        wmodel = Whisper(ModelDimensions(**dims_dict(dims)), {}, device=device)
-        wmodel.adopt_engine(torch.float16, model)
-        opts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=N, suppress_tokens=[-1, tok.eot])
+        try:
+            wmodel = Whisper(ModelDimensions(**dims_dict(dims)), {}, device=device)
+            wmodel.adopt_engine(torch.float16, model)
+            opts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=N, suppress_tokens=[-1, tok.eot])
 
-        def api_pass():
-            mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
-            return whisper_amd.decode(wmodel, mel, opts)
+            def api_pass():
+                mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
+                return whisper_amd.decode(wmodel, mel, opts)
 
-        res = api_pass()
-        torch.cuda.synchronize(device)
-        same = all(r.tokens == direct_tokens[i, T0:].tolist() for i, r in enumerate(res))
-        reps = max(2, min(args.steps, 5))
-        t0 = time.perf_counter()
-        for _ in range(reps):
             res = api_pass()
-        torch.cuda.synchronize(device)
-        api_ms = (time.perf_counter() - t0) / reps * 1e3
-        out["public_api"] = {"ms_per_step": round(api_ms, 3), "vs_direct": round(api_ms / ms_per_step, 4),
-                             "tokens_equal_direct": bool(same),
-                             "path": "whisper_amd.log_mel_spectrogram + whisper_amd.decode(model, mel, DecodingOptions(fp16=True, sample_len=N))"}
-        log(f"public API leg: {api_ms:.1f} ms per pass ({api_ms / ms_per_step:.3f} x direct), tokens equal: {same}")
-
-        extras = {}
-        # BASELINE configs[3] shape: beam search (beam 5) on this GPU's clips, device-side beam loop
-        if args.beam >= 2:
-            bopts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=args.beam_steps, beam_size=args.beam,
-                                                suppress_tokens=[-1, tok.eot])
-            mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
-            whisper_amd.decode(wmodel, mel, bopts)
             torch.cuda.synchronize(device)
+            same = all(r.tokens == direct_tokens[i, T0:].tolist() for i, r in enumerate(res))
+            reps = max(2, min(args.steps, 5))
             t0 = time.perf_counter()
-            for _ in range(2):
+            for _ in range(reps):
+                res = api_pass()
+            torch.cuda.synchronize(device)
+            api_ms = (time.perf_counter() - t0) / reps * 1e3
+            out["public_api"] = {"ms_per_step": round(api_ms, 3), "vs_direct": round(api_ms / ms_per_step, 4),
+                                 "tokens_equal_direct": bool(same),
+                                 "path": "whisper_amd.log_mel_spectrogram + whisper_amd.decode(model, mel, DecodingOptions(fp16=True, sample_len=N))"}
+            log(f"public API leg: {api_ms:.1f} ms per pass ({api_ms / ms_per_step:.3f} x direct), tokens equal: {same}")
+
+            extras = {}
+            # BASELINE configs[3] shape: beam search (beam 5) on this GPU's clips, device-side beam loop
+            if args.beam >= 2:
+                bopts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=args.beam_steps, beam_size=args.beam,
+                                                    suppress_tokens=[-1, tok.eot])
                 mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
                 whisper_amd.decode(wmodel, mel, bopts)
-            torch.cuda.synchronize(device)
-            bms = (time.perf_counter() - t0) / 2 * 1e3
-            extras["beam_search"] = {"beam_size": args.beam, "clips": B, "rows": B * args.beam, "steps": args.beam_steps,
-                                     "ms_per_pass": round(bms, 2), "audio_s_per_s": round(30.0 * B / (bms * 1e-3), 1)}
-            log(f"beam {args.beam}: {bms:.1f} ms per pass of {B} clips x {args.beam_steps} steps")
-        # BASELINE configs[4] shape: word timestamps (cross-attention alignment + DTW) for every clip of the batch
-        if args.word_timestamps:
-            from whisper_amd.timing import find_alignment_batch
-            mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
-            text = [[t for t in r.tokens if t < tok.eot][:200] for r in res]
-            find_alignment_batch(wmodel, tok, text, mel.half(), [3000] * B)
-            torch.cuda.synchronize(device)
-            t0 = time.perf_counter()
-            for _ in range(2):
-                al = find_alignment_batch(wmodel, tok, text, mel.half(), [3000] * B)
-            torch.cuda.synchronize(device)
-            wms = (time.perf_counter() - t0) / 2 * 1e3
-            extras["word_timestamps"] = {"clips": B, "text_tokens_per_clip": len(text[0]), "ms_per_batch": round(wms, 2),
-                                         "words": sum(len(a) for a in al),
-                                         "note": "find_alignment_batch: encoder + one teacher-forced pass + alignment heads QK + DTW"}
-            log(f"word timestamps: {wms:.1f} ms per batch of {B} clips")
-        out["extras"] = extras
-        wmodel = None
-        # BASELINE configs[1] (base, 1 clip, greedy) and configs[4] (turbo, 32 clips, greedy + word timestamps) at their own
-        # model dims, through the public API; weights generated on the device
-        if args.other_configs and args.model == "large-v3":
-            task_bytes = model.task_cache_bytes
-            model.drop_cached_tasks()
-            extras["other_configs"] = other_configs(device, N)
-            model.task_cache_bytes = task_bytes
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
+                    whisper_amd.decode(wmodel, mel, bopts)
+                torch.cuda.synchronize(device)
+                bms = (time.perf_counter() - t0) / 2 * 1e3
+                extras["beam_search"] = {"beam_size": args.beam, "clips": B, "rows": B * args.beam, "steps": args.beam_steps,
+                                         "ms_per_pass": round(bms, 2), "audio_s_per_s": round(30.0 * B / (bms * 1e-3), 1)}
+                log(f"beam {args.beam}: {bms:.1f} ms per pass of {B} clips x {args.beam_steps} steps")
+            # BASELINE configs[4] shape: word timestamps (cross-attention alignment + DTW) for every clip of the batch
+            if args.word_timestamps:
+                from whisper_amd.timing import find_alignment_batch
+                mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
+                text = [[t for t in r.tokens if t < tok.eot][:200] for r in res]
+                find_alignment_batch(wmodel, tok, text, mel.half(), [3000] * B)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    al = find_alignment_batch(wmodel, tok, text, mel.half(), [3000] * B)
+                torch.cuda.synchronize(device)
+                wms = (time.perf_counter() - t0) / 2 * 1e3
+                extras["word_timestamps"] = {"clips": B, "text_tokens_per_clip": len(text[0]), "ms_per_batch": round(wms, 2),
+                                             "words": sum(len(a) for a in al),
+                                             "note": "find_alignment_batch: encoder + one teacher-forced pass + alignment heads QK + DTW"}
+                log(f"word timestamps: {wms:.1f} ms per batch of {B} clips")
+            out["extras"] = extras
+            wmodel = None
+            # BASELINE configs[1] (base, 1 clip, greedy) and configs[4] (turbo, 32 clips, greedy + word timestamps) at their own
+            # model dims, through the public API; weights generated on the device
+            if args.other_configs and args.model == "large-v3":
+                task_bytes = model.task_cache_bytes
+                model.drop_cached_tasks()
+                extras["other_configs"] = other_configs(device, N)
+                model.task_cache_bytes = task_bytes
+        except Exception as e:      # the optional legs never cost the headline line: report and go on
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            out.setdefault("extras", {})["error"] = f"{type(e).__name__}: {e}"[:300]
 
     # ---- CPU baseline: the oracle (fp32 torch-CPU restatement of the reference) on this box's host cores ----
     if want_cpu:
-        base, parity = cpu_baseline(args, dims, init, suppress, tok, audio[:1].cpu().numpy(), sd_cpu, hip_row0)
-        out["cpu_baseline"] = base
-        out["parity"] = parity
+        try:
+            base, parity = cpu_baseline(args, dims, init, suppress, tok, audio[:1].cpu().numpy(), sd_cpu, hip_row0)
+            out["cpu_baseline"] = base
+            out["parity"] = parity
+        except Exception as e:          # never at the price of the measured line
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            out["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         print(json.dumps(out), flush=True)
