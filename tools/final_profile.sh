@@ -21,3 +21,6 @@ if [ -x $R/tools/probe_gemm ]; then
     [ -x $R/tools/probe_gemm_p ] && { echo "== phase stamps (-DWH_PROBE): 1 first K tile landed, 2 K loop done, 3 ring free, 5 stores issued, 7 next tile's first K tile landed"; timeout 90 $R/tools/probe_gemm_p | head -n 6; }
   } > $O/probe_gemm.txt 2>&1
 fi
+# flash-attention tile layout check (product layout vs plain, bit for bit) and the LDS counters of the encoder kernels
+[ -x $R/tools/probe_flash_layout ] && timeout 60 $R/tools/probe_flash_layout > $O/probe_flash_layout.txt 2>&1
+[ -x $R/tools/probe_gemm ] && bash $R/tools/pmc_lds.sh final > /dev/null 2>&1 && cp $R/gpurun_out/final_pmc_lds.csv $O/pmc_lds.csv
