@@ -935,3 +935,61 @@ def test_flash_attention_lds_tile_layouts_are_conflict_free_and_consistent():
     # (3) the plain layout: lanes 0..31 read bytes hi*8.. of the same unit -> 16 distinct bank pairs for 32 lanes
     pairs = [((swz(l, 2) + 0) // 8) % 32 for l in range(32)]
     assert len(set(pairs)) == 16
+
+
+def test_weight_packing_algebra():
+    """What hip.pack_weights folds into the fp16 blob is exact algebra on the checkpoint tensors (float64 here):
+    (1) LayerNorm affine parts folded into the consuming projection (WH_WEIGHTS_DEC_LN_FOLDED, model.py:39-50,142-171);
+    (2) the encoder's softmax scale carried by the query / key projections (WH_WEIGHTS_ENC_QK_SCALED, model.py:118-121);
+    (3) Conv1d as a GEMM over overlapping rows of the padded, transposed input (model.py:53-59,193-194)."""
+    import math
+    import torch
+    from whisper_amd import hip
+    from whisper_amd.synthetic import dims_for, synthetic_state_dict
+    g = torch.Generator().manual_seed(3)
+    D, N, R = 48, 80, 7
+    W, b = torch.randn(N, D, generator=g, dtype=torch.float64), torch.randn(N, generator=g, dtype=torch.float64)
+    gam, bet = torch.randn(D, generator=g, dtype=torch.float64), torch.randn(D, generator=g, dtype=torch.float64)
+    x = torch.randn(R, D, generator=g, dtype=torch.float64) * 3 + 1
+    xhat = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    want = torch.nn.functional.linear(torch.nn.functional.layer_norm(x, (D,), gam, bet, 1e-5), W, b)
+    Wf, bf = hip._fold_ln(W, b, gam, bet)
+    got = xhat.float() @ Wf.T + bf                     # _fold_ln computes in fp32
+    assert torch.allclose(got.double(), want, atol=2e-4, rtol=1e-5)
+
+    # (2) pieces of an encoder block: rows [:2D] of qkv_w and the query bias carry ENC_QK_SCALE, the key bias is zero
+    assert abs(hip.ENC_QK_SCALE ** 2 - 0.125 * math.log2(math.e)) < 1e-12
+    dims = dims_for("tiny.en")
+    sd = synthetic_state_dict(dims, seed=0, device="cpu")
+    Da = dims.n_audio_state
+    plain = dict((f, t) for f, t, _ in hip._block_pieces(sd, "encoder.blocks.0.", False, Da))
+    scaled = dict((f, t) for f, t, _ in hip._block_pieces(sd, "encoder.blocks.0.", False, Da, qk_scale=hip.ENC_QK_SCALE))
+    assert torch.equal(scaled["qkv_w"][2 * Da:].float(), plain["qkv_w"][2 * Da:].float())
+    assert torch.allclose(scaled["qkv_w"][: 2 * Da].float(), plain["qkv_w"][: 2 * Da].float() * hip.ENC_QK_SCALE, rtol=1e-6)
+    assert torch.all(scaled["qkv_b"][Da: 2 * Da] == 0) and torch.all(plain["qkv_b"][Da: 2 * Da] == 0)
+    xe = torch.randn(5, Da, generator=g)
+    q = (xe @ plain["qkv_w"][:Da].float().T + plain["qkv_b"][:Da]).double()
+    k = (xe @ plain["qkv_w"][Da: 2 * Da].float().T).double()
+    qs = (xe @ scaled["qkv_w"][:Da].float().T + scaled["qkv_b"][:Da]).double()
+    ks = (xe @ scaled["qkv_w"][Da: 2 * Da].float().T).double()
+    h = slice(0, 64)                                    # one head; model.py:118-121: (q * d^-.25) @ (k * d^-.25)^T, softmax
+    ref_p = torch.softmax((q[:, h] * 64 ** -0.25) @ (k[:, h] * 64 ** -0.25).T, -1)
+    e2 = torch.exp2(qs[:, h] @ ks[:, h].T)             # the kernel's form: p = 2^(k'.q'), normalised by the row sum
+    assert torch.allclose(e2 / e2.sum(-1, keepdim=True), ref_p, atol=1e-6)
+
+    # folded decoder block: stored gamma / beta become (1, 0)
+    Dt = dims.n_text_state
+    folded = dict((f, t) for f, t, _ in hip._block_pieces(sd, "decoder.blocks.0.", True, Dt, fold=True))
+    for n in ("attn_ln", "cross_ln", "mlp_ln"):
+        assert torch.all(folded[n + "_w"] == 1) and torch.all(folded[n + "_b"] == 0)
+
+    # (3) conv as GEMM: rows of the GEMM input are 3 consecutive time steps of the zero-padded [time][channel] input
+    C, T = 6, 11
+    wc, xc = torch.randn(D, C, 3, generator=g), torch.randn(1, C, T, generator=g)
+    wg = hip._conv_as_gemm(wc, 64)
+    assert wg.shape == (D, 64) and torch.all(wg[:, 3 * C:] == 0)
+    xt = torch.nn.functional.pad(xc[0].T, (0, 0, 1, 1))                                  # [T + 2][C]
+    rows1 = torch.stack([xt[t: t + 3].reshape(-1) for t in range(T)])                    # stride 1 (conv1)
+    assert torch.allclose(rows1 @ wg[:, : 3 * C].T, torch.nn.functional.conv1d(xc, wc, padding=1)[0].T, atol=1e-5)
+    rows2 = torch.stack([xt[t: t + 3].reshape(-1) for t in range(0, T - 1, 2)])          # stride 2 (conv2): lda = 2 C
+    assert torch.allclose(rows2 @ wg[:, : 3 * C].T, torch.nn.functional.conv1d(xc, wc, stride=2, padding=1)[0].T[: rows2.shape[0]], atol=1e-5)
