@@ -993,3 +993,60 @@ def test_weight_packing_algebra():
     assert torch.allclose(rows1 @ wg[:, : 3 * C].T, torch.nn.functional.conv1d(xc, wc, padding=1)[0].T, atol=1e-5)
     rows2 = torch.stack([xt[t: t + 3].reshape(-1) for t in range(0, T - 1, 2)])          # stride 2 (conv2): lda = 2 C
     assert torch.allclose(rows2 @ wg[:, : 3 * C].T, torch.nn.functional.conv1d(xc, wc, stride=2, padding=1)[0].T[: rows2.shape[0]], atol=1e-5)
+
+
+def test_sampler_row_state_model_equals_timestamp_rules():
+    """csrc/sampling.hip keeps three ints per row between steps (last sampled token is a timestamp, the one before is,
+    last timestamp value + 1) instead of walking the sampled tokens; the partial kernel derives the masks of
+    ApplyTimestampRules (decoding.py:441-505) from them and the decision kernel applies the "timestamp mass" rule to two
+    range statistics.  Python model of exactly that, step by step against the host filter (itself checked against the
+    reference in test_logit_filters_match_reference), greedy choice on random logits."""
+    import types
+    import torch
+    from whisper_amd.decoding import ApplyTimestampRules
+    V, TB, EOT, NOTS, T0, MAXI = 72, 40, 30, 35, 3, 5
+    tk = types.SimpleNamespace(timestamp_begin=TB, eot=EOT, no_timestamps=NOTS)
+    filt = ApplyTimestampRules(tk, T0, MAXI)
+    g = torch.Generator().manual_seed(11)
+    R, steps = 16, 40
+    tokens = torch.randint(0, EOT, (R, T0), generator=g)
+    state = [[0, 0, 0] for _ in range(R)]                       # row_state: last is ts, previous is ts, last ts value + 1
+    NEG = float("-inf")
+    for step in range(steps):
+        # logits with a varying tilt towards timestamps so that every rule fires somewhere
+        logits = torch.randn(R, V, generator=g) * 2.0
+        logits[:, TB:] += torch.randn(R, 1, generator=g) * 2.0
+        want = logits.clone()
+        filt.apply(want, tokens)
+        want_tok = want.argmax(-1)
+        L = tokens.shape[1] - T0
+        got = []
+        for r in range(R):
+            s0, s1, s2 = state[r]
+            last_ts, pen_ts = (L >= 1) and s0 != 0, (L < 2) or s1 != 0
+            lo = hi = 0
+            if s2 > 0:
+                lo, hi = TB, (s2 - 1) if (last_ts and not pen_ts) else s2
+            x = logits[r].clone()
+            for v in range(V):
+                m = v == NOTS
+                if last_ts:
+                    m = m or (v >= TB if pen_ts else v < EOT)
+                m = m or (lo <= v < hi)
+                if L == 0:
+                    m = m or v < TB or v > TB + MAXI
+                if m:
+                    x[v] = NEG
+            # decision kernel: statistics of the text range [0, TB) and the timestamp range [TB, V)
+            tx, ts = x[:TB], x[TB:]
+            lse_all = torch.logsumexp(x, 0)
+            ts_lse = torch.logsumexp(ts, 0) - lse_all if torch.isfinite(ts).any() else torch.tensor(NEG)
+            text_best = tx.max() - lse_all if torch.isfinite(tx).any() else torch.tensor(NEG)
+            nxt = int(ts.argmax()) + TB if ts_lse > text_best else int(x.argmax())
+            got.append(nxt)
+            is_ts = nxt >= TB
+            state[r] = [1 if is_ts else 0, s0, (nxt + 1) if is_ts else s2]
+        assert got == want_tok.tolist(), (step, got, want_tok.tolist())
+        tokens = torch.cat([tokens, want_tok[:, None]], 1)
+    sampled = tokens[:, T0:]
+    assert (sampled >= TB).any() and (sampled < EOT).any()      # both kinds were produced
