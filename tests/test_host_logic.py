@@ -1050,3 +1050,50 @@ def test_sampler_row_state_model_equals_timestamp_rules():
         tokens = torch.cat([tokens, want_tok[:, None]], 1)
     sampled = tokens[:, T0:]
     assert (sampled >= TB).any() and (sampled < EOT).any()      # both kinds were produced
+
+
+def test_beam_shared_history_permutation_model_is_exact():
+    """The fused beam loop moves only part of the self-attention cache when the beams are re-ordered (csrc/beam.hip:
+    lcp' / copy_from, csrc/elementwise.hip::permute_group_kernel): new row i takes from its source only the positions
+    from lcp[i][src[i]] on, and lcp'[i][j] = lcp[src[i]][src[j]] (everything so far for equal sources).  Model with the
+    cache content of (row, position) identified by the token history it was computed from: after every limited
+    permutation each row must hold exactly what the full gather of decoding.py:172-176 would have given it."""
+    rng = np.random.default_rng(5)
+    moved = full = 0
+    for G in (2, 5, 8):
+        for trial in range(20):
+            prompt = [int(t) for t in rng.integers(0, 9, size=int(rng.integers(1, 4)))]
+            hist = [list(prompt) for _ in range(G)]                       # token history of each beam
+            cache = [[tuple(prompt[: p + 1]) for p in range(len(prompt))] for _ in range(G)]
+            lcp = [[0x7F7F7F7F] * 8 for _ in range(8)]                    # hipMemsetAsync(0x7f): "everything so far"
+            for step in range(30):
+                length = len(hist[0])                                     # cached positions == tokens in a row
+                assert all(cache[i] == [tuple(hist[i][: p + 1]) for p in range(length)] for i in range(G))
+                # the update: every new beam picks a source (sticky / collapsing / random phases) and a new token
+                mode = rng.integers(0, 3)
+                src = [i if mode == 0 and rng.random() < 0.8 else int(rng.integers(0, G if mode != 1 else min(G, 2)))
+                       for i in range(G)]
+                tok = [int(t) for t in rng.integers(0, 9, size=G)]
+                new_lcp = [[0] * 8 for _ in range(8)]
+                for i in range(G):
+                    for j in range(G):
+                        new_lcp[i][j] = min(length, length if src[i] == src[j] else lcp[src[i]][src[j]])
+                copy_from = [min(length, length if src[i] == i else lcp[i][src[i]]) for i in range(G)]
+                old = [list(c) for c in cache]
+                for i in range(G):
+                    if src[i] != i:
+                        for p in range(copy_from[i], length):
+                            cache[i][p] = old[src[i]][p]
+                        moved += length - copy_from[i]
+                    full += length if src[i] != i else 0
+                hist = [hist[src[i]] + [tok[i]] for i in range(G)]
+                # exactness: what the full gather would hold
+                assert all(cache[i] == [tuple(hist[i][: p + 1]) for p in range(length)] for i in range(G)), (G, trial, step)
+                # and the table keeps its meaning: rows i, j agree on their first lcp'[i][j] positions
+                for i in range(G):
+                    for j in range(G):
+                        assert cache[i][: new_lcp[i][j]] == cache[j][: new_lcp[i][j]]
+                lcp = new_lcp
+                for i in range(G):                                        # the next decode step appends position `length`
+                    cache[i].append(tuple(hist[i]))
+    assert moved < full                                                   # and it does save copies
