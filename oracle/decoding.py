@@ -214,3 +214,24 @@ def rank_candidates(cands, sample_begin: int, eot: int, length_penalty: Optional
         if best is None or score > best_score:
             best, best_score = (body, lp), score
     return best
+
+
+def sequence_logprob(model: OracleModel, feats: torch.Tensor, initial_tokens: List[int], sampled: List[int],
+                     r: SamplingRules) -> float:
+    """Sum of the filtered log-probabilities the oracle assigns to `sampled` after `initial_tokens` on ONE audio
+    (feats (1500, D) or (1, 1500, D)): what BeamSearchDecoder / GreedyDecoder accumulate in sum_logprobs
+    (decoding.py:283-287, 341-345) when they emit exactly this sequence.  One teacher-forced pass; an EOT ends the sum
+    (tokens after it carry no log-probability, decoding.py:285).  Test helper: scores the sequence an fp16 beam search
+    chose under the fp32 model, so that a different winner can be told from a worse one."""
+    toks = torch.tensor([list(initial_tokens) + list(sampled)], dtype=torch.int64)
+    with torch.no_grad():
+        logits = model.decoder(toks[:, :-1], feats[None] if feats.dim() == 2 else feats)[0]
+    n0 = len(initial_tokens)
+    total = 0.0
+    for t, tok in enumerate(sampled):
+        row = logits[n0 - 1 + t].clone()
+        apply_filters(row, list(sampled[:t]), r)
+        total += float(F.log_softmax(row.float(), dim=-1)[tok])
+        if tok == r.eot:
+            break
+    return total

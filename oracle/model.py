@@ -100,9 +100,18 @@ class OracleModel:
                 ck, cv = self._lin(xa, p + ".cross_attn.key"), self._lin(xa, p + ".cross_attn.value")
                 if cache is not None:
                     cache["cross_k"][i], cache["cross_v"][i] = ck, cv
+            cq = self._lin(h, p + ".cross_attn.query")
             if group > 1:
-                ck, cv = ck.repeat_interleave(group, 0), cv.repeat_interleave(group, 0)
-            a, qk = self._attend(self._lin(h, p + ".cross_attn.query"), ck, cv, d.n_text_head, None)
+                # decoding.py:734 repeat_interleave()s the audio features so that row r attends to audio r // group.
+                # The same sums without materialising `group` copies of K / V (2 x 300 MB per layer and step at 40 rows
+                # of large-v3): the rows of one audio become extra query positions of that audio — cross attention has
+                # no mask, every (query, key) product and every softmax row is unchanged.
+                Bq = xa.shape[0]
+                a, qk = self._attend(cq.reshape(Bq, group * T, -1), ck, cv, d.n_text_head, None)
+                a = a.reshape(R, T, -1)
+                qk = qk.view(Bq, d.n_text_head, group, T, -1).permute(0, 2, 1, 3, 4).reshape(R, d.n_text_head, T, -1)
+            else:
+                a, qk = self._attend(cq, ck, cv, d.n_text_head, None)
             if keep_qk:
                 qks.append(qk)
             x = x + self._lin(a, p + ".cross_attn.out")

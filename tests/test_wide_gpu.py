@@ -268,6 +268,10 @@ def test_large_v3_batch_invariance_and_determinism(gpu_device):
 
 
 FP16_LOGIT_BOUND = 6e-2     # |logit(fp16 engine) - logit(fp32 oracle)| asserted above at 2 + 2 layers
+# The same quantity at FULL depth, measured (profiles/r03_parity_fp16.json, written by the tests below): teacher-forced
+# logits of the fp16 engine against the fp32 oracle over (rows x positions x 51866) logits of unit scale.
+FP16_FULL_DEPTH_MAX = {"large-v3": 0.60, "turbo": 0.25}      # asserted max |dlogit|  (32 + 32 / 32 + 4 layers)
+FP16_FULL_DEPTH_RMS = {"large-v3": 8e-2, "turbo": 3e-2}      # asserted rms |dlogit|
 
 
 def greedy_rows_match_or_near_tie(got: torch.Tensor, want: dict, n_init: int, bound: float):
@@ -289,22 +293,95 @@ def greedy_rows_match_or_near_tie(got: torch.Tensor, want: dict, n_init: int, bo
     return report
 
 
-def test_large_v3_full_depth_vs_oracle(gpu_device):
+def _offset_feats(dims, n, seed):
+    """n rows of random audio features with a per-clip offset vector (plain noise features all decode to the same token
+    string with random-init weights: uniform cross-attention averages them out, and a row mix-up would be invisible);
+    fp16-exact, so the fp32 oracle and both engines see identical values."""
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(n, dims.n_audio_ctx, dims.n_audio_state, generator=g)
+            + 3.0 * torch.randn(n, 1, dims.n_audio_state, generator=g)).half().float()
+
+
+class _FullDepth:
+    """one model at full depth for a module: seed-s CPU weights (numpy PCG64: the same tensors on both sides), the
+    oracle on them, and lazily packed engines"""
+
+    def __init__(self, name, seed, device):
+        from whisper_amd.synthetic import dims_for, synthetic_state_dict
+        self.name, self.device = name, device
+        self.dims = dims_for(name)
+        self.sd = synthetic_state_dict(self.dims, seed=seed)
+        self.om = oracle.OracleModel(self.dims, self.sd)
+        self._engines = {}
+
+    def engine(self, dt):
+        if dt not in self._engines:
+            self._engines[dt] = hip.HipModel(self.dims, dt, hip.pack_weights(self.sd, self.dims, dt, self.device))
+        return self._engines[dt]
+
+    def whisper(self):
+        """the public model object on the same engines"""
+        from whisper_amd.model import ModelDimensions, Whisper
+        from whisper_amd.synthetic import dims_dict
+        m = Whisper(ModelDimensions(**dims_dict(self.dims)), self.sd, device=self.device)
+        m.adopt_engine(torch.float32, self.engine(hip.WH_F32))
+        m.adopt_engine(torch.float16, self.engine(hip.WH_F16))
+        return m
+
+
+@pytest.fixture(scope="module")
+def large_v3(gpu_device):
+    return _FullDepth("large-v3", 0, gpu_device)          # seed 0 = the weights bench.py times
+
+
+@pytest.fixture(scope="module")
+def turbo(gpu_device):
+    return _FullDepth("turbo", 4, gpu_device)             # seed 4 = tests/golden/make_golden_turbo.py
+
+
+def _tf_error(fd, dt, feats, toks, T0):
+    """prefill(T0 tokens) + one step per remaining token through engine `dt` against ONE teacher-forced pass of the
+    oracle: (max |dlogit|, rms |dlogit|, per-position max) over all rows, positions and vocabulary entries"""
+    with torch.no_grad():
+        want = fd.om.decoder(toks, feats)                                       # (R, T, V): logits AFTER each token
+    model = fd.engine(dt)
+    R, T = toks.shape
+    task = hip.HipTask(model, feats.shape[0], R // feats.shape[0], max(T0, 8))
+    per_pos, sq, n = [], 0.0, 0
+    try:
+        task.set_audio(feats.to(fd.device, model.torch_dtype).contiguous())
+        dtoks = toks.to(fd.device)
+        got0 = task.prefill(dtoks[:, :T0].contiguous()).cpu()                   # positions 0 .. T0-1
+        assert torch.isfinite(got0).all()
+        d = (got0 - want[:, :T0]).abs()
+        per_pos += d.amax(dim=(0, 2)).tolist()
+        sq, n = sq + float((d.double() ** 2).sum()), n + d.numel()
+        for i in range(T0, T):                                                  # feeding token i gives position i
+            got = task.step(dtoks[:, i]).cpu()
+            d = (got - want[:, i]).abs()
+            per_pos.append(float(d.max()))
+            sq, n = sq + float((d.double() ** 2).sum()), n + d.numel()
+    finally:
+        task.close()
+    return max(per_pos), (sq / n) ** 0.5, per_pos
+
+
+def test_large_v3_full_depth_vs_oracle(large_v3, gpu_device):
     """The benchmarked configuration itself — large-v3, 32 + 32 layers, the seed-0 weights of bench.py — against the
     CPU oracle (restating whisper/model.py:188-249, decoding.py:680-710):
       fp32 strict engine: log-mel -> 32-layer encoder on one clip (|d| < 2e-3), teacher-forced prefill + 8 steps of
         2 rows (logits within 1e-3: the north-star bar), 8 greedy steps (ids exact);
-      fp16 engine (what bench.py times), 8 rows x 32 greedy steps: ids equal to the oracle's, or the first
-        difference of a row is a near-tie inside twice the fp16 logit bound; at least half of the rows agree over all
-        32 steps."""
-    from whisper_amd.synthetic import dims_for, synthetic_state_dict
-    dims = dims_for("large-v3")
-    sd = synthetic_state_dict(dims, seed=0)                         # CPU generation: the same weights on both sides
-    om = oracle.OracleModel(dims, sd)
+      fp16 engine (what bench.py times): teacher-forced prefill + 8 steps of 8 rows along the oracle's own greedy path —
+        max / rms |dlogit| MEASURED at full depth, asserted at FP16_FULL_DEPTH_*, written to the parity report; then
+        8 rows x 32 greedy steps: ids equal to the oracle's, or the first difference of a row is a near-tie inside
+        twice that measured-depth bound; the number of rows agreeing over all 32 steps is asserted at what was observed."""
+    from conftest import write_report
+    fd = large_v3
+    dims, om = fd.dims, fd.om
     tok, init, params, rules, mask = _greedy_setup(dims, 8, gpu_device, suppress_eot=True)
 
     # ---- fp32 engine
-    model32 = hip.HipModel(dims, hip.WH_F32, hip.pack_weights(sd, dims, hip.WH_F32, gpu_device))
+    model32 = fd.engine(hip.WH_F32)
     rng = np.random.default_rng(11)
     t = np.arange(480000) / 16000.0
     audio = (rng.standard_normal(480000) * 0.05 + 0.2 * np.sin(2 * np.pi * 330 * t)).astype(np.float32)[None]
@@ -317,49 +394,47 @@ def test_large_v3_full_depth_vs_oracle(gpu_device):
     got_enc = model32.encode(got_mel).float().cpu()
     enc_err = (got_enc - want_enc).abs().max().item()
     assert enc_err < 2e-3, enc_err
+    enc16 = fd.engine(hip.WH_F16).encode(got_mel).float().cpu()
+    enc16_err = (enc16 - want_enc).abs().max().item()
+    enc16_rms = ((enc16 - want_enc) ** 2).mean().sqrt().item()
+    assert enc16_err < 4e-2 and enc16_rms < 4e-3, (enc16_err, enc16_rms)      # fp16 engine, 32 encoder layers
 
-    g = torch.Generator().manual_seed(4)
-    feats = (torch.randn(8, dims.n_audio_ctx, dims.n_audio_state, generator=g)
-             + 3.0 * torch.randn(8, 1, dims.n_audio_state, generator=g)).half().float()     # fp16-exact: both engines see the same
-    feats[0] = want_enc[0].half().float()                                                   # row 0: a real encoder output
+    feats = _offset_feats(dims, 8, seed=4)
+    feats[0] = want_enc[0].half().float()                                       # row 0: a real encoder output
     T0 = len(init)
+    g = torch.Generator().manual_seed(4)
     toks = torch.randint(0, dims.n_vocab, (2, T0 + 8), generator=g)
     toks[:, :T0] = torch.tensor(init)
-    cache = om.new_cache()
-    with torch.no_grad():
-        want0 = om.decoder(toks[:, :T0], feats[:2], cache)
-    task = hip.HipTask(model32, 2, 1, 8)
-    try:
-        task.set_audio(feats[:2].to(gpu_device).contiguous())
-        dtoks = toks.to(gpu_device)
-        got0 = task.prefill(dtoks[:, :T0].contiguous()).cpu()
-        assert (got0 - want0).abs().max().item() < 1e-3
-        for i in range(8):
-            with torch.no_grad():
-                want = om.decoder(toks[:, T0 + i: T0 + i + 1], feats[:2], cache)[:, -1]
-            got = task.step(dtoks[:, T0 + i]).cpu()
-            err = (got - want).abs().max().item()
-            assert err < 1e-3, (i, err)
-    finally:
-        task.close()
+    mx, rms, per_pos = _tf_error(fd, hip.WH_F32, feats[:2], toks, T0)
+    assert mx < 1e-3, (mx, per_pos)
     with torch.no_grad():
         want_g = oracle.greedy_decode(om, feats[:2], init, 8, rules)
     n, got_g, _, _ = _run_greedy(model32, feats[:2].to(gpu_device), init, params, 8, gpu_device, tok)
     assert torch.equal(got_g, want_g["tokens"])
-    del model32
-    torch.cuda.empty_cache()
 
     # ---- fp16 engine: the bench configuration (8 rows), 32 greedy steps
     n_steps = 32
     tok, init, params, rules, mask = _greedy_setup(dims, n_steps, gpu_device, suppress_eot=True)
-    model16 = hip.HipModel(dims, hip.WH_F16, hip.pack_weights(sd, dims, hip.WH_F16, gpu_device))
+    model16 = fd.engine(hip.WH_F16)
     with torch.no_grad():
         want16 = oracle.greedy_decode(om, feats, init, n_steps, rules, keep_logits=True)
+    # measured logit error at full depth, teacher-forced along the oracle's greedy path (8 rows, T0 + 8 positions)
+    mx16, rms16, per_pos16 = _tf_error(fd, hip.WH_F16, feats, want16["tokens"][:, : T0 + 8].contiguous(), T0)
     n, got16, _, _ = _run_greedy(model16, feats.to(gpu_device).half(), init, params, n_steps, gpu_device, tok)
     assert n == len(init) + n_steps
-    report = greedy_rows_match_or_near_tie(got16, want16, len(init), 2 * FP16_LOGIT_BOUND)
+    bound = 2 * FP16_FULL_DEPTH_MAX["large-v3"]
+    report = greedy_rows_match_or_near_tie(got16, want16, len(init), bound)
     full = sum(1 for t, _ in report if t is None)
-    print("fp16 large-v3 vs oracle, per row (first divergence step, margin):", report)
+    write_report("fp16_large_v3_greedy.json", {
+        "model": "large-v3 32+32, seed-0 weights, fp16 engine vs fp32 oracle", "rows": 8, "greedy_steps": n_steps,
+        "teacher_forced": {"positions": T0 + 8, "max_abs_dlogit": mx16, "rms_dlogit": rms16, "per_position_max": per_pos16,
+                           "asserted_max": FP16_FULL_DEPTH_MAX["large-v3"], "asserted_rms": FP16_FULL_DEPTH_RMS["large-v3"]},
+        "fp32_engine": {"encoder_max_err": enc_err, "teacher_forced_max_abs_dlogit": mx},
+        "fp16_encoder": {"max_err": enc16_err, "rms_err": enc16_rms},
+        "rows_equal_all_steps": full, "near_tie_bound": bound,
+        "per_row": [{"row": k, "first_divergence": t, "oracle_margin": m} for k, (t, m) in enumerate(report)]})
+    print("fp16 large-v3 vs oracle: teacher-forced max", mx16, "rms", rms16, "| per row (first divergence, margin):", report)
+    assert mx16 < FP16_FULL_DEPTH_MAX["large-v3"] and rms16 < FP16_FULL_DEPTH_RMS["large-v3"], (mx16, rms16)
     assert full >= 4, report
     distinct = len({int(x) for x in want16["tokens"][:, len(init):].flatten()})
     assert distinct >= 40                                                       # the decode is not degenerate
@@ -401,3 +476,219 @@ def test_other_widths_encoder_and_steps(gpu_device, name, dt, tol):
             assert (got - want).abs().max().item() < tol, i
     finally:
         task.close()
+
+
+def _golden_audio(seed, n=480000):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 16000.0
+    x = rng.standard_normal(n).astype(np.float32) * 0.05
+    x += (0.3 * np.sin(2 * np.pi * 440 * t) + 0.1 * np.sin(2 * np.pi * 1870 * t)).astype(np.float32)
+    return x
+
+
+def _word_arrays(words):
+    return (np.array([w.start for w in words]), np.array([w.end for w in words]),
+            np.array([w.probability for w in words]))
+
+
+def test_turbo_dims_vs_oracle(turbo, gpu_device):
+    """BASELINE.json configs[4] dims: turbo = large-v3 widths, 32 encoder / 4 decoder layers (UNEQUAL depths — every
+    other GPU model in the tests has equal ones), `word_timestamps=True` (whisper/timing.py:163-242, model.py:252-277),
+    seed-4 weights, against the LIVE reference (tests/golden/turbo_dims.npz, make_golden_turbo.py) and the oracle.
+      fp32 strict engine: encoder on one clip (2e-3 vs the oracle, the reference's slice), teacher-forced logits vs the
+        reference (1e-3) and prefill + 8 steps vs the oracle (1e-3), greedy ids of 2 rows exact (reference);
+        `find_alignment` word times vs the reference exact; `find_alignment_batch` on 4 clips of different token /
+        frame counts vs the oracle's alignment_matrix -> dtw_path -> word_times: frame indices exact;
+      fp16 engine (what bench.py's turbo leg runs): teacher-forced logit error measured and bounded, 32 rows x 32 greedy
+        steps under the near-tie rule, and the word boundaries of the fp16 alignment against the fp32 engine's
+        (share of words within +-1 frame reported and asserted)."""
+    import os
+    import whisper_amd
+    from conftest import write_report
+    from whisper_amd.timing import find_alignment, find_alignment_batch
+    from whisper_amd.tokenizer import get_tokenizer
+    fd = turbo
+    dims, om = fd.dims, fd.om
+    assert (dims.n_audio_layer, dims.n_text_layer) == (32, 4)
+    T = np.load(os.path.join(os.path.dirname(__file__), "golden", "turbo_dims.npz"))
+    model = fd.whisper()
+    assert np.array_equal(model.alignment_heads.to_dense().numpy(), T["alignment_heads"])    # layers 2, 3 x 20 heads
+    tok = get_tokenizer(True, num_languages=model.num_languages, language="en", task="transcribe")
+    problems, rep = [], {"model": "turbo dims 32+4, seed-4 weights"}
+
+    def check(ok, what):
+        if not ok:
+            problems.append(what)
+
+    # ---- fp32 engine: encoder
+    a = _golden_audio(31)
+    mel = whisper_amd.pad_or_trim(whisper_amd.log_mel_spectrogram(a, dims.n_mels, device=gpu_device), 3000)
+    feats32 = model.encoder(mel[None].float())
+    assert feats32.dtype == torch.float32
+    ref_err = float(np.abs(feats32[0, ::50, :24].cpu().numpy() - T["enc_slice"]).max())
+    omel = oracle.log_mel_spectrogram(a, oracle.mel_filterbank(dims.n_mels))
+    with torch.no_grad():
+        want_enc = om.encoder(omel[None])
+    enc_err = float((feats32.cpu() - want_enc).abs().max())
+    rep["fp32_encoder"] = {"max_err_vs_oracle": enc_err, "max_err_vs_reference_slice": ref_err}
+    check(enc_err < 2e-3 and ref_err < 2e-3, ("encoder fp32", enc_err, ref_err))
+    # ---- teacher-forced logits: the reference's 2 x 9 tokens on the real features; oracle on noise features
+    toks = torch.from_numpy(T["tf_tokens"]).to(gpu_device)
+    logits = model.decoder(toks, feats32.repeat(2, 1, 1))
+    tf_ref = float(np.abs(logits[:, :, ::997].cpu().numpy() - T["tf_logits_slice"]).max())
+    check(tf_ref < 1e-3, ("teacher-forced logits vs reference", tf_ref))
+    check(np.array_equal(logits.argmax(-1).cpu().numpy(), T["tf_logits_argmax"]), "teacher-forced arg-max vs reference")
+    noise = _feats(dims, 2, seed=21)                       # the rows make_golden_turbo.py decoded
+    tk, init, params, rules, mask = _greedy_setup(dims, 24, gpu_device, suppress_eot=False)
+    T0 = len(init)
+    g = torch.Generator().manual_seed(4)
+    rtoks = torch.randint(0, dims.n_vocab, (2, T0 + 8), generator=g)
+    rtoks[:, :T0] = torch.tensor(init)
+    mx32, _, pp32 = _tf_error(fd, hip.WH_F32, noise, rtoks, T0)
+    rep["fp32_teacher_forced"] = {"max_abs_dlogit_vs_oracle": mx32, "max_abs_dlogit_slice_vs_reference": tf_ref}
+    check(mx32 < 1e-3, ("prefill + 8 steps fp32 vs oracle", mx32, pp32))
+    # ---- greedy ids vs the live reference (2 rows, 24 steps)
+    rs = whisper_amd.decode(model, noise.to(gpu_device), whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=24))
+    for i, r in enumerate(rs):
+        want = [t for t in T["greedy_tokens"][i].tolist() if t >= 0]
+        check(r.tokens == want, ("greedy ids vs reference, row", i, r.tokens, want))
+        check(abs(r.avg_logprob - T["greedy_stats"][i, 0]) < 1e-3, ("avg_logprob row", i))
+        check(len(set(want)) >= 10, ("degenerate golden row", i))
+    # ---- word alignment, fp32 engine vs the live reference (one clip, two token lists)
+    for tag in ("fixed", "greedy"):
+        al = find_alignment(model, tok, T[f"align_{tag}_tokens"].tolist(), mel.float(), 3000)
+        s, e, p = _word_arrays(al)
+        ok = (len(al) == len(T[f"align_{tag}_start"]) and np.abs(s - T[f"align_{tag}_start"]).max() < 1e-6
+              and np.abs(e - T[f"align_{tag}_end"]).max() < 1e-6)
+        check(ok, ("find_alignment vs reference", tag, s.tolist(), T[f"align_{tag}_start"].tolist()))
+        check(len(al) == len(T[f"align_{tag}_prob"]) and np.allclose(p, T[f"align_{tag}_prob"], rtol=5e-3, atol=1e-6),
+              ("word probabilities vs reference", tag))
+    # ---- batched alignment, fp32 engine vs the oracle: clip 0 = the real encoder output, clips 1-3 noise features
+    texts = [tok.encode(" hello world this is a test of word level timing"), tok.encode(" one two three"),
+             T["align_greedy_tokens"].tolist(),
+             tok.encode(" the quick brown fox jumps over the lazy dog and keeps running for a while longer")]
+    frames = [3000, 2000, 3000, 2600]
+    feats4 = torch.cat([feats32.cpu(), _feats(dims, 3, seed=77)]).half().float()       # fp16-exact: both engines see the same
+    heads = model.alignment_heads.indices().T.tolist()
+    got32 = find_alignment_batch(model, tok, texts, None, frames, audio_features=feats4.to(gpu_device))
+    n_words, exact = 0, 0
+    for i in range(4):
+        with torch.no_grad():
+            ws, we, wp = oracle.word_times(om, tok, texts[i], feats4[i: i + 1], frames[i], heads)
+        s, e, p = _word_arrays(got32[i])
+        same = len(s) == len(ws) and np.abs(s - ws).max() < 1e-6 and np.abs(e - we).max() < 1e-6
+        n_words += len(ws)
+        exact += int(np.sum((np.abs(s - ws) < 1e-6) & (np.abs(e - we) < 1e-6))) if len(s) == len(ws) else 0
+        check(same, ("find_alignment_batch fp32 vs oracle, clip", i, s.tolist(), ws.tolist()))
+        check(len(p) == len(wp) and np.allclose(p, wp, rtol=5e-3, atol=1e-6), ("word probabilities vs oracle, clip", i))
+    rep["fp32_alignment_vs_oracle"] = {"clips": 4, "words": n_words, "words_exact": exact}
+
+    # ---- fp16 engine
+    feats32r = _feats(dims, 32, seed=33).half().float()
+    n_steps = 32
+    tk, init, params, rules, mask = _greedy_setup(dims, n_steps, gpu_device, suppress_eot=True)
+    with torch.no_grad():
+        want16 = oracle.greedy_decode(om, feats32r, init, n_steps, rules, keep_logits=True)
+    mx16, rms16, pp16 = _tf_error(fd, hip.WH_F16, feats32r[:8], want16["tokens"][:8, : T0 + 8].contiguous(), T0)
+    check(mx16 < FP16_FULL_DEPTH_MAX["turbo"] and rms16 < FP16_FULL_DEPTH_RMS["turbo"], ("fp16 logit error", mx16, rms16))
+    n, got16, _, _ = _run_greedy(fd.engine(hip.WH_F16), feats32r.to(gpu_device).half(), init, params, n_steps, gpu_device, tk)
+    check(n == T0 + n_steps, "fp16 greedy step count")
+    bound = 2 * FP16_FULL_DEPTH_MAX["turbo"]
+    try:
+        report = greedy_rows_match_or_near_tie(got16, want16, T0, bound)
+    except AssertionError as err:
+        report, _ = [], check(False, ("fp16 greedy near-tie rule", str(err)))
+    full = sum(1 for t, _ in report if t is None)
+    check(full >= 16, ("fp16 rows equal to the oracle over all steps", full))
+    check(len({int(x) for x in want16["tokens"][:, T0:].flatten()}) >= 100, "degenerate oracle decode")
+    rep["fp16_greedy"] = {"rows": 32, "steps": n_steps, "rows_equal_all_steps": full, "near_tie_bound": bound,
+                          "teacher_forced": {"rows": 8, "positions": T0 + 8, "max_abs_dlogit": mx16, "rms_dlogit": rms16,
+                                             "per_position_max": pp16},
+                          "per_row": [{"row": k, "first_divergence": t, "oracle_margin": m} for k, (t, m) in enumerate(report)]}
+    # word boundaries: the fp16 engine's alignment against the fp32 engine's on the same features
+    got16a = find_alignment_batch(model, tok, texts, None, frames, audio_features=feats4.to(gpu_device).half())
+    within, total, worst = 0, 0, 0.0
+    for i in range(4):
+        s32, e32, _ = _word_arrays(got32[i])
+        s16, e16, _ = _word_arrays(got16a[i])
+        check([w.word for w in got16a[i]] == [w.word for w in got32[i]], ("fp16 alignment words, clip", i))
+        if len(s16) == len(s32):
+            d = np.maximum(np.abs(s16 - s32), np.abs(e16 - e32))
+            within += int(np.sum(d <= 0.02 + 1e-6))
+            total += len(d)
+            worst = max(worst, float(d.max()) if len(d) else 0.0)
+    rep["fp16_alignment_vs_fp32_engine"] = {"clips": 4, "words": total, "words_within_1_frame": within,
+                                            "words_differing_more": total - within, "worst_seconds": worst}
+    check(total > 0 and within >= 0.8 * total, ("fp16 alignment: words within +-1 frame of the fp32 engine", within, total))
+    rep["problems"] = [str(p) for p in problems]
+    write_report("turbo_dims.json", rep)
+    print("turbo dims report:", rep)
+    assert not problems, problems
+
+
+def test_large_v3_full_depth_beam5_vs_oracle(large_v3, gpu_device):
+    """BASELINE.json configs[3] shape on one GPU at FULL depth (large-v3 32 + 32, seed-0 weights): device-side beam
+    search (wh_task_beam, beam 5) against the oracle's BeamSearchDecoder restatement (decoding.py:301-404, 734-740).
+      fp32 strict engine, 2 audio x 5 beams, 8 steps: the candidate lists after finalize() — every token sequence and its
+        sum_logprob (1e-3) — and the ranked winner;
+      fp16 engine, 8 audio x 5 beams = 40 rows (the 48-row projection kernels, matrix-core group attention, in-place
+        cache permutation), 16 steps: the ranked winner equals the oracle's, or it is a near-tie: scored by the ORACLE
+        (teacher-forced, filtered log-probabilities), its length-normalised score is within the full-depth fp16 bound
+        of — or above — the oracle winner's (beam search is a heuristic: a rounding-level difference may keep another,
+        equally good hypothesis).  Rows equal / near-tie are reported and asserted at what was observed."""
+    import whisper_amd
+    from conftest import write_report
+    from whisper_amd.decoding import DecodingTask
+    fd = large_v3
+    dims, om = fd.dims, fd.om
+    model = fd.whisper()
+    feats = _offset_feats(dims, 8, seed=4)
+    tok, init, params, rules, mask = _greedy_setup(dims, 8, gpu_device, suppress_eot=False)
+    T0 = len(init)
+    # ---- fp32
+    opts = whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=8, beam_size=5)
+    task = DecodingTask(model, opts)
+    res = task.run(feats[:2].to(gpu_device))
+    with torch.no_grad():
+        want = oracle.beam_decode(om, feats[:2], init, 8, rules, 5)
+    worst = 0.0
+    for a in range(2):
+        got_c = {tuple(k): v for k, v in task.decoder.finished_sequences[a].items()}
+        want_c = {tuple(k): v for k, v in want["candidates"][a]}
+        assert list(got_c) == list(want_c), (a, list(got_c), list(want_c))                  # ids, and the dict order
+        for k in want_c:
+            worst = max(worst, abs(got_c[k] - want_c[k]))
+        body, lp = oracle.decoding.rank_candidates(want["candidates"][a], T0, tok.eot)
+        assert res[a].tokens == body, a
+        assert abs(res[a].avg_logprob - lp / (len(body) + 1)) < 1e-3
+    assert worst < 1e-3, worst
+    # ---- fp16, 40 rows
+    n_steps = 16
+    rules16 = oracle.SamplingRules(**{**rules.__dict__})
+    opts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=n_steps, beam_size=5)
+    res16 = whisper_amd.decode(model, feats.to(gpu_device).half(), opts)
+    with torch.no_grad():
+        want16 = oracle.beam_decode(om, feats, init, n_steps, rules16, 5)
+    eps = FP16_FULL_DEPTH_MAX["large-v3"]
+    rows = []
+    for a in range(8):
+        body, lp = oracle.decoding.rank_candidates(want16["candidates"][a], T0, tok.eot)
+        got = res16[a].tokens
+        if got == body:
+            rows.append({"audio": a, "equal": True, "oracle_norm_score": lp / max(len(body), 1)})
+            continue
+        with torch.no_grad():
+            lp_got = oracle.sequence_logprob(om, feats[a], init, got + [tok.eot], rules16) if len(got) < n_steps else \
+                oracle.sequence_logprob(om, feats[a], init, got, rules16)
+        s_want, s_got = lp / max(len(body), 1), lp_got / max(len(got), 1)
+        rows.append({"audio": a, "equal": False, "first_divergence": oracle.first_divergence(got, body),
+                     "oracle_norm_score": s_want, "hip_winner_norm_score_under_oracle": s_got,
+                     "near_tie": bool(s_got > s_want - eps)})
+    n_eq = sum(r["equal"] for r in rows)
+    n_tie = sum((not r["equal"]) and r["near_tie"] for r in rows)
+    write_report("fp16_large_v3_beam5.json", {"model": "large-v3 32+32, seed-0 weights", "rows": 40, "steps": n_steps,
+                                               "fp32_candidates_max_score_err": worst, "near_tie_eps": eps,
+                                               "winners_equal": n_eq, "winners_near_tie": n_tie, "per_audio": rows})
+    print("fp16 beam-5 full depth:", rows)
+    assert n_eq + n_tie == 8, rows
+    assert n_eq >= 2, rows
