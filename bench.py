@@ -15,9 +15,15 @@ weight blob and RCCL-broadcasts it over xGMI at load.
 Prints ONE JSON line on rank 0 (contract in the task statement).  Besides the headline it carries
   roofline      dominant kernel (cross-attention K/V stream) + `step_frac` of the whole decode step, HIP events
   public_api    the same workload through whisper_amd.log_mel_spectrogram + whisper_amd.decode (drop-in surface)
-  parity        row 0 of the timed pass against the tokens of the CPU baseline's oracle (same weights, same clip)
-  extras        BASELINE configs[3] / [4] shaped workloads (beam 5; word timestamps) — never the headline
-  cpu_baseline  the oracle (port of the reference's CPU fp32 path) on this box's host cores: warm-up + repeats
+  parity        ALL rows of the timed pass against the oracle decoding the same 8 clips as one batch (same weights)
+  extras        BASELINE configs[3] / [4] shaped workloads (beam 5; word timestamps) and configs[1] / [4] at their own
+                model dims — never the headline; each leg carries its own roofline figures (decode-step fraction of
+                the HBM peak, encoder TFLOP/s, log-mel time, device / host split of the alignment)
+  cpu_baseline  the oracle (port of the reference's CPU fp32 path) on this box's host cores: one clip (warm-up +
+                repeats) and the GPU's own batch of 8 clips (`value_batch8`, the figure the GPU / CPU ratio uses)
+
+Weights: seeded random-init tensors of the named architecture, unless `--checkpoint PATH` is given or the released
+checkpoint of `--model` sits in ~/.cache/whisper/ (where the reference's load_model keeps it): then those are used.
 """
 from __future__ import annotations
 
@@ -44,7 +50,10 @@ def log(msg: str) -> None:
 
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s float4-copy achievable)
-FP16_LOGIT_BOUND = 6e-2     # fp16 engine vs fp32 oracle, asserted by tests/test_wide_gpu.py
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16
+# fp16 engine vs fp32 oracle at FULL depth (32 + 32 layers): max |dlogit| measured and asserted by
+# tests/test_wide_gpu.py::test_large_v3_full_depth_vs_oracle (profiles/r03_parity_fp16.json)
+FP16_FULL_DEPTH_MAX = 0.60
 
 
 def parse():
@@ -66,8 +75,24 @@ def parse():
                    help="skip the base x 1 and turbo x 32 (+ word timestamps) legs of the extras")
     p.add_argument("--cpu-steps", type=int, default=12, help="decode steps timed on the CPU baseline")
     p.add_argument("--cpu-repeats", type=int, default=3)
+    p.add_argument("--parity-steps", type=int, default=24, help="decode steps of the batch-8 oracle pass (parity of all rows)")
+    p.add_argument("--checkpoint", default=None, help="reference-format checkpoint to run instead of seeded weights "
+                                                      "(default: ~/.cache/whisper/<model file> when it exists)")
     p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = all usable cores)")
     return p.parse_args()
+
+
+def torchrun_command(n_gpus: int, argv, port: int):
+    """argv + environment of `python bench.py --gpus N` re-executed as one process per GPU: the driver's own launch line
+    (torch.distributed.run, one node, rendezvous on 127.0.0.1 — the container hostname may not resolve).  The
+    environment is the caller's plus HSA_ENABLE_IPC_MODE_LEGACY=0 (the host driver only supports dmabuf IPC; without it
+    RCCL fails with hipIpcGetMemHandle: invalid argument)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    return cmd, env
 
 
 def relaunch_under_torchrun(args) -> None:
@@ -76,10 +101,9 @@ def relaunch_under_torchrun(args) -> None:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd, env = torchrun_command(args.gpus, sys.argv[1:], port)
     log(f"--gpus {args.gpus} without a launcher: re-executing under torch.distributed.run (port {port})")
-    os.execv(sys.executable, cmd)
+    os.execve(sys.executable, cmd, env)
 
 
 def synth_audio(batch: int, rank: int, device) -> torch.Tensor:
@@ -125,7 +149,15 @@ def main():
     from whisper_amd.synthetic import dims_dict, dims_for, synthetic_state_dict
     from whisper_amd.tokenizer import get_tokenizer
 
-    dims = dims_for(args.model)
+    ckpt_path = find_checkpoint(args)
+    ckpt_sd = None
+    if ckpt_path is not None:
+        from types import SimpleNamespace
+        ck = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+        dims, ckpt_sd = SimpleNamespace(**ck["dims"]), ck["model_state_dict"]
+        log(f"weights from checkpoint {ckpt_path}")
+    else:
+        dims = dims_for(args.model)
     dtype = hip.WH_F16
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     # ---- weights: rank 0 packs, everyone else receives the blob over RCCL -----------------------
@@ -133,7 +165,10 @@ def main():
     # the HIP engine see the very same tensors and their token ids can be compared; otherwise on the device (seconds).
     blob, sd_cpu = None, None
     if rank == 0:
-        if want_cpu:
+        if ckpt_sd is not None:
+            sd_cpu = ckpt_sd
+            blob = hip.pack_weights(sd_cpu, dims, dtype, device)
+        elif want_cpu:
             sd_cpu = synthetic_state_dict(dims, seed=0, device="cpu")
             blob = hip.pack_weights(sd_cpu, dims, dtype, device)
         else:
@@ -193,24 +228,28 @@ def main():
         n_tok = one_pass()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]     # imbalance shows here
+        elapsed = max(float(x.item()) for x in every)                        # MAX over ranks
     assert n_tok == T0 + N, (n_tok, T0, N)
     ms_per_step = elapsed / args.steps * 1e3
     log(f"timed: {ms_per_step:.1f} ms per pass")
     audio_s = 30.0 * B * world * args.steps
     value = audio_s / elapsed
-    hip_row0 = tokens[0, T0: T0 + N].tolist()
     direct_tokens = tokens[:, : T0 + N].clone()
 
     out = {
         "metric": "audio-seconds transcribed per wall-second (large-v3 greedy)",
         "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"{args.model} dims (random-init weights), {B} x 30 s synthetic clips per GPU, "
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+        "data": "synthetic" if ckpt_path is None else f"synthetic audio, weights of {os.path.basename(ckpt_path)}",
+        "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
+        "config": {"workload": f"{args.model} dims ({'random-init weights' if ckpt_path is None else 'released checkpoint'}), {B} x 30 s synthetic clips per GPU, "
                                f"greedy, fp16 weights/KV + fp32 accumulate, {N} forced decode steps per clip "
                                f"(EOT suppressed), log-mel + encoder + cross-KV + decode timed",
                    "clips_per_gpu": B, "sample_len": N, "parallelism": f"dp{world} (clips sharded, no step collective)"},
@@ -234,17 +273,17 @@ def main():
             model.encode(mel)
         torch.cuda.synchronize(device)
         enc_ms = (time.perf_counter() - t0) / 3 * 1e3
-        D_, L_, M_ = dims.n_audio_state, dims.n_audio_layer, dims.n_mels
-        enc_flop = B * (2 * 3000 * M_ * 3 * D_ + 2 * 1500 * D_ * 3 * D_ + L_ * (24 * 1500 * D_ * D_ + 4 * 1500 * 1500 * D_))
+        enc_flop = encoder_flop(dims, B)
         kern["encoder_forward"] = {"avg_us": round(enc_ms * 1e3, 1), "flop": enc_flop,
-                                   "TFLOPs": round(enc_flop / (enc_ms * 1e-3) / 1e12, 1), "mfma_peak_TFLOPs": 2500.0}
+                                   "TFLOPs": round(enc_flop / (enc_ms * 1e-3) / 1e12, 1), "mfma_peak_TFLOPs": MFMA_PEAK_TFLOPS,
+                                   "frac": round(enc_flop / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
         log(f"encoder forward: {enc_ms:.1f} ms, {enc_flop / (enc_ms * 1e-3) / 1e12:.0f} TFLOP/s")
         dom = kern["attn_decode_cross"]
         # HBM traffic per launch from the PMC counters: they cannot be read from inside this process, so the
         # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/, per round),
         # and only when it was taken on this very workload; otherwise null.
         traffic, tsrc = None, None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             tf = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
             if os.path.isfile(tf) and args.model == "large-v3" and B == 8:
                 with open(tf) as f:
@@ -305,6 +344,9 @@ def main():
                 bms = (time.perf_counter() - t0) / 2 * 1e3
                 extras["beam_search"] = {"beam_size": args.beam, "clips": B, "rows": B * args.beam, "steps": args.beam_steps,
                                          "ms_per_pass": round(bms, 2), "audio_s_per_s": round(30.0 * B / (bms * 1e-3), 1)}
+                # the 40-row decode step alone (graph replay, HIP events) at the pass's middle position, against its
+                # algorithmic bytes (weights once + every audio's cross K/V once + the rows' self K/V + logits)
+                extras["beam_search"].update(step_roofline(model, model.encode(mel), B, args.beam, T0 + args.beam_steps // 2))
                 log(f"beam {args.beam}: {bms:.1f} ms per pass of {B} clips x {args.beam_steps} steps")
             # BASELINE configs[4] shape: word timestamps (cross-attention alignment + DTW) for every clip of the batch
             if args.word_timestamps:
@@ -314,12 +356,18 @@ def main():
                 find_alignment_batch(wmodel, tok, text, mel.half(), [3000] * B)
                 torch.cuda.synchronize(device)
                 t0 = time.perf_counter()
+                stats = {}
                 for _ in range(2):
-                    al = find_alignment_batch(wmodel, tok, text, mel.half(), [3000] * B)
+                    al = find_alignment_batch(wmodel, tok, text, mel.half(), [3000] * B, stats=stats)
                 torch.cuda.synchronize(device)
                 wms = (time.perf_counter() - t0) / 2 * 1e3
                 extras["word_timestamps"] = {"clips": B, "text_tokens_per_clip": len(text[0]), "ms_per_batch": round(wms, 2),
                                              "words": sum(len(a) for a in al),
+                                             # wall clock until the device results (paths, probabilities) are on the host /
+                                             # host-only work after that (word split, boundaries), last batch
+                                             "device_ms": round(stats.get("device_s", 0.0) * 1e3, 2),
+                                             "host_ms": round(stats.get("host_s", 0.0) * 1e3, 2),
+                                             "host_share": round(stats.get("host_s", 0.0) / max(stats.get("device_s", 0.0) + stats.get("host_s", 0.0), 1e-9), 3),
                                              "note": "find_alignment_batch: encoder + one teacher-forced pass + alignment heads QK + DTW"}
                 log(f"word timestamps: {wms:.1f} ms per batch of {B} clips")
             out["extras"] = extras
@@ -339,7 +387,9 @@ def main():
     # ---- CPU baseline: the oracle (fp32 torch-CPU restatement of the reference) on this box's host cores ----
     if want_cpu:
         try:
-            base, parity = cpu_baseline(args, dims, init, suppress, tok, audio[:1].cpu().numpy(), sd_cpu, hip_row0)
+            base, parity = cpu_baseline(args, dims, init, suppress, tok, audio.cpu().numpy(), sd_cpu,
+                                        direct_tokens[:, T0:].cpu().tolist())
+            base["gpu_over_cpu_batch8"] = round(value / base["value_batch8"], 1) if base.get("value_batch8") else None
             out["cpu_baseline"] = base
             out["parity"] = parity
         except Exception as e:          # never at the price of the measured line
@@ -352,6 +402,64 @@ def main():
     if dist is not None:
         dist.barrier()                      # rank 0 measures its kernel table after the timed region: leave together
         dist.destroy_process_group()
+
+
+def find_checkpoint(args):
+    """--checkpoint PATH, else the released checkpoint of --model where the reference's load_model keeps it
+    (~/.cache/whisper/<file>, whisper/__init__.py:126-135), else None (seeded random-init weights)"""
+    if args.checkpoint:
+        if not os.path.isfile(args.checkpoint):
+            raise SystemExit(f"--checkpoint {args.checkpoint}: no such file")
+        return args.checkpoint
+    from whisper_amd.registry import MODEL_URLS
+    url = MODEL_URLS.get(args.model)
+    if url is None:
+        return None
+    default = os.path.join(os.path.expanduser("~"), ".cache")
+    path = os.path.join(os.getenv("XDG_CACHE_HOME", default), "whisper", os.path.basename(url))
+    return path if os.path.isfile(path) else None
+
+
+def encoder_flop(dims, B: int) -> float:
+    """AudioEncoder.forward on B windows: two convolutions + per layer 12 D^2 per frame of projections
+    and MLP (x 2 flop) + 4 T^2 D of attention"""
+    D_, L_, M_ = dims.n_audio_state, dims.n_audio_layer, dims.n_mels
+    return float(B) * (2 * 3000 * M_ * 3 * D_ + 2 * 1500 * D_ * 3 * D_ + L_ * (24 * 1500 * D_ * D_ + 4 * 1500 * 1500 * D_))
+
+
+def step_roofline(engine, feats, B: int, G: int, position: int) -> dict:
+    """One decode step of R = B x G rows at `position` cached tokens: the captured step graph replayed and timed with HIP
+    events on the launch stream (wh_task_bench_kernel kind 0), against its algorithmic bytes — every weight matrix and
+    the tied logits matrix once, every audio's cross K/V once, the rows' self K/V, the logits written."""
+    from whisper_amd import hip
+    dims = engine.dims
+    task = hip.HipTask(engine, B, G, 64 if position <= 64 else dims.n_text_ctx)
+    try:
+        task.set_audio(feats.contiguous())
+        g = torch.Generator(device=feats.device).manual_seed(1)
+        toks = torch.randint(0, dims.n_vocab - 1600, (B * G, position), generator=g, device=feats.device)
+        task.prefill(toks, sel=[position - 1])
+        ms, nbytes = task.bench_kernel(0, 16)
+    finally:
+        task.close()
+    gbps = nbytes / (ms * 1e-3) / 1e9
+    return {"step_us": round(ms * 1e3, 1), "step_bytes": nbytes, "step_rows": B * G, "step_position": position,
+            "step_GBps": round(gbps, 1), "step_frac": round(gbps / HBM_PEAK_GBS, 4)}
+
+
+def event_ms(fn, device, reps: int = 5) -> float:
+    """median device time of fn() between two events on the current stream"""
+    fn()
+    torch.cuda.synchronize(device)
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return sorted(ts)[len(ts) // 2]
 
 
 def other_configs(device, N):
@@ -397,17 +505,33 @@ def other_configs(device, N):
         res[key] = {"ms_per_pass": round(ms, 2), "audio_s_per_s": round(30.0 * batch / (ms * 1e-3), 1), "steps": N,
                     "passes_ms": [round(x, 1) for x in times]}
         log(f"other config {key}: {ms:.1f} ms per pass = {30.0 * batch / (ms * 1e-3):.0f} audio-s/s")
+        # where this leg stands against the hardware: log-mel, encoder (MFMA peak), one decode step (HBM peak)
+        mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
+        mel_ms = event_ms(lambda: whisper_amd.log_mel_spectrogram(audio, dims.n_mels), device)
+        enc_ms = event_ms(lambda: eng.encode(mel), device, reps=3)
+        flop = encoder_flop(dims, batch)
+        res[key].update({"mel_us": round(mel_ms * 1e3, 1), "encoder_ms": round(enc_ms, 3),
+                         "encoder_TFLOPs": round(flop / (enc_ms * 1e-3) / 1e12, 1),
+                         "encoder_frac": round(flop / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)})
+        res[key].update(step_roofline(eng, eng.encode(mel), batch, 1, 4 + N // 2))
+        log(f"other config {key}: mel {mel_ms * 1e3:.0f} us, encoder {res[key]['encoder_TFLOPs']} TFLOP/s, "
+            f"step {res[key]['step_us']} us = {res[key]['step_frac']} of HBM peak")
         eng.drop_cached_tasks()
         m = eng = None
         torch.cuda.empty_cache()
     return res
 
 
-def cpu_baseline(args, dims, init, suppress, tok, audio_np, sd, hip_row0):
+def cpu_baseline(args, dims, init, suppress, tok, audio_np, sd, hip_rows):
     """Oracle = "port": same algorithm as the reference's CPU fp32 path (calibrated beside the live reference in
-    BASELINE.md).  Bounded sample: 1 clip; log-mel + encoder + `cpu_steps` decode steps, one warm-up and
-    `cpu_repeats` timed repetitions of each stage, medians; audio-s/s extrapolated linearly to `sample_len` steps.
-    The tokens of those steps are compared with row 0 of the HIP pass (same weights, same clip)."""
+    BASELINE.md §2b).  Bounded sample, two legs on the same workload:
+      batch 1  — clip 0: log-mel + encoder + `cpu_steps` decode steps, one warm-up and `cpu_repeats` timed repetitions
+                 of each stage, medians -> `value` (audio-s/s extrapolated linearly to `sample_len` steps);
+      batch B  — all clips as ONE batch, as the reference's decode() can (decoding.py:713-789) and as the GPU pass runs:
+                 the encoder once, `parity_steps` decode steps once (this run also yields the tokens every HIP row is
+                 compared with) + repetitions of `cpu_steps` steps -> `value_batch8`, the fair side of the GPU / CPU ratio
+                 (the 6 GB fp32 weight read of a step is shared by the rows).
+    `hip_rows`: the sampled tokens of every row of the timed HIP pass (same weights, same clips), or None."""
     import oracle
     from whisper_amd.utils import usable_cores
     cores = getattr(args, "cpu_threads", 0) or usable_cores()
@@ -416,6 +540,7 @@ def cpu_baseline(args, dims, init, suppress, tok, audio_np, sd, hip_row0):
     om = oracle.OracleModel(dims, sd)
     filt = oracle.mel_filterbank(dims.n_mels)
     reps = max(1, args.cpu_repeats)
+    B = audio_np.shape[0]
 
     def timed(fn, n):
         fn()                                       # warm-up (thread pool, allocator, caches)
@@ -435,7 +560,7 @@ def cpu_baseline(args, dims, init, suppress, tok, audio_np, sd, hip_row0):
                                  suppress_tokens=suppress, blank_token=tok.encode(" ")[0], no_speech=tok.no_speech)
     k = args.cpu_steps
     with torch.no_grad():
-        dec, t_dec = timed(lambda: oracle.greedy_decode(om, feats, init, k, rules, keep_logits=True), reps)
+        dec, t_dec = timed(lambda: oracle.greedy_decode(om, feats, init, k, rules), reps)
     per_step = [t / k for t in t_dec]
     log(f"cpu_baseline: {k} decode steps, median {statistics.median(t_dec):.2f}s (x{reps})")
     m_mel, m_enc, m_step = statistics.median(t_mel), statistics.median(t_enc), statistics.median(per_step)
@@ -447,20 +572,58 @@ def cpu_baseline(args, dims, init, suppress, tok, audio_np, sd, hip_row0):
             "sample": f"1 clip of the same workload, 1 warm-up + {reps} repeats, medians: log-mel {m_mel:.3f}s + encoder "
                       f"{m_enc:.2f}s + {k} decode steps at {m_step * 1e3:.0f} ms/step, extrapolated to {args.sample_len} "
                       f"steps (fp32, torch CPU, {cores} threads)"}
-    # parity of the benchmarked engine: the oracle's tokens for clip 0 against row 0 of the HIP pass
-    want = dec["tokens"][0, len(init):].tolist()
-    if hip_row0 is None:                       # tools/cpu_baseline_only.py: no HIP pass to compare with
+    if B == 1:
         return base, None
-    got = hip_row0[: len(want)]
-    t = oracle.first_divergence(got, want)
-    parity = {"steps": len(want), "tokens_equal": t is None, "first_divergence": t, "margin": None,
-              "rule": f"fp16 engine: equal, or the first difference is a near-tie (< {2 * FP16_LOGIT_BOUND}) in the "
-                      "oracle's filtered logits"}
-    if t is not None:
-        lg = dec["step_logits"][t][0]
-        parity["margin"] = round(float(lg[want[t]]) - float(lg[got[t]]), 5)
-        parity["near_tie"] = bool(0 <= parity["margin"] < 2 * FP16_LOGIT_BOUND)
-    log(f"parity vs oracle (clip 0, {len(want)} steps): {parity}")
+    # ---- the GPU's own batch: B clips in one oracle batch
+    kp = max(args.parity_steps, 1)
+    t0 = time.perf_counter()
+    mels = torch.stack([oracle.log_mel_spectrogram(audio_np[b], filt) for b in range(B)])
+    t_melB = time.perf_counter() - t0
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        featsB = om.encoder(mels)
+        t_encB = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        decB = oracle.greedy_decode(om, featsB, init, kp, rules, keep_logits=True)       # also the warm-up of this shape
+        t_first = time.perf_counter() - t0
+        repsB = max(1, min(reps, 2))
+        tB = []
+        for _ in range(repsB):
+            t0 = time.perf_counter()
+            oracle.greedy_decode(om, featsB, init, k, rules)
+            tB.append((time.perf_counter() - t0) / k)
+    stepB = statistics.median(tB)
+    totalB = t_melB + t_encB + stepB * args.sample_len
+    base["value_batch8"] = round(30.0 * B / totalB, 3)
+    base["batch8"] = {"clips": B, "encoder_s": round(t_encB, 2), "ms_per_step": round(stepB * 1e3, 1),
+                      "first_run_ms_per_step": round(t_first / kp * 1e3, 1), "repeats": repsB,
+                      "sample": f"{B} clips as one batch: log-mel {t_melB:.2f}s + encoder {t_encB:.1f}s (once) + decode steps at "
+                                f"{stepB * 1e3:.0f} ms/step (median of {repsB} x {k} steps after a {kp}-step first run), "
+                                f"extrapolated to {args.sample_len} steps"}
+    log(f"cpu_baseline batch {B}: encoder {t_encB:.1f}s, {stepB * 1e3:.0f} ms/step -> {base['value_batch8']} audio-s/s")
+    if hip_rows is None:                       # tools/cpu_baseline_only.py: no HIP pass to compare with
+        return base, None
+    # ---- parity of the benchmarked engine: every row of the timed HIP pass against the oracle's tokens for that clip
+    bound = 2 * FP16_FULL_DEPTH_MAX
+    rows, n_eq, n_tie = [], 0, 0
+    for b in range(B):
+        want = decB["tokens"][b, len(init):].tolist()
+        got = hip_rows[b][: len(want)]
+        t = oracle.first_divergence(got, want)
+        row = {"row": b, "first_divergence": t, "margin": None}
+        if t is None:
+            n_eq += 1
+        else:
+            lg = decB["step_logits"][t][b]
+            row["margin"] = round(float(lg[want[t]]) - float(lg[got[t]]), 5)
+            row["near_tie"] = bool(0 <= row["margin"] < bound)
+            n_tie += int(row["near_tie"])
+        rows.append(row)
+    parity = {"rows": B, "steps": kp, "rows_equal": n_eq, "rows_near_tie": n_tie, "rows_wrong": B - n_eq - n_tie,
+              "tokens_equal": n_eq == B, "per_row": rows,
+              "rule": f"fp16 engine vs fp32 oracle, all {B} rows x {kp} steps: ids equal, or the first difference of a row is a "
+                      f"near-tie (< {bound} = twice the measured full-depth fp16 logit bound) in the oracle's filtered logits"}
+    log(f"parity vs oracle ({B} rows x {kp} steps): equal {n_eq}, near-tie {n_tie}, wrong {B - n_eq - n_tie}")
     return base, parity
 
 

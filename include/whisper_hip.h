@@ -102,6 +102,9 @@ typedef struct wh_model_weights {
  *   they are.  Without the flag the kernel multiplies by 0.125 log2 e itself.  whisper_amd.hip.pack_weights sets it
  *   for WH_F16 blobs; the decoder's attention is never pre-scaled. */
 #define WH_WEIGHTS_ENC_QK_SCALED 2u
+/* wh_model_create rejects (WH_ERR_ARG) any other bit in `flags`, and any flag with WH_F32: zero the struct before
+ * filling it.  whisper_amd.hip.pack_weights records the flags in the last 64 bytes of the blob it returns
+ * (int32 magic "WHB1", dtype, flags) so that they travel with the bytes. */
 
 typedef struct wh_model wh_model;   /* opaque: dims + copies of the pointer tables */
 typedef struct wh_task wh_task;     /* opaque: per-DecodingTask KV caches + workspace carve-up.  One call at a time per
@@ -257,6 +260,19 @@ int wh_median_filter(const float *x, float *out, int64_t rows, int n, int width,
  * and dtw_cpu's tie rule (timing.py:95-100); row 0 / column 0 hold the codes backtrace() forces there
  * (timing.py:61-62).  N <= 8192. */
 int wh_dtw_trace(const float *x, int N, int M, int8_t *trace_out, void *stream);
+/* backtrace() of whisper/timing.py:57-79 for a batch of traces, on the device: clip b's trace is dense
+ * int8 [(n_rows[b] + 1)][(n_cols[b] + 1)] at trace + b * trace_stride (as wh_dtw_trace / wh_task_align_batch write it);
+ * d_n_rows / d_n_cols are DEVICE int32 arrays of n_clips entries, max_rows / max_cols their maxima.
+ *   jumps_out (device int32 [n_clips][jump_stride], jump_stride >= max_rows, or NULL): entry [b][i] = the time index of the
+ *     first path element whose text index is i — `time_indices[jumps]` of timing.py:226-228, what find_alignment turns
+ *     into word boundaries (only these n_rows[b] ints per clip have to reach the host, not the trace);
+ *   path_out (device int32 [n_clips][2][path_stride], path_stride >= max_rows + max_cols, or NULL) with path_len_out
+ *     (device int32 [n_clips]): the (text, time) index pairs of `dtw()` (timing.py:141-151), RIGHT-aligned: row 0 =
+ *     text indices, row 1 = time indices, both in [path_stride - len, path_stride); len = -1 if a trace code was invalid
+ *     (the reference raises ValueError there). */
+int wh_dtw_backtrace_batch(const int8_t *trace, int64_t trace_stride, const int32_t *d_n_rows, const int32_t *d_n_cols,
+                           int n_clips, int max_rows, int max_cols, int32_t *jumps_out, int64_t jump_stride,
+                           int32_t *path_out, int64_t path_stride, int32_t *path_len_out, void *stream);
 /* find_alignment's attention post-processing — whisper/timing.py:207-216: qk fp32 [n_heads][n_tok][n_audio_ctx]
  * (from wh_task_cross_qk) -> crop to the first n_frames frames, softmax(qk * qk_scale) over frames, z-normalise
  * over the token axis (biased std), median filter of odd `width` along frames, mean over heads, keep token rows

@@ -210,6 +210,73 @@ def test_dtw(gpu_device, N, M):
     assert np.array_equal(oracle.backtrace(got), oracle.backtrace(want))
 
 
+@pytest.mark.parametrize("N,M", [(1, 1), (10, 20), (32, 16), (123, 1500), (234, 189), (447, 1500), (700, 1500)])
+def test_dtw_backtrace_on_device(gpu_device, N, M):
+    """wh_dtw_backtrace_batch (timing.py:57-79 on the device, a lane per clip on the 2-bit LDS copy of the trace; the
+    700 x 1500 trace does not fit the LDS and is walked in global memory): the path equals the oracle's `dtw_path`
+    entry by entry, the jump frames equal `time_indices[jumps]` (timing.py:226-228); also the planted monotone path of
+    the reference's tests/test_timing.py:20-46 generator, and `whisper_amd.timing.dtw` end to end."""
+    from whisper_amd.timing import dtw
+    rng = np.random.default_rng(N * 31 + M)
+    x = rng.standard_normal((N, M)).astype(np.float32)
+    want = oracle.dtw_path(x)
+    trace = hip.dtw_trace(torch.from_numpy(x).to(gpu_device))
+    jumps, path = hip.dtw_backtrace(trace)
+    assert np.array_equal(path.cpu().numpy(), want)
+    ti, fi = want
+    first = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
+    assert np.array_equal(jumps.cpu().numpy(), fi[first])
+    assert np.array_equal(dtw(torch.from_numpy(x).to(gpu_device)), want)
+    # a planted path: cost 1 everywhere except 0 along a random monotone walk (tests/test_timing.py:20-46)
+    steps = np.concatenate([np.zeros(M - 1, np.uint8), np.ones(N - 1, np.uint8)])
+    rng.shuffle(steps)
+    pi, pj = [0], [0]
+    for st in steps:
+        pi.append(pi[-1] + int(st == 1))
+        pj.append(pj[-1] + int(st == 0))
+    y = np.ones((N, M), np.float32)
+    y[pi, pj] = 0
+    got = dtw(torch.from_numpy(y).to(gpu_device))
+    assert np.array_equal(got, oracle.dtw_path(y))
+    assert np.array_equal(got[0], pi) and np.array_equal(got[1], pj)
+
+
+def test_dtw_backtrace_batch_ragged(gpu_device):
+    """several clips of different sizes in one launch, incl. a clip whose trace holds an invalid code (length -1)"""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    sizes = [(12, 40), (57, 211), (3, 1500), (230, 1500)]
+    Nm, Mm = max(n for n, _ in sizes), max(m for _, m in sizes)
+    stride = (Nm + 1) * (Mm + 1)
+    traces = torch.zeros(len(sizes) + 1, stride, dtype=torch.int8)
+    wants = []
+    for b, (n, m) in enumerate(sizes):
+        x = rng.standard_normal((n, m)).astype(np.float32)
+        tr = oracle.dtw_trace(x)
+        traces[b, : tr.size] = torch.from_numpy(tr.reshape(-1))
+        wants.append(oracle.backtrace(tr))
+    bad = np.full((5, 7), 2, np.int8); bad[:, 0] = 1; bad[3, 4] = -1; bad[4, 6] = 0; bad[4, 5] = 0
+    bad[4, 6] = 1                                                                # (4,6) up -> (3,6) left ... -> (3,4): invalid
+    traces[len(sizes), : bad.size] = torch.from_numpy(bad.reshape(-1))
+    rows = torch.tensor([n for n, _ in sizes] + [4], dtype=torch.int32).to(gpu_device)
+    cols = torch.tensor([m for _, m in sizes] + [6], dtype=torch.int32).to(gpu_device)
+    d_tr = traces.to(gpu_device)
+    R = len(sizes) + 1
+    jumps = torch.zeros(R, Nm, dtype=torch.int32, device=gpu_device)
+    path = torch.zeros(R, 2, Nm + Mm, dtype=torch.int32, device=gpu_device)
+    plen = torch.zeros(R, dtype=torch.int32, device=gpu_device)
+    s = torch.cuda.current_stream(gpu_device)
+    hip.check(hip.lib().wh_dtw_backtrace_batch(d_tr.data_ptr(), stride, rows.data_ptr(), cols.data_ptr(), R, Nm, Mm,
+                                               jumps.data_ptr(), Nm, path.data_ptr(), Nm + Mm, plen.data_ptr(), hip.stream_ptr(s)))
+    plen_h, path_h, jumps_h = plen.cpu().tolist(), path.cpu().numpy(), jumps.cpu().numpy()
+    for b, want in enumerate(wants):
+        assert plen_h[b] == want.shape[1]
+        assert np.array_equal(path_h[b][:, Nm + Mm - plen_h[b]:], want)
+        first = np.pad(np.diff(want[0]), (1, 0), constant_values=1).astype(bool)
+        assert np.array_equal(jumps_h[b, : sizes[b][0]], want[1][first])
+    assert plen_h[-1] == -1                                                      # the reference raises ValueError there
+
+
 @pytest.mark.parametrize("n_steps", [1, 2, 7, 8, 9, 17])
 def test_fused_greedy_step_count_edges(micro, gpu_device, n_steps):
     """the device loop polls for completion every 8 tokens: step counts around that period and the degenerate

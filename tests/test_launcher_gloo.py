@@ -101,6 +101,71 @@ def test_balanced_shards():
         assert max(loads) - min(loads) <= max(costs)
 
 
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` without a launcher re-executes itself as the driver would launch it: one process per
+    GPU under torch.distributed.run, one node, rendezvous on 127.0.0.1, every bench flag carried over, the caller's
+    environment kept and the dmabuf-IPC switch RCCL needs on this driver set"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    os.environ["WH_TEST_SENTINEL"] = "kept"
+    try:
+        cmd, env = bench.torchrun_command(8, ["--gpus", "8", "--steps", "5", "--warmup", "2"], 29777)
+    finally:
+        del os.environ["WH_TEST_SENTINEL"]
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29777"
+    script = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    assert env["WH_TEST_SENTINEL"] == "kept" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert env["MASTER_ADDR"] == "127.0.0.1"
+
+
+def _worker_large(rank, world, port, q):
+    """the weight broadcast with the REAL byte layout of large-v3 (3.1 GB fp16 blob, sizes only: zeros + one marker per
+    packed tensor + the header pack_weights writes), world 2 over gloo"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dims = dims_for("large-v3")
+        layout, total = hip.blob_layout(dims, hip.WH_F16)
+        blob = None
+        if rank == 0:
+            blob = torch.zeros(total, dtype=torch.uint8)
+            for k, (name, (off, shape, mat)) in enumerate(layout.items()):
+                blob[off: off + 8].view(torch.int64)[0] = k + 1                  # a marker at the start of every tensor
+            flags = hip.WH_WEIGHTS_DEC_LN_FOLDED | hip.WH_WEIGHTS_ENC_QK_SCALED
+            blob[total - 64: total - 48].view(torch.int32).copy_(torch.tensor([hip.BLOB_MAGIC, hip.WH_F16, flags, 0], dtype=torch.int32))
+        got = launcher.broadcast_weights(blob, dims, hip.WH_F16, torch.device("cpu"), dist)
+        marks = [int(got[off: off + 8].view(torch.int64)[0]) for off, _, _ in layout.values()]
+        q.put((rank, int(got.numel()), int(got.view(torch.int64).sum()), marks == list(range(1, len(layout) + 1)),
+               hip.blob_header(got, total)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_large_v3_layout_world2():
+    """rank 1 receives exactly rank 0's bytes for the real large-v3 layout (every tensor's marker at its offset, the
+    header with the packing flags at the tail), i.e. both ranks derive the same layout from the dims alone"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_large, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, n0, c0, ok0, h0), (r1, n1, c1, ok1, h1) = out
+    assert n0 == n1 > 3_000_000_000 and n0 % 8 == 0
+    assert c0 == c1 != 0 and ok0 and ok1
+    assert h0 == h1 == (hip.WH_F16, hip.WH_WEIGHTS_DEC_LN_FOLDED | hip.WH_WEIGHTS_ENC_QK_SCALED)
+
+
 @pytest.mark.gpu
 def test_broadcast_weights_nccl_world1(gpu_device):
     """the RCCL leg of the launcher on the real device: process group "nccl" (= RCCL on ROCm), world size 1 —

@@ -117,6 +117,10 @@ extern "C" int wh_model_create(const wh_dims* dims, int dtype, const wh_model_we
   if (d.n_audio_state % 64 != 0 || d.n_audio_state / 64 != d.n_audio_head || d.n_text_state / 64 != d.n_text_head)
     return WH_ERR_ARG;   // d_head == 64 for every Whisper checkpoint
   if (d.n_audio_state > 2048 || d.n_mels > 128 || d.n_audio_ctx > 1536 || d.n_text_ctx > 1536) return WH_ERR_LIMIT;
+  // `flags` changes how the kernels read the blob: a caller built against an older struct (or one that left the field
+  // uninitialised) must fail here, not produce silently wrong LayerNorms / attention scores
+  if (weights->flags & ~(WH_WEIGHTS_DEC_LN_FOLDED | WH_WEIGHTS_ENC_QK_SCALED)) return WH_ERR_ARG;
+  if (dtype == WH_F32 && weights->flags != 0) return WH_ERR_ARG;     // the strict-parity engine keeps the reference's order
   wh_model* m = new (std::nothrow) wh_model();
   if (!m) return WH_ERR_ARG;
   m->d = d;
@@ -1230,6 +1234,20 @@ extern "C" int wh_dtw_trace(const float* x, int N, int M, int8_t* trace_out, voi
   if (!x || !trace_out || N <= 0 || M <= 0) return WH_ERR_ARG;
   if (N > 8192) return WH_ERR_LIMIT;
   HIPCHK(launch_dtw(x, N, M, trace_out, (hipStream_t)stream));
+  return WH_OK;
+}
+
+extern "C" int wh_dtw_backtrace_batch(const int8_t* trace, int64_t trace_stride, const int32_t* d_n_rows,
+                                      const int32_t* d_n_cols, int n_clips, int max_rows, int max_cols, int32_t* jumps_out,
+                                      int64_t jump_stride, int32_t* path_out, int64_t path_stride, int32_t* path_len_out,
+                                      void* stream) {
+  if (!trace || !d_n_rows || !d_n_cols || n_clips <= 0 || max_rows <= 0 || max_cols <= 0) return WH_ERR_ARG;
+  if (!jumps_out && !path_out) return WH_ERR_ARG;
+  if (jumps_out && jump_stride < max_rows) return WH_ERR_ARG;
+  if (path_out && (path_stride < (int64_t)max_rows + max_cols || !path_len_out)) return WH_ERR_ARG;
+  if (trace_stride < (int64_t)(max_rows + 1) * (max_cols + 1)) return WH_ERR_ARG;
+  HIPCHK(launch_dtw_backtrace_batch(trace, trace_stride, d_n_rows, d_n_cols, n_clips, max_rows, max_cols, jumps_out,
+                                    jump_stride, path_out, path_stride, path_len_out, (hipStream_t)stream));
   return WH_OK;
 }
 

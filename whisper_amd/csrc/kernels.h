@@ -217,6 +217,12 @@ hipError_t launch_align_batch(const float* qk, const int* d_ntok, const int* d_n
 // dtw of every clip's cost matrix; trace of clip b dense [(N_b + 1)][(F_b + 1)] at trace + b * trace_bs
 hipError_t launch_dtw_batch(const float* cost, const int* d_ntok, const int* d_nfr, int clips, int Tmax, int Fmax,
                             int row_begin, int row_tail, int Nmax, int8_t* trace, int64_t trace_bs, hipStream_t stream);
+// back-trace of every clip's trace (dense [(rows_b + 1)][(cols_b + 1)] at trace + b * trace_bs; d_rows / d_cols device
+// arrays): jumps [clips][jump_stride] = frame at which each text index is first reached; optional right-aligned path
+// [clips][2][path_stride] + path_len [clips]
+hipError_t launch_dtw_backtrace_batch(const int8_t* trace, int64_t trace_bs, const int* d_rows, const int* d_cols, int clips,
+                                      int max_rows, int max_cols, int* jumps, int64_t jump_stride, int* path,
+                                      int64_t path_stride, int* path_len, hipStream_t stream);
 // qk [H][T][Tk] -> softmax over first F frames, z-norm over tokens, median(width), -mean over heads of rows
 // [row_begin,row_end) -> out [rows][F]; scratch: 2*H*T*F floats + 2 ints
 hipError_t launch_align_matrix(const float* qk, int H, int T, int Tk, int F, int width, int row_begin,

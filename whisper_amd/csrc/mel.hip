@@ -25,19 +25,25 @@ constexpr int MEL_THREADS = 256;
 constexpr int SCR_LO = 16;
 constexpr int SCR_HI = 16 + 128;
 
-__global__ void mel_bands_kernel(const float* __restrict__ filters, int n_mels, int* __restrict__ scratch) {
-  int m = threadIdx.x;
-  if (m == 0) scratch[0] = float_to_ordered(WH_NEG_INF);
-  if (m >= n_mels) return;
+// first / last non-zero tap of every mel filter: one wave per filter (64 lanes x 4 taps cover the 201 bins, min / max
+// across the wave by DPP) — the round-2 version scanned the 201 taps serially in one thread per filter, 32.7 us per call
+__global__ __launch_bounds__(64) void mel_bands_kernel(const float* __restrict__ filters, int n_mels, int* __restrict__ scratch) {
+  const int m = blockIdx.x, lane = threadIdx.x;
+  if (m == 0 && lane == 0) scratch[0] = float_to_ordered(WH_NEG_INF);
   int lo = NBIN, hi = -1;
-  for (int k = 0; k < NBIN; ++k) {
-    if (filters[m * NBIN + k] != 0.0f) {
-      if (lo == NBIN) lo = k;
-      hi = k;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k = lane + 64 * e;
+    if (k < NBIN && filters[m * NBIN + k] != 0.0f) {
+      if (k < lo) lo = k;
+      if (k > hi) hi = k;
     }
   }
-  scratch[SCR_LO + m] = lo;
-  scratch[SCR_HI + m] = hi;
+  const float flo = -wave_max(-(float)lo), fhi = wave_max((float)hi);     // exact: |values| <= 201
+  if (lane == 0) {
+    scratch[SCR_LO + m] = (int)flo;
+    scratch[SCR_HI + m] = (int)fhi;
+  }
 }
 
 __global__ __launch_bounds__(MEL_THREADS) void mel_kernel(
@@ -130,7 +136,7 @@ hipError_t launch_log_mel(const float* audio, int64_t n_samples, int batch, int 
                           hipStream_t stream) {
   const int n_frames = (int)(n_samples / HOP);
   int* scr = (int*)scratch;
-  hipLaunchKernelGGL(mel_bands_kernel, dim3(1), dim3(128), 0, stream, filters, n_mels, scr);
+  hipLaunchKernelGGL(mel_bands_kernel, dim3(n_mels), dim3(64), 0, stream, filters, n_mels, scr);
   dim3 grid((n_frames + FT - 1) / FT, batch);
   hipLaunchKernelGGL(mel_kernel, grid, dim3(MEL_THREADS), 0, stream, audio, n_samples, n_frames, n_mels,
                      filters, tables, out, scr);

@@ -263,6 +263,66 @@ __global__ __launch_bounds__(1024) void dtw_batch_kernel(const float* __restrict
   }
 }
 
+
+// ---- back-trace of every clip's trace matrix on the device (timing.py:57-79) ------------------------------------------
+// One workgroup per clip.  The clip's int8 trace [(N+1)][(M+1)] is first packed to 2 bits per entry in LDS by all
+// threads (coalesced reads; a 230 x 1501 trace is 86 KB packed), then ONE lane walks it from (N, M) to the origin: an
+// LDS load per step instead of a dependent global load (the reference walks a numpy array on the host; round 2 copied
+// every clip's whole trace to the host for that).  Traces too large for the LDS are walked in global memory.
+// Outputs, per clip:
+//   jumps[i], i in [0, N): time index (frame) of the FIRST path entry whose text index is i — exactly
+//     `time_indices[jumps]` of timing.py:226-228 (the path visits every text index, in order);
+//   path (optional): the (text, time) pairs right-aligned in [2][path_stride] (entries [path_stride - len, path_stride)),
+//     path_len[clip] = len — the (2, len) array `dtw()` returns (timing.py:141-151).
+// Border rule as the reference: row 0 moves left, column 0 moves up (timing.py:61-62); a code outside {0,1,2} stops the
+// walk and reports length -1 (the reference raises ValueError).
+__global__ __launch_bounds__(1024) void dtw_backtrace_batch_kernel(const int8_t* __restrict__ trace_all, int64_t trace_bs,
+                                                                   const int* __restrict__ n_rows, const int* __restrict__ n_cols,
+                                                                   int lds_bytes, int* __restrict__ jumps, int64_t jump_stride,
+                                                                   int* __restrict__ path, int64_t path_stride,
+                                                                   int* __restrict__ path_len) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char packed[];
+  const int b = blockIdx.x;
+  const int N = n_rows[b], M = n_cols[b];
+  if (N <= 0 || M <= 0) { if (path_len && threadIdx.x == 0) path_len[b] = 0; return; }
+  const int8_t* trace = trace_all + b * trace_bs;
+  const int W = M + 1, RS = (W + 3) >> 2;                     // packed row stride in bytes
+  const bool in_lds = (int64_t)(N + 1) * RS <= lds_bytes;
+  if (in_lds) {
+    const int total = (N + 1) * RS;
+    for (int q = threadIdx.x; q < total; q += blockDim.x) {
+      const int i = q / RS, j0 = (q - i * RS) << 2;
+      const int8_t* src = trace + (int64_t)i * W + j0;
+      unsigned v = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (j0 + e < W) v |= ((unsigned)src[e] & 3u) << (2 * e);      // codes 0..2; anything else was never written (-1 -> 3)
+      packed[q] = (unsigned char)v;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  int i = N, j = M, len = 0;
+  int* jp = jumps ? jumps + b * jump_stride : nullptr;
+  int* pt = path ? path + b * 2 * path_stride : nullptr;
+  bool bad = false;
+  while (i > 0 || j > 0) {
+    if (jp && i >= 1) jp[i - 1] = j - 1;                       // the last write per i is the first entry in path order
+    if (pt && len < path_stride) { pt[path_stride - 1 - len] = i - 1; pt[2 * path_stride - 1 - len] = j - 1; }
+    ++len;
+    int t;
+    if (i == 0) t = 2;
+    else if (j == 0) t = 1;
+    else if (in_lds) t = (packed[i * RS + (j >> 2)] >> (2 * (j & 3))) & 3;
+    else t = trace[(int64_t)i * W + j] & 3;
+    if (t == 0) { --i; --j; }
+    else if (t == 1) --i;
+    else if (t == 2) --j;
+    else { bad = true; break; }
+  }
+  if (path_len) path_len[b] = bad ? -1 : len;
+}
+
 }  // namespace
 
 namespace whk {
@@ -307,6 +367,23 @@ hipError_t launch_dtw_batch(const float* cost, const int* d_ntok, const int* d_n
   if (threads > 1024) threads = 1024;
   const size_t lds = 3 * (size_t)(Nmax + 1) * sizeof(float);
   hipLaunchKernelGGL(dtw_batch_kernel, dim3(clips), dim3(threads), lds, stream, cost, ab, row_begin, row_tail, Nmax, trace, trace_bs);
+  return hipGetLastError();
+}
+
+hipError_t launch_dtw_backtrace_batch(const int8_t* trace, int64_t trace_bs, const int* d_rows, const int* d_cols, int clips,
+                                      int max_rows, int max_cols, int* jumps, int64_t jump_stride, int* path,
+                                      int64_t path_stride, int* path_len, hipStream_t stream) {
+  if (clips <= 0) return hipSuccess;
+  const int64_t need = (int64_t)(max_rows + 1) * ((max_cols + 4) >> 2);
+  const int LDS_MAX = 156 * 1024;
+  const int lds = need <= LDS_MAX ? (int)((need + 15) & ~15ll) : 0;          // 0: walk the global trace
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dtw_backtrace_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(dtw_backtrace_batch_kernel, dim3(clips), dim3(lds ? 1024 : 64), (size_t)lds, stream, trace, trace_bs,
+                     d_rows, d_cols, lds, jumps, jump_stride, path, path_stride, path_len);
   return hipGetLastError();
 }
 

@@ -400,7 +400,8 @@ class DecodingTask:
         """`prompts` (no counterpart in the reference, whose task shares ONE initial_tokens tuple between all rows,
         decoding.py:719): one previous-text token list per audio segment, each used exactly as
         `options.prompt` would be for that segment alone.  Prompts of different lengths ("ragged") are decoded by the
-        fused greedy loop, every row at its own positions; `options.prompt` must then be unset."""
+        device-side loops (greedy, sampling, beam search: wh_task_set_lag), every row at its own positions;
+        `options.prompt` must then be unset."""
         self.model = model
         tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages,
                                   language=options.language or "en", task=options.task)

@@ -6,6 +6,7 @@ point raises — there is deliberately no CPU fallback on the product path.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -107,6 +108,8 @@ SIGNATURES = {
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "wh_median_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "wh_dtw_trace": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "wh_dtw_backtrace_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "wh_align_matrix": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -304,7 +307,18 @@ def blob_layout(dims, dtype: int) -> Tuple[Dict[str, Tuple[int, Tuple[int, ...],
             n *= s
         layout[name] = (off, shape, mat)
         off = _align(off + n * (esize if mat else 4))
-    return layout, off + 4096   # tail slack: padded-K GEMM reads never leave the blob
+    return layout, off + 4096   # tail slack: padded-K GEMM reads never leave the blob; its last 64 bytes = blob_header
+
+
+BLOB_MAGIC = 0x31424857          # "WHB1"
+
+
+def blob_header(blob: torch.Tensor, total: int) -> Optional[Tuple[int, int]]:
+    """(dtype, flags) recorded by pack_weights in the last 64 bytes of the blob, or None for a blob packed without
+    a header.  The flags say how the kernels must read the weights (LayerNorm folded / softmax scale in q, k): they
+    travel WITH the bytes (also through broadcast_weights) instead of being re-derived from the dtype at load."""
+    h = blob[total - 64: total - 48].view(torch.int32).cpu().tolist()
+    return (h[1], h[2]) if h[0] == BLOB_MAGIC else None
 
 
 def pack_weights(sd: Dict[str, torch.Tensor], dims, dtype: int, device: torch.device) -> torch.Tensor:
@@ -318,6 +332,8 @@ def pack_weights(sd: Dict[str, torch.Tensor], dims, dtype: int, device: torch.de
         dt = tdt if mat else torch.float32
         nbytes = t.numel() * (2 if dt == torch.float16 else 4)
         blob[off: off + nbytes].view(dt).copy_(t.detach().to(device=device, dtype=dt).reshape(-1))
+    flags = (WH_WEIGHTS_DEC_LN_FOLDED if folds_decoder_ln(dtype) else 0) | (WH_WEIGHTS_ENC_QK_SCALED if scales_encoder_qk(dtype) else 0)
+    blob[total - 64: total - 48].view(torch.int32).copy_(torch.tensor([BLOB_MAGIC, dtype, flags, 0], dtype=torch.int32))
     return blob
 
 
@@ -348,8 +364,14 @@ class HipModel:
             setattr(w, f, addr(f))
         w.enc_layers = C.cast(self._enc, C.POINTER(LayerWeights))
         w.dec_layers = C.cast(self._dec, C.POINTER(LayerWeights))
-        w.flags = (WH_WEIGHTS_DEC_LN_FOLDED if folds_decoder_ln(dtype) else 0) | (
-            WH_WEIGHTS_ENC_QK_SCALED if scales_encoder_qk(dtype) else 0)
+        hdr = blob_header(blob, total)
+        if hdr is not None:                            # the blob says how it was packed
+            if hdr[0] != dtype:
+                raise HipError(f"weight blob was packed for dtype {hdr[0]}, engine asked for {dtype}")
+            w.flags = hdr[1]
+        else:                                          # header-less blob (packed by an older pack_weights)
+            w.flags = (WH_WEIGHTS_DEC_LN_FOLDED if folds_decoder_ln(dtype) else 0) | (
+                WH_WEIGHTS_ENC_QK_SCALED if scales_encoder_qk(dtype) else 0)
         d = Dims(*[getattr(dims, n) for n, _ in Dims._fields_])
         h = C.c_void_p()
         check(lib().wh_model_create(C.byref(d), dtype, C.byref(w), C.byref(h)), "wh_model_create")
@@ -357,7 +379,15 @@ class HipModel:
         self.stream = torch.cuda.Stream(device=self.device)
         self._enc_ws: Optional[torch.Tensor] = None
         self._task_cache: List["HipTask"] = []          # idle tasks, most recently used last
-        self.task_cache_bytes = 24 << 30                # workspaces kept alive between windows (288 GB HBM per GPU)
+        # workspaces kept alive between windows: WH_TASK_CACHE_GB, else 10 % of the device memory (28 GB of the 288 GB of
+        # an MI355X; a smaller GPU gets a smaller cache).  Allocation failures anywhere on this engine's path drop the
+        # cache and retry once (`_alloc`), because torch's own out-of-memory retry cannot reclaim tensors we hold.
+        env = os.environ.get("WH_TASK_CACHE_GB")
+        if env is not None:
+            self.task_cache_bytes = int(float(env) * (1 << 30))
+        else:
+            with torch.cuda.device(self.device):
+                self.task_cache_bytes = int(torch.cuda.mem_get_info()[1] * 0.10)
 
     # -- decoding tasks are expensive to set up (GBs of workspace, a 250-node graph capture): keep them -------------
     def acquire_task(self, n_audio: int, n_group: int, max_prefill: int, capture_q: bool = False,
@@ -381,9 +411,22 @@ class HipModel:
         task._cached = True
         return task
 
+    def _alloc(self, nbytes: int) -> torch.Tensor:
+        """device bytes for a workspace; when the allocator is out of memory the idle cached tasks go first"""
+        try:
+            return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        except torch.OutOfMemoryError:
+            if not self._task_cache:
+                raise
+            self.drop_cached_tasks()
+            torch.cuda.empty_cache()
+            return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
     def _release_task(self, task: "HipTask") -> bool:
         if task.ws is None or task.ws.numel() > self.task_cache_bytes:
             return False
+        if any(t is task for t in self._task_cache):     # closed twice: it is already idle, do not list it again
+            return True
         self._task_cache.append(task)
         total = sum(t.ws.numel() for t in self._task_cache)
         while total > self.task_cache_bytes and len(self._task_cache) > 1:
@@ -418,14 +461,14 @@ class HipModel:
         need = lib().wh_encoder_workspace_bytes(self.handle, B)
         if self._enc_ws is None or self._enc_ws.numel() < need:
             self._enc_ws = None
-            self._enc_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._enc_ws = self._alloc(need)
         out = torch.empty(B, d.n_audio_ctx, d.n_audio_state, dtype=self.torch_dtype, device=self.device)
-        torch.cuda.set_device(self.device)             # the C ABI launches on the calling thread's current device
-        cur = torch.cuda.current_stream(self.device)
-        self.stream.wait_stream(cur)
-        check(lib().wh_encode(self.handle, mel.data_ptr(), int(mel.dtype == torch.float16), B, out.data_ptr(),
-                              self._enc_ws.data_ptr(), self._enc_ws.numel(), stream_ptr(self.stream)), "wh_encode")
-        cur.wait_stream(self.stream)
+        with torch.cuda.device(self.device):           # the C ABI launches on the calling thread's current device
+            cur = torch.cuda.current_stream(self.device)
+            self.stream.wait_stream(cur)
+            check(lib().wh_encode(self.handle, mel.data_ptr(), int(mel.dtype == torch.float16), B, out.data_ptr(),
+                                  self._enc_ws.data_ptr(), self._enc_ws.numel(), stream_ptr(self.stream)), "wh_encode")
+            cur.wait_stream(self.stream)
         mel.record_stream(self.stream)
         return out
 
@@ -449,7 +492,7 @@ class HipTask:
             need = lib().wh_task_workspace_bytes(model.handle, n_audio, n_group, max_prefill, flags)
             if need == 0:
                 raise HipError("wh_task_workspace_bytes: invalid arguments")
-            self.ws = torch.empty(need, dtype=torch.uint8, device=model.device)
+            self.ws = model._alloc(need)
             h = C.c_void_p()
             check(lib().wh_task_create(model.handle, n_audio, n_group, max_prefill, flags, self.ws.data_ptr(),
                                        self.ws.numel(), C.byref(h)), "wh_task_create")
@@ -484,18 +527,22 @@ class HipTask:
         except Exception:   # noqa: BLE001 — interpreter shutdown: module globals (even HipError) may already be None
             pass            # (the library or torch may already be gone)
 
-    def _enter(self):
-        torch.cuda.set_device(self.model.device)       # the C ABI launches on the calling thread's current device
-        cur = torch.cuda.current_stream(self.model.device)
-        self.stream.wait_stream(cur)
-        return cur
+    @contextlib.contextmanager
+    def _call(self):
+        """one C-ABI call on the task's stream: the library launches on the calling thread's CURRENT device, so make the
+        model's device current for the duration of the call (and restore the caller's afterwards); the task's stream
+        waits for the caller's stream before the call and the caller's stream for the task's after it"""
+        with torch.cuda.device(self.model.device):
+            cur = torch.cuda.current_stream(self.model.device)
+            self.stream.wait_stream(cur)
+            yield cur
+            cur.wait_stream(self.stream)
 
     def set_audio(self, features: torch.Tensor):
         assert features.is_cuda and features.dtype == self.model.torch_dtype and features.is_contiguous()
         assert features.shape[0] == self.n_audio
-        cur = self._enter()
-        check(lib().wh_task_set_audio(self.handle, features.data_ptr(), stream_ptr(self.stream)), "wh_task_set_audio")
-        cur.wait_stream(self.stream)
+        with self._call():
+            check(lib().wh_task_set_audio(self.handle, features.data_ptr(), stream_ptr(self.stream)), "wh_task_set_audio")
         features.record_stream(self.stream)
 
     def prefill(self, tokens: torch.Tensor, sel: Optional[Sequence[int]] = None) -> torch.Tensor:
@@ -505,10 +552,9 @@ class HipTask:
         n_sel = T0 if sel is None else len(sel)
         logits = torch.empty(self.n_rows, n_sel, self.model.dims.n_vocab, dtype=torch.float32, device=tokens.device)
         sel_arr = None if sel is None else (C.c_int32 * n_sel)(*sel)
-        cur = self._enter()
-        check(lib().wh_task_prefill(self.handle, tokens.data_ptr(), tokens.stride(0), T0, sel_arr, n_sel,
-                                    logits.data_ptr(), stream_ptr(self.stream)), "wh_task_prefill")
-        cur.wait_stream(self.stream)
+        with self._call():
+            check(lib().wh_task_prefill(self.handle, tokens.data_ptr(), tokens.stride(0), T0, sel_arr, n_sel,
+                                        logits.data_ptr(), stream_ptr(self.stream)), "wh_task_prefill")
         tokens.record_stream(self.stream)
         return logits
 
@@ -516,24 +562,21 @@ class HipTask:
         """last_tokens: int64 view [n_rows] (any stride)."""
         assert last_tokens.is_cuda and last_tokens.dtype == torch.int64 and last_tokens.dim() == 1
         logits = torch.empty(self.n_rows, self.model.dims.n_vocab, dtype=torch.float32, device=last_tokens.device)
-        cur = self._enter()
-        check(lib().wh_task_step(self.handle, last_tokens.data_ptr(), last_tokens.stride(0), logits.data_ptr(),
-                                 stream_ptr(self.stream)), "wh_task_step")
-        cur.wait_stream(self.stream)
+        with self._call():
+            check(lib().wh_task_step(self.handle, last_tokens.data_ptr(), last_tokens.stride(0), logits.data_ptr(),
+                                     stream_ptr(self.stream)), "wh_task_step")
         last_tokens.record_stream(self.stream)
         return logits
 
     def rearrange(self, source_indices: Sequence[int]):
         arr = (C.c_int32 * len(source_indices))(*[int(i) for i in source_indices])
         assert len(source_indices) == self.n_rows
-        cur = self._enter()
-        check(lib().wh_task_rearrange(self.handle, arr, stream_ptr(self.stream)), "wh_task_rearrange")
-        cur.wait_stream(self.stream)
+        with self._call():
+            check(lib().wh_task_rearrange(self.handle, arr, stream_ptr(self.stream)), "wh_task_rearrange")
 
     def reset(self):
-        cur = self._enter()
-        check(lib().wh_task_reset(self.handle, stream_ptr(self.stream)), "wh_task_reset")
-        cur.wait_stream(self.stream)
+        with self._call():
+            check(lib().wh_task_reset(self.handle, stream_ptr(self.stream)), "wh_task_reset")
 
     def set_lag(self, lag: Optional[Sequence[int]]):
         """ragged prompts: row r's sequence is the longest row's shifted left by lag[r] (include/whisper_hip.h)"""
@@ -541,9 +584,8 @@ class HipTask:
         if lag is not None:
             assert len(lag) == self.n_rows
             arr = (C.c_int32 * len(lag))(*[int(v) for v in lag])
-        cur = self._enter()
-        check(lib().wh_task_set_lag(self.handle, arr, stream_ptr(self.stream)), "wh_task_set_lag")
-        cur.wait_stream(self.stream)
+        with self._call():
+            check(lib().wh_task_set_lag(self.handle, arr, stream_ptr(self.stream)), "wh_task_set_lag")
 
     @property
     def position(self) -> int:
@@ -557,11 +599,10 @@ class HipTask:
         sum_lp = torch.empty(self.n_rows, dtype=torch.float32, device=dev)
         nsp = torch.empty(self.n_rows, dtype=torch.float32, device=dev) if no_speech_token >= 0 else None
         n_out = C.c_int32(0)
-        cur = self._enter()
-        check(lib().wh_task_greedy(self.handle, C.byref(params), tokens.data_ptr(), tokens.stride(0), sot_index,
-                                   no_speech_token, sum_lp.data_ptr(), _ptr(nsp), C.byref(n_out),
-                                   stream_ptr(self.stream)), "wh_task_greedy")
-        cur.wait_stream(self.stream)
+        with self._call():
+            check(lib().wh_task_greedy(self.handle, C.byref(params), tokens.data_ptr(), tokens.stride(0), sot_index,
+                                       no_speech_token, sum_lp.data_ptr(), _ptr(nsp), C.byref(n_out),
+                                       stream_ptr(self.stream)), "wh_task_greedy")
         return n_out.value, sum_lp, nsp
 
     def beam(self, tokens: torch.Tensor, params: BeamParams, sot_index: int, no_speech_token: int):
@@ -579,21 +620,19 @@ class HipTask:
         fin_score = torch.zeros(n_audio, mc, dtype=torch.float32, device=dev)
         fin_count = torch.zeros(n_audio, dtype=torch.int32, device=dev)
         n_out = C.c_int32(0)
-        cur = self._enter()
-        check(lib().wh_task_beam(self.handle, C.byref(params), tokens.data_ptr(), stride, sot_index, no_speech_token,
-                                 sum_lp.data_ptr(), _ptr(nsp), fin_tok.data_ptr(), fin_len.data_ptr(),
-                                 fin_score.data_ptr(), fin_count.data_ptr(), C.byref(n_out),
-                                 stream_ptr(self.stream)), "wh_task_beam")
-        cur.wait_stream(self.stream)
+        with self._call():
+            check(lib().wh_task_beam(self.handle, C.byref(params), tokens.data_ptr(), stride, sot_index, no_speech_token,
+                                     sum_lp.data_ptr(), _ptr(nsp), fin_tok.data_ptr(), fin_len.data_ptr(),
+                                     fin_score.data_ptr(), fin_count.data_ptr(), C.byref(n_out),
+                                     stream_ptr(self.stream)), "wh_task_beam")
         return n_out.value, sum_lp, nsp, (fin_tok, fin_len, fin_score, fin_count)
 
     def bench_kernel(self, kind: int, iters: int) -> Tuple[float, float]:
         """(average ms per launch, algorithmic bytes per launch): `iters` layer-rotated launches replayed from a hipGraph
         and timed with HIP events on the launch stream inside wh_task_bench_kernel (best of 3 replays)"""
         nbytes, ms = C.c_double(0.0), C.c_float(0.0)
-        cur = self._enter()
-        check(lib().wh_task_bench_kernel(self.handle, kind, iters, C.byref(nbytes), C.byref(ms), stream_ptr(self.stream)), "bench")
-        cur.wait_stream(self.stream)
+        with self._call():
+            check(lib().wh_task_bench_kernel(self.handle, kind, iters, C.byref(nbytes), C.byref(ms), stream_ptr(self.stream)), "bench")
         return float(ms.value), nbytes.value
 
     def cross_qk(self, row: int, layers: Sequence[int], heads: Sequence[int], tok_begin: int, n_tok: int) -> torch.Tensor:
@@ -601,17 +640,18 @@ class HipTask:
         out = torch.empty(n, n_tok, self.model.dims.n_audio_ctx, dtype=torch.float32, device=self.model.device)
         la = (C.c_int32 * n)(*[int(x) for x in layers])
         ha = (C.c_int32 * n)(*[int(x) for x in heads])
-        cur = self._enter()
-        check(lib().wh_task_cross_qk(self.handle, row, la, ha, n, tok_begin, n_tok, out.data_ptr(),
-                                     stream_ptr(self.stream)), "wh_task_cross_qk")
-        cur.wait_stream(self.stream)
+        with self._call():
+            check(lib().wh_task_cross_qk(self.handle, row, la, ha, n, tok_begin, n_tok, out.data_ptr(),
+                                         stream_ptr(self.stream)), "wh_task_cross_qk")
         return out
 
 
     def align_batch(self, layers: Sequence[int], heads: Sequence[int], n_tok: Sequence[int], n_frames: Sequence[int],
                     width: int, row_begin: int, qk_scale: float = 1.0):
-        """find_alignment core for every row of the task (wh_task_align_batch).  Returns (cost [R][Nmax][Fmax] fp32,
-        traces: list of int8 numpy arrays [(N_r + 1)][(n_frames[r] + 1)])."""
+        """find_alignment core for every row of the task (wh_task_align_batch + wh_dtw_backtrace_batch).  Returns
+        (cost [R][Nmax][Fmax] fp32, jumps int32 [R][Nmax], both on the device): jumps[r][i] = the frame at which the DTW
+        path of clip r first reaches text row i (`time_indices[jumps]` of timing.py:226-228).  Nothing is copied to the
+        host here and nothing synchronises beyond the C call's own upload of the size arrays."""
         R, P = self.n_rows, len(layers)
         assert len(n_tok) == R and len(n_frames) == R
         Tmax, Fmax = max(n_tok), max(n_frames)
@@ -622,20 +662,20 @@ class HipTask:
         cost = torch.empty(R, Nmax, Fmax, dtype=torch.float32, device=dev)
         stride = (Nmax + 1) * (Fmax + 1)
         trace = torch.empty(R, stride, dtype=torch.int8, device=dev)
+        jumps = torch.zeros(R, Nmax, dtype=torch.int32, device=dev)
+        sizes = torch.tensor([[n_tok[r] - 1 - row_begin for r in range(R)], [int(f) for f in n_frames]],
+                             dtype=torch.int32).to(dev)                      # before _enter(): ordered on the caller's stream
         arr = lambda v: (C.c_int32 * len(v))(*[int(x) for x in v])
-        cur = self._enter()
-        check(lib().wh_task_align_batch(self.handle, arr(layers), arr(heads), P, arr(n_tok), arr(n_frames), width, row_begin,
-                                        float(qk_scale), cost.data_ptr(), trace.data_ptr(), stride, scratch.data_ptr(),
-                                        scratch.numel(), stream_ptr(self.stream)), "wh_task_align_batch")
-        cur.wait_stream(self.stream)
-        for t_ in (scratch, cost, trace):
+        with self._call():
+            check(lib().wh_task_align_batch(self.handle, arr(layers), arr(heads), P, arr(n_tok), arr(n_frames), width, row_begin,
+                                            float(qk_scale), cost.data_ptr(), trace.data_ptr(), stride, scratch.data_ptr(),
+                                            scratch.numel(), stream_ptr(self.stream)), "wh_task_align_batch")
+            check(lib().wh_dtw_backtrace_batch(trace.data_ptr(), stride, sizes[0].data_ptr(), sizes[1].data_ptr(), R, Nmax, Fmax,
+                                               jumps.data_ptr(), Nmax, None, 0, None, stream_ptr(self.stream)),
+                  "wh_dtw_backtrace_batch")
+        for t_ in (scratch, cost, trace, jumps, sizes):
             t_.record_stream(self.stream)
-        host = trace.cpu().numpy()
-        traces = []
-        for r in range(R):
-            n, m = n_tok[r] - 1 - row_begin, n_frames[r]
-            traces.append(host[r, : (n + 1) * (m + 1)].reshape(n + 1, m + 1))
-        return cost, traces
+        return cost, jumps
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -676,6 +716,29 @@ def dtw_trace(x: torch.Tensor) -> torch.Tensor:
     s = torch.cuda.current_stream(x.device)
     check(lib().wh_dtw_trace(xc.data_ptr(), N, M, trace.data_ptr(), stream_ptr(s)), "wh_dtw_trace")
     return trace
+
+
+def dtw_backtrace(trace: torch.Tensor, want_path: bool = True):
+    """trace int8 [N+1][M+1] on the GPU (dtw_trace) -> (jumps int32 [N], path int32 [2][len] | None) on the device:
+    the back-trace walk of whisper/timing.py:57-79 done by wh_dtw_backtrace_batch (a batch of one)."""
+    require_gpu(trace.device)
+    assert trace.dtype == torch.int8 and trace.dim() == 2 and trace.is_contiguous()
+    N, M = trace.shape[0] - 1, trace.shape[1] - 1
+    dev = trace.device
+    sizes = torch.tensor([N, M], dtype=torch.int32).to(dev)
+    jumps = torch.zeros(N, dtype=torch.int32, device=dev)
+    path = torch.zeros(2, N + M, dtype=torch.int32, device=dev) if want_path else None
+    plen = torch.zeros(1, dtype=torch.int32, device=dev) if want_path else None
+    s = torch.cuda.current_stream(dev)
+    check(lib().wh_dtw_backtrace_batch(trace.data_ptr(), trace.numel(), sizes[0:1].data_ptr(), sizes[1:2].data_ptr(), 1, N, M,
+                                       jumps.data_ptr(), N, _ptr(path), N + M, _ptr(plen), stream_ptr(s)),
+          "wh_dtw_backtrace_batch")
+    if not want_path:
+        return jumps, None
+    n = int(plen.item())
+    if n < 0:
+        raise ValueError("Unexpected trace[i, j]")          # reference timing.py:77
+    return jumps, path[:, N + M - n:]
 
 
 def align_matrix(qk: torch.Tensor, n_frames: int, width: int, row_begin: int, row_end: int,

@@ -6,7 +6,9 @@ Differences in *how*: the reference re-runs encoder + decoder with SDPA disabled
 cross-attention module to grab QK^T (timing.py:186-197); here one teacher-forced prefill keeps the per-layer
 queries (wh_task created with WH_TASK_CAPTURE_Q) and `wh_task_cross_qk` evaluates QK^T only for the alignment
 heads.  softmax / z-norm / median / head-mean are one C call (`wh_align_matrix`), DTW runs as an anti-diagonal
-wavefront kernel with dtw_cpu's tie rule (timing.py:95-100) and only the back-trace walk is host code.
+wavefront kernel with dtw_cpu's tie rule (timing.py:95-100) and the back-trace walk as one lane per clip on an
+LDS-packed copy of the trace (`wh_dtw_backtrace_batch`): per clip only the frame at which each token is first reached
+travels to the host.
 """
 from __future__ import annotations
 
@@ -54,9 +56,10 @@ def backtrace(trace: np.ndarray) -> np.ndarray:
 
 
 def dtw(x: torch.Tensor) -> np.ndarray:
-    """(2, path_len) array of (row, column) indices of the cheapest monotone path through cost matrix x"""
-    trace = hip.dtw_trace(x.to(torch.float32)).cpu().numpy()
-    return backtrace(trace)
+    """(2, path_len) array of (row, column) indices of the cheapest monotone path through cost matrix x
+    (reference timing.py:141-151).  Cost fill and the back-trace walk both run on the device; only the path comes back."""
+    _, path = hip.dtw_backtrace(hip.dtw_trace(x.to(torch.float32)))
+    return path.cpu().numpy().astype(np.int64)
 
 
 @dataclass
@@ -88,28 +91,41 @@ def find_alignment(model: "Whisper", tokenizer: Tokenizer, text_tokens: List[int
             task.set_audio(features.contiguous())
             text_positions = list(range(n_sot, n_sot + len(text_tokens)))
             logits = task.prefill(tokens[None].contiguous(), sel=text_positions)[0]       # (n_text, vocab)
-            probs = logits[:, : tokenizer.eot].softmax(dim=-1)
-            text_token_probs = probs[torch.arange(len(text_tokens)), torch.tensor(text_tokens)].tolist()
+            text_token_probs = _token_probs(logits[None], torch.tensor([list(text_tokens)], device=logits.device),
+                                            tokenizer.eot)[0].tolist()
             heads = model.alignment_heads.indices().T.tolist()
             qk = task.cross_qk(0, [h[0] for h in heads], [h[1] for h in heads], 0, int(tokens.numel()))
         finally:
             task.close()
         # softmax over frames -> z-norm over tokens -> median filter -> -mean over heads, rows [n_sot, -1)
         matrix = hip.align_matrix(qk, num_frames // 2, medfilt_width, n_sot, int(tokens.numel()) - 1, qk_scale)
-        text_indices, time_indices = dtw(matrix)
+        jumps, _ = hip.dtw_backtrace(hip.dtw_trace(matrix), want_path=False)
 
-    return _words_from_path(tokenizer, list(text_tokens), text_token_probs, text_indices, time_indices)
+    return _words_from_jumps(tokenizer, list(text_tokens), text_token_probs, jumps.cpu().numpy())
+
+
+def _token_probs(logits: torch.Tensor, tokens: torch.Tensor, eot: int) -> torch.Tensor:
+    """logits (rows, n, vocab) at the positions that predict `tokens` (rows, n): softmax over the text vocabulary
+    [0, eot) and the probability of each token (reference timing.py:218-221); padded token slots hold token 0's."""
+    return logits[:, :, :eot].softmax(dim=-1).gather(2, tokens[:, :, None])[:, :, 0]
 
 
 def _words_from_path(tokenizer: Tokenizer, text_tokens: List[int], text_token_probs: List[float],
                      text_indices: np.ndarray, time_indices: np.ndarray) -> List[WordTiming]:
     """token / frame path -> word boundaries (reference timing.py:218-242)"""
+    jumps = np.pad(np.diff(text_indices), (1, 0), constant_values=1).astype(bool)
+    return _words_from_jumps(tokenizer, text_tokens, text_token_probs, time_indices[jumps])
+
+
+def _words_from_jumps(tokenizer: Tokenizer, text_tokens: List[int], text_token_probs: List[float],
+                      jump_frames: np.ndarray) -> List[WordTiming]:
+    """`jump_frames[i]` = frame at which the alignment path first reaches text row i (= `time_indices[jumps]`,
+    reference timing.py:226-228; computed on the device by wh_dtw_backtrace_batch) -> word boundaries (timing.py:218-242)"""
     words, word_tokens = tokenizer.split_to_word_tokens(text_tokens + [tokenizer.eot])
     if len(word_tokens) <= 1:
         return []          # only EOT: nothing to align
     word_boundaries = np.pad(np.cumsum([len(t) for t in word_tokens[:-1]]), (1, 0))
-    jumps = np.pad(np.diff(text_indices), (1, 0), constant_values=1).astype(bool)
-    jump_times = time_indices[jumps] / TOKENS_PER_SECOND
+    jump_times = np.asarray(jump_frames) / TOKENS_PER_SECOND
     start_times = jump_times[word_boundaries[:-1]]
     end_times = jump_times[word_boundaries[1:]]
     word_probabilities = [np.mean(text_token_probs[i:j]) for i, j in zip(word_boundaries[:-1], word_boundaries[1:])]
@@ -122,13 +138,21 @@ ALIGN_BATCH_SCRATCH_BYTES = 6 << 30      # bound on the QK / softmax slabs of on
 
 def find_alignment_batch(model: "Whisper", tokenizer: Tokenizer, text_tokens: List[List[int]], mel: torch.Tensor,
                          num_frames: List[int], *, medfilt_width: int = 7, qk_scale: float = 1.0,
-                         audio_features: Optional[torch.Tensor] = None) -> List[List[WordTiming]]:
+                         audio_features: Optional[torch.Tensor] = None, stats: Optional[dict] = None) -> List[List[WordTiming]]:
     """`find_alignment` for every clip of a batch — mel (B, n_mels, 3000), one token list and frame count per clip —
     with identical results, clip by clip (BASELINE configs[4]: word timestamps over a batch).  One encoder pass (none
     when `audio_features` (B, 1500, D), the DecodingResult.audio_features of the same windows, is passed), ONE
     teacher-forced decoder pass over all clips (rows padded on the right; causal attention keeps the padding out of the
     real positions), one launch each for the alignment heads' QK, softmax, z-norm, median, head mean and DTW
-    (wh_task_align_batch, a workgroup per clip for the DTW wavefront); only the back-trace walk is host code."""
+    (wh_task_align_batch, a workgroup per clip for the DTW wavefront) and for the back-trace walk
+    (wh_dtw_backtrace_batch: a lane per clip on the LDS-packed trace); what reaches the host per clip is the frame at
+    which each token is first reached and the token probabilities.  Host code = splitting tokens into words.
+    `stats` (dict, optional): receives "device_s" (wall clock until those results are on the host, i.e. encoder +
+    teacher-forced pass + alignment kernels + the copy) and "host_s" (the word split after it) of this call."""
+    import time
+    t_start = time.perf_counter()
+    if stats is not None:
+        stats.clear()
     B = len(text_tokens)
     out: List[List[WordTiming]] = [[] for _ in range(B)]
     live = [i for i in range(B) if len(text_tokens[i]) > 0]
@@ -155,16 +179,25 @@ def find_alignment_batch(model: "Whisper", tokenizer: Tokenizer, text_tokens: Li
                 task.set_audio(features.contiguous())
                 n_text_max = Tmax - n_sot - 2
                 logits = task.prefill(tokens.contiguous(), sel=list(range(n_sot, n_sot + n_text_max)))   # (rows, n_text_max, V)
-                cost, traces = task.align_batch([h[0] for h in heads], [h[1] for h in heads], n_tok,
-                                                [int(num_frames[i]) // 2 for i in ids], medfilt_width, n_sot, qk_scale)
+                cost, jumps = task.align_batch([h[0] for h in heads], [h[1] for h in heads], n_tok,
+                                               [int(num_frames[i]) // 2 for i in ids], medfilt_width, n_sot, qk_scale)
             finally:
                 task.close()
+            # probabilities of all text tokens of all clips in one gather; ONE copy to the host (the paths' jump frames
+            # and the probabilities: a few KB per clip — the trace matrices stay on the device)
+            padded = torch.tensor([list(text_tokens[i]) + [0] * (n_text_max - len(text_tokens[i])) for i in ids],
+                                  device=model.device)
+            probs = _token_probs(logits, padded, tokenizer.eot)
+            jumps_h, probs_h = jumps.cpu().numpy(), probs.cpu().numpy()
+            if stats is not None:
+                stats["device_s"] = stats.get("device_s", 0.0) + time.perf_counter() - t_start
+                t_start = time.perf_counter()
             for k, i in enumerate(ids):
                 tt = list(text_tokens[i])
-                probs = logits[k, : len(tt), : tokenizer.eot].softmax(dim=-1)
-                text_token_probs = probs[torch.arange(len(tt)), torch.tensor(tt)].tolist()
-                text_indices, time_indices = backtrace(traces[k])
-                out[i] = _words_from_path(tokenizer, tt, text_token_probs, text_indices, time_indices)
+                out[i] = _words_from_jumps(tokenizer, tt, probs_h[k, : len(tt)].tolist(), jumps_h[k, : len(tt) + 1])
+            if stats is not None:
+                stats["host_s"] = stats.get("host_s", 0.0) + time.perf_counter() - t_start
+                t_start = time.perf_counter()
     return out
 
 

@@ -415,8 +415,9 @@ def _options_key(opts: dict):
 def _prompt_batches(model: "Whisper", options: DecodingOptions, prompts: List[Optional[List[int]]], members: List[int],
                     batch_size: int) -> List[List[int]]:
     """split `members` (windows with the same options and the prompts `prompts[i]`) into batches one DecodingTask
-    can take: rows whose initial sequences have different lengths may share a call only in the fused greedy mode
-    and below its length limit (DecodingTask.ragged_limit); any rows of EQUAL length may always share one"""
+    can take: rows whose initial sequences have different lengths may share a call in the device-side modes (greedy,
+    sampling, beam search with the stock decoder / filters) below the length limit (DecodingTask.ragged_limit: no row
+    may reach the context limit before the step budget ends); any rows of EQUAL length may always share one"""
     probe = DecodingTask(model, options)
     limit = probe.ragged_limit()
     classes = {}
@@ -451,7 +452,9 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, max_acti
     the driver advances them in lock-step and decodes the windows that are pending at the same moment — and whose
     decoding options other than the prompt are identical — as batches of up to `batch_size` rows, each row
     conditioned on its own file's previous text (`DecodingTask(..., prompts=...)`: rows of different prompt lengths
-    share a greedy call; beam search batches rows of equal prompt length).  Results are the same dicts `transcribe`
+    share a call in every device-side mode — greedy, sampling and beam search with the stock decoder and filters; the
+    beams of a segment share its prompt.  With ragged rows the beam loop copies whole cache rows when beams are
+    reordered instead of only the part after the shared history).  Results are the same dicts `transcribe`
     returns, in input order.  Windows of one file stay sequential (seek and prompt depend on the previous window).
     Windows whose result trips the temperature-fallback criteria climb the temperature ladder together: the next
     rung decodes them as a batch again (sampling runs on the device, `best_of` rows per window).  With
@@ -468,8 +471,12 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, max_acti
                     clip_timestamps="0", hallucination_silence_threshold=None)
     fixed = {k: kwargs.pop(k, defaults[k]) for k in names}
     audios = list(audios)
+    if batch_size < 1:
+        raise ValueError(f"batch_size must be at least 1 (got {batch_size})")
     if max_active_files is None:
         max_active_files = 2 * batch_size
+    if max_active_files < 1:
+        raise ValueError(f"max_active_files must be at least 1 (got {max_active_files})")
     workers = [_Transcriber(model, *[fixed[k] for k in names], dict(kwargs)) for _ in audios]
     detect = kwargs.get("language") is None and model.is_multilingual and len(audios) > 1
     walks: List[Optional[object]] = [None] * len(audios)
