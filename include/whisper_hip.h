@@ -139,7 +139,11 @@ int wh_encode(const wh_model *m, const void *mel, int mel_is_f16, int batch, voi
 
 /* ---- decoding task: PyTorchInference + kv_cache — whisper/decoding.py:144-176, model.py:310-341 */
 /* flags for wh_task_create */
-enum { WH_TASK_CAPTURE_Q = 1 };   /* keep cross-attention queries of every layer (word timestamps) */
+enum {
+  WH_TASK_CAPTURE_Q = 1,      /* keep cross-attention queries of every layer (word timestamps) */
+  WH_TASK_TWO_LAUNCH_ATTN = 2 /* decode step: projection and attention as separate launches even where the fused kernels of
+                               * csrc/xattn.hip apply (A/B and tests: the results must agree) */
+};
 /* The workspace holds the cross-attention K/V of n_audio segments, the self-attention cache of n_audio * n_group rows
  * and the step buffers.  WH_F16 tasks with n_group > 1 (beam search) additionally hold a transposed copy of the
  * cross-attention V per layer (the matrix-core form of the beam-group attention reads it): + n_text_layer * n_audio *
@@ -180,6 +184,12 @@ int wh_task_reset(wh_task *t, void *stream);   /* stream-ordered (no host synchr
 int wh_task_set_lag(wh_task *t, const int32_t *lag, void *stream);
 /* number of cached self-attention positions of the longest row (the `offset` of model.py:234) */
 int wh_task_position(const wh_task *t);
+/* Introspection for tests and the benchmark.  what = 0: 1 when this task's decode step runs the cross attention with its
+ * LayerNorm + query projection inside the same launch (csrc/xattn.hip: fp16, <= 8 rows, one row per audio), else 0.
+ * what = 2: the same question for self attention + QKV projection + cache append (sattn8_kernel).
+ * what = 1: number of bounded hand-off spins that ran out in that kernel since the task was created (always 0 on a
+ * healthy device; reads device memory, i.e. synchronises `stream`).  Negative on error. */
+int wh_task_info(wh_task *t, int what, void *stream);
 
 /*
  * Fused sampling loop == DecodingTask._main_loop with GreedyDecoder (arg-max at temperature 0, otherwise one

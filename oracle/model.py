@@ -18,8 +18,12 @@ class OracleModel:
     """Functional Whisper on CPU tensors.  `dtype` is the activation dtype (float32 = the reference's CPU
     path, whisper/transcribe.py:128-136)."""
 
-    def __init__(self, dims, sd: Dict[str, torch.Tensor], dtype=torch.float32):
-        self.dims, self.dtype = dims, dtype
+    def __init__(self, dims, sd: Dict[str, torch.Tensor], dtype=torch.float32, sdpa: bool = False):
+        """sdpa: compute attention with torch's scaled_dot_product_attention wherever the scores themselves are not
+        asked for — what the reference does by default (model.py:124-128, `SDPA_AVAILABLE and use_sdpa`).  The tests
+        keep the explicit form (model.py:130-139, the definition); bench.py's CPU baseline times the fused form,
+        because that is what a user of the reference's CPU path runs."""
+        self.dims, self.dtype, self.sdpa = dims, dtype, sdpa
         self.sd = {k: v.detach().cpu().float() for k, v in sd.items()}
 
     # -- primitives -----------------------------------------------------------------------------
@@ -30,14 +34,18 @@ class OracleModel:
         b = self.sd.get(p + ".bias")
         return F.linear(x, self.sd[p + ".weight"].to(x.dtype), None if b is None else b.to(x.dtype))
 
-    def _attend(self, q, k, v, n_head, causal_offset: Optional[int]):
+    def _attend(self, q, k, v, n_head, causal_offset: Optional[int], need_qk: bool = True):
         """model.py:114-139 manual path: scale d_head**-0.25 on q and k, fp32 softmax.  causal_offset = number of
-        cached positions preceding the queries, or None for no mask.  Returns (out, qk)."""
+        cached positions preceding the queries, or None for no mask.  Returns (out, qk); with `sdpa` and no need for
+        the scores, the fused form of model.py:124-128 (qk = None)."""
         B, Tq, Dm = q.shape
         scale = (Dm // n_head) ** -0.25
         qh = q.view(B, Tq, n_head, -1).permute(0, 2, 1, 3)
         kh = k.view(k.shape[0], k.shape[1], n_head, -1).permute(0, 2, 1, 3)
         vh = v.view(v.shape[0], v.shape[1], n_head, -1).permute(0, 2, 1, 3)
+        if self.sdpa and not need_qk and (causal_offset is None or Tq == 1 or causal_offset == 0):
+            a = F.scaled_dot_product_attention(qh, kh, vh, is_causal=causal_offset is not None and Tq > 1)
+            return a.permute(0, 2, 1, 3).flatten(start_dim=2), None
         qk = (qh * scale) @ (kh * scale).transpose(-1, -2)
         if causal_offset is not None and Tq > 1:      # model.py:125: the T=1 step attends to everything cached
             Tk = k.shape[1]
@@ -60,7 +68,7 @@ class OracleModel:
             p = f"encoder.blocks.{i}"
             h = self._ln(x, p + ".attn_ln")
             a, _ = self._attend(self._lin(h, p + ".attn.query"), self._lin(h, p + ".attn.key"),
-                                self._lin(h, p + ".attn.value"), d.n_audio_head, None)
+                                self._lin(h, p + ".attn.value"), d.n_audio_head, None, need_qk=False)
             x = x + self._lin(a, p + ".attn.out")
             h = self._ln(x, p + ".mlp_ln")
             x = x + self._lin(F.gelu(self._lin(h, p + ".mlp.0")), p + ".mlp.2")
@@ -91,7 +99,7 @@ class OracleModel:
                     k = torch.cat([cache["self_k"][i], k], dim=1)      # model.py:332
                     v = torch.cat([cache["self_v"][i], v], dim=1)
                 cache["self_k"][i], cache["self_v"][i] = k, v
-            a, _ = self._attend(self._lin(h, p + ".attn.query"), k, v, d.n_text_head, offset)
+            a, _ = self._attend(self._lin(h, p + ".attn.query"), k, v, d.n_text_head, offset, need_qk=False)
             x = x + self._lin(a, p + ".attn.out")
             h = self._ln(x, p + ".cross_attn_ln")
             if cache is not None and cache["cross_k"][i] is not None:   # model.py:106-109
@@ -107,11 +115,12 @@ class OracleModel:
                 # of large-v3): the rows of one audio become extra query positions of that audio — cross attention has
                 # no mask, every (query, key) product and every softmax row is unchanged.
                 Bq = xa.shape[0]
-                a, qk = self._attend(cq.reshape(Bq, group * T, -1), ck, cv, d.n_text_head, None)
+                a, qk = self._attend(cq.reshape(Bq, group * T, -1), ck, cv, d.n_text_head, None, need_qk=keep_qk)
                 a = a.reshape(R, T, -1)
-                qk = qk.view(Bq, d.n_text_head, group, T, -1).permute(0, 2, 1, 3, 4).reshape(R, d.n_text_head, T, -1)
+                if qk is not None:
+                    qk = qk.view(Bq, d.n_text_head, group, T, -1).permute(0, 2, 1, 3, 4).reshape(R, d.n_text_head, T, -1)
             else:
-                a, qk = self._attend(cq, ck, cv, d.n_text_head, None)
+                a, qk = self._attend(cq, ck, cv, d.n_text_head, None, need_qk=keep_qk)
             if keep_qk:
                 qks.append(qk)
             x = x + self._lin(a, p + ".cross_attn.out")

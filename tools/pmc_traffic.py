@@ -9,7 +9,8 @@ import sys
 
 # bench name -> regex on "mangled name grid=(...)" rows (large-v3, 8 clips, fp16)
 PATTERNS = {
-    "attn_decode_cross": r"attn_decode_kernelIDF16_Li16ELi4ELb0E.*grid=\(768,20,8\)",
+    # round 3: LN + query projection + cross attention in one launch (xattn.hip); the two-launch form otherwise
+    "attn_decode_cross": r"(xattn8_kernel<16>|xattn8_kernelILi16E|attn_decode_kernelIDF16_Li16ELi4ELb0E.*grid=\(768,20,8\))",
     "attn_decode_self": r"attn_decode_kernelIDF16_Li8ELi8ELb1E.*grid=\(512,20,8\)",
     # gemv8_kernel<PRO, GS, KS, NU, CSm, XW, NRT> (round 2): LN = 1, PLAIN = 0, COMBINE = 2
     "gemv_qkv": r"gemv8_kernel<1, 2, 4, 5, 1, 8, 1>",

@@ -297,6 +297,10 @@ struct wh_task {
   int* beam_lcp;           // [B][8][8] shared-history lengths of the rows of a segment + [R] first position to copy
   void* qcap;              // [L][R*Tcap][D] captured cross-attention queries
   int cross_splits, self_splits;
+  // fused query projection + cross attention (xattn.hip; fp16, <= 8 rows): q granules, the step tick, the error word
+  unsigned long long* xq_gran; int* d_tick; int* d_err;
+  unsigned long long* sq_gran;   // the same for self attention + QKV projection (q, new k, new v)
+  bool fused_xattn, fused_sattn;
   size_t total;
 };
 
@@ -366,6 +370,10 @@ static void task_carve(wh_task* t, void* base) {
   t->beam_flags = t->G > 1 ? (int*)c.take((2 * (size_t)t->B + 1) * 4) : nullptr;
   t->beam_lcp = t->G > 1 ? (int*)c.take(((size_t)t->B * 64 + R) * 4) : nullptr;
   t->qcap = (t->flags & WH_TASK_CAPTURE_Q) ? c.take(L * R * C * D * es) : nullptr;
+  t->xq_gran = (unsigned long long*)c.take(R * (D / 2) * 8);
+  t->sq_gran = (unsigned long long*)c.take(R * (3 * D / 2) * 8);
+  t->d_tick = (int*)c.take(256);
+  t->d_err = t->d_tick + 16;
   t->total = align_up(c.off, 256);
 }
 
@@ -393,6 +401,10 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
     const int cap = attn_decode_capacity(m->dtype);
     t->self_splits = (m->d.n_text_ctx + cap - 1) / cap;
   }
+  t->fused_xattn = !(flags & WH_TASK_TWO_LAUNCH_ATTN) && m->dtype == WH_F16 && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) &&
+                   xattn_supported(m->d.n_text_state, m->d.n_text_head, t->R, t->G, m->d.n_audio_ctx, t->cross_splits);
+  t->fused_sattn = !(flags & WH_TASK_TWO_LAUNCH_ATTN) && m->dtype == WH_F16 && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) && t->self_splits == 1 &&
+                   sattn_supported(m->d.n_text_state, m->d.n_text_head, t->R, m->d.n_text_ctx);
   t->h_lag = (int*)calloc((size_t)t->R, sizeof(int));
   if (!t->h_lag) { delete t; return WH_ERR_ARG; }
   // no device work here: the position counter and the lag array are zeroed by the first wh_task_reset, which the
@@ -417,6 +429,20 @@ extern "C" void wh_task_destroy(wh_task* t) {
 
 extern "C" int wh_task_position(const wh_task* t) { return t ? t->pos : -1; }
 
+extern "C" int wh_task_info(wh_task* t, int what, void* stream) {
+  if (!t) return -1;
+  if (what == 0) return t->fused_xattn ? 1 : 0;
+  if (what == 2) return t->fused_sattn ? 1 : 0;
+  if (what == 1) {                       // hand-off timeouts of the fused cross attention since the task was created
+    if (t->needs_reset) return 0;
+    int v = 0;
+    if (hipMemcpyAsync(&v, t->d_err, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+    return v;
+  }
+  return -1;
+}
+
 static int task_reset_impl(wh_task* t, void* stream_);
 extern "C" int wh_task_reset(wh_task* t, void* stream_) {
   TASK_ENTER(t);
@@ -427,6 +453,13 @@ static int task_reset_impl(wh_task* t, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   HIPCHK(hipMemsetAsync(t->d_pos, 0, 4, s));     // stream-ordered: no host or device-wide synchronisation
   t->pos = 0;
+  if (t->needs_reset) {
+    // the workspace arrives uninitialised: no granule may carry a tag that looks valid, and the tick starts at 0 (it
+    // only ever counts up afterwards, so tags never repeat while the task lives)
+    HIPCHK(hipMemsetAsync(t->xq_gran, 0, (size_t)t->R * (t->m->d.n_text_state / 2) * 8, s));
+    HIPCHK(hipMemsetAsync(t->sq_gran, 0, (size_t)t->R * (3 * t->m->d.n_text_state / 2) * 8, s));
+    HIPCHK(hipMemsetAsync(t->d_tick, 0, 256, s));
+  }
   if (t->lag_on || t->needs_reset) {
     HIPCHK(hipMemsetAsync(t->d_lag, 0, (size_t)t->R * 4, s));
     memset(t->h_lag, 0, (size_t)t->R * sizeof(int));
@@ -659,6 +692,40 @@ extern "C" int wh_task_prefill(wh_task* t, const int64_t* tokens, int64_t token_
   return prefill_impl(t, tokens, token_stride, T0, sel_pos, n_sel, logits_out, t->m->d.n_vocab, (hipStream_t)stream);
 }
 
+static inline void* cross_layer(const wh_task* t, int l);
+// arguments of the fused LN -> cross query -> cross attention launch of layer l (xattn.hip)
+static XAttnArgs xattn_args(const wh_task* t, int l, int epoch) {
+  const wh_model* m = t->m;
+  const wh_dims& d = m->d;
+  const int D = d.n_text_state, Ta = d.n_audio_ctx;
+  const wh_layer_weights& L = m->dec[l];
+  XAttnArgs a; memset(&a, 0, sizeof(a));
+  a.xf = t->x; a.xf_ld = D; a.W = L.cq_w; a.bias = L.cq_b; a.D = D; a.H = d.n_text_head; a.R = t->R;
+  a.k = cross_layer(t, l); a.k_ld = 2 * D; a.k_bs = (int64_t)Ta * 2 * D;
+  a.v = (char*)cross_layer(t, l) + (size_t)D * m->esize; a.v_ld = 2 * D; a.v_bs = a.k_bs;
+  a.Tk = Ta; a.splits = t->cross_splits;
+  a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
+  a.qg = t->xq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err;
+  return a;
+}
+
+static inline void* self_k_layer(const wh_task* t, int l);
+static inline void* self_v_layer(const wh_task* t, int l);
+// arguments of the fused LN -> QKV -> cache append -> self attention launch of layer l (xattn.hip)
+static SAttnArgs sattn_args(const wh_task* t, int l, int epoch) {
+  const wh_model* m = t->m;
+  const wh_dims& d = m->d;
+  const int D = d.n_text_state;
+  const wh_layer_weights& L = m->dec[l];
+  SAttnArgs a; memset(&a, 0, sizeof(a));
+  a.xf = t->x; a.xf_ld = D; a.W = L.qkv_w; a.bias = L.qkv_b; a.D = D; a.H = d.n_text_head; a.R = t->R;
+  a.kcache = self_k_layer(t, l); a.vcache = self_v_layer(t, l); a.cache_bs = (int64_t)d.n_text_ctx * D;
+  a.d_pos = t->d_pos; a.lag = t->d_lag; a.q_out = t->qbuf;
+  a.out = t->att; a.o_ld = D;
+  a.qg = t->sq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err;
+  return a;
+}
+
 // ---- one decode step (all kernels read the position from *d_pos: graph-replayable) ---------------
 static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
   const wh_model* m = t->m;
@@ -671,6 +738,10 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
   for (int l = 0; l < d.n_text_layer; ++l) {
     const wh_layer_weights& L = m->dec[l];
     GemvArgs g;
+    if (t->fused_sattn) {
+      // LN -> QKV -> cache append -> self attention as ONE launch (xattn.hip, sattn8_kernel)
+      HIPCHK(launch_sattn8(sattn_args(t, l, 0), s));
+    } else {
     // LN -> QKV, K/V appended in place at *d_pos
     memset(&g, 0, sizeof(g));
     g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.attn_ln_w; g.ln_b = L.attn_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
@@ -689,6 +760,7 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
       a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
       HIPCHK(launch_attn_decode(a, m->dtype, s));
     }
+    }
     memset(&g, 0, sizeof(g));
     if (t->self_splits > 1) {
       g.pro = PRO_COMBINE; g.part_o = t->part_o; g.part_ml = t->part_ml; g.splits = t->self_splits; g.H = H;
@@ -698,6 +770,11 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
     g.W = L.out_w; g.bias = L.out_b; g.N = D; g.K = D; g.R = R;
     g.epi = EPI_RESID; g.resid = t->x; g.resid_ld = D;
     HIPCHK(launch_gemv(g, m->dtype, s));
+    if (t->fused_xattn) {
+      // LN -> cross query -> cross attention as ONE launch: the K/V stream starts at kernel entry, the projection runs
+      // under it and reaches the K/V waves through tagged granules (xattn.hip)
+      HIPCHK(launch_xattn8(xattn_args(t, l, 0), s));
+    } else {
     // LN -> cross query
     memset(&g, 0, sizeof(g));
     g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.cross_ln_w; g.ln_b = L.cross_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
@@ -715,6 +792,7 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
         a.vt = (char*)t->cross_vt + (size_t)l * t->B * D * t->vt_ld * es; a.vt_ld = t->vt_ld; a.vt_bs = (int64_t)D * t->vt_ld;
       }
       HIPCHK(launch_attn_decode(a, m->dtype, s));
+    }
     }
     memset(&g, 0, sizeof(g));
     // 17+ rows (beam search): the projection runs as 16-row workgroups that would each merge their rows' partials
@@ -749,6 +827,7 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
     g.W = m->w.tok_emb; g.bias = nullptr; g.N = V; g.K = D; g.R = R;
     g.epi = EPI_F32; g.y = t->logits; g.y_ld = V;
     g.bump = t->d_pos; g.bump_by = 1;         // the last kernel of the step advances the position counter
+    g.bump2 = t->d_tick;                      // ... and the step tick the granule tags of xattn.hip are made of
     HIPCHK(launch_gemv(g, m->dtype, s));
   }
   return WH_OK;
@@ -1046,7 +1125,13 @@ static int bench_issue(wh_task* t, int kind, int iters, double* bytes_per_launch
         bytes = es * ((double)Ln * 14.0 * D * D + (double)V * D) + (double)t->B * Ln * 2.0 * Ta * D * es +
                 (double)R * (t->pos + 1) * Ln * 2.0 * D * es + (double)R * V * 4.0;
       } break;
-      case 1: {
+      case 1: if (t->fused_xattn) {
+        // the fused launch: the tag of launch i is unique within the graph (epoch = i); one add behind the chain keeps
+        // replays apart
+        HIPCHK(launch_xattn8(xattn_args(t, l, i), s));
+        if (i == iters - 1) HIPCHK(launch_add_int(t->d_tick, iters, s));
+        bytes = (double)t->B * 2.0 * Ta * D * es + (double)D * D * es;
+      } else {
         DecAttnArgs a; memset(&a, 0, sizeof(a));
         a.q = t->qbuf; a.q_ld = D;
         a.k = cross_layer(t, l); a.k_ld = 2 * D; a.k_bs = (int64_t)Ta * 2 * D;
@@ -1056,7 +1141,11 @@ static int bench_issue(wh_task* t, int kind, int iters, double* bytes_per_launch
         HIPCHK(launch_attn_decode(a, m->dtype, s));
         bytes = (double)t->B * 2.0 * Ta * D * es;
       } break;
-      case 2: {
+      case 2: if (t->fused_sattn) {
+        HIPCHK(launch_sattn8(sattn_args(t, l, i), s));
+        if (i == iters - 1) HIPCHK(launch_add_int(t->d_tick, iters, s));
+        bytes = (double)R * t->pos * 2.0 * D * es + 3.0 * D * D * es;
+      } else {
         DecAttnArgs a; memset(&a, 0, sizeof(a));
         a.q = t->qbuf; a.q_ld = D;
         a.k = self_k_layer(t, l); a.k_ld = D; a.k_bs = (int64_t)C * D;

@@ -438,6 +438,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(whk::GemvArgs a, int g
 
   WH_PROBE_AT(a, wgid, 6);
   if (a.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.bump, a.bump_by);
+  if (a.bump2 && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.bump2, 1);
 }
 
 template <typename T, int RT, int LPR, int PRO, int J, bool MULTI, int WAVES, int GS, bool MF = false>
@@ -719,6 +720,7 @@ __global__ __launch_bounds__(512) void gemv_stream_kernel(whk::GemvArgs a, int g
     }
   }
   if (a.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.bump, a.bump_by);
+  if (a.bump2 && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.bump2, 1);
 }
 
 template <typename T, int RT>
@@ -1058,6 +1060,7 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
   }
   WH_PROBE_AT(a, wgid, 6);
   if (a.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.bump, a.bump_by);
+  if (a.bump2 && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.bump2, 1);
 }
 
 template <int PRO, int GS, int KS, int CSm, int XW, int NRT>
@@ -1288,6 +1291,7 @@ __global__ __launch_bounds__(1024) void gemv_rows48_kernel(whk::GemvArgs a) {
     }
   }
   if (a.bump && blockIdx.x == 0 && tid == 0) atomicAdd(a.bump, a.bump_by);
+  if (a.bump2 && blockIdx.x == 0 && tid == 0) atomicAdd(a.bump2, 1);
 }
 
 // applies to: fp16, LayerNorm prologue with folded affine part, 17..48 rows, K a multiple of 256 up to 1280,
@@ -1426,6 +1430,7 @@ __global__ __launch_bounds__(1024) void gemv_rows48_stream_kernel(whk::GemvArgs 
     }
   }
   if (a.bump && blockIdx.x == 0 && tid == 0) atomicAdd(a.bump, a.bump_by);
+  if (a.bump2 && blockIdx.x == 0 && tid == 0) atomicAdd(a.bump2, 1);
 }
 
 // fp16, LayerNorm prologue, fp32 output without bias, 17..48 rows, K a multiple of 256 up to 1280, a long N

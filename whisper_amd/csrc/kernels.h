@@ -115,6 +115,41 @@ hipError_t launch_cross_qk_batch(const void* qcap, int64_t q_layer_stride, int64
 hipError_t launch_cross_qk(const void* q, int64_t q_ld, const void* k, int64_t k_ld, int head, int n_tok,
                            int Tk, float* out, int dtype, hipStream_t stream);
 
+// ---- xattn.hip: cross attention of one decode step with its LayerNorm + query projection inside the launch ----------
+struct XAttnArgs {
+  // projection: q = (W . LN(x) + bias) * d_head^-0.5, LayerNorm affine folded into W / bias (WH_WEIGHTS_DEC_LN_FOLDED)
+  const float* xf; int64_t xf_ld;                 // fp32 residual rows [R][D]
+  const void* W; const float* bias;               // fp16 [D][D], fp32 [D]
+  int D, H, R;
+  // cross K/V of row r (one audio per row): key j of head h at k + r*k_bs + j*k_ld + h*64
+  const void* k; int64_t k_ld; int64_t k_bs;
+  const void* v; int64_t v_ld; int64_t v_bs;
+  int Tk, splits;
+  void* out; int64_t o_ld;                        // splits == 1
+  void* part_o; float* part_ml;                   // splits > 1 (layouts of DecAttnArgs)
+  // hand-off of q between workgroups: 8-byte granules {2 x fp16, tag} [R][D/2]; tag = ((*d_tick + 1 + epoch) << 6) | (layer + 1)
+  unsigned long long* qg; const int* d_tick; int epoch, layer;
+  int* err;                                       // set to 1 when a bounded spin ran out (never on a healthy device)
+  WH_PROBE_FIELD
+};
+bool xattn_supported(int D, int H, int R, int kv_group, int Tk, int splits);
+hipError_t launch_xattn8(const XAttnArgs& a, hipStream_t stream);
+// self attention of one decode step with LayerNorm + QKV projection + KV-cache append inside the launch
+struct SAttnArgs {
+  const float* xf; int64_t xf_ld;                 // fp32 residual rows [R][D]
+  const void* W; const float* bias;               // fp16 [3D][D] = [query; key; value], fp32 [3D] (LayerNorm folded in)
+  int D, H, R;
+  void* kcache; void* vcache; int64_t cache_bs;   // this layer's self K / V [R][n_ctx][D]; row r appends at *d_pos - lag[r]
+  const int* d_pos; const int* lag;               // lag may be null
+  void* q_out;                                    // optional: the unscaled q rows [R][D] (what the two-launch form leaves)
+  void* out; int64_t o_ld;                        // attention output [R][D]
+  unsigned long long* qg; const int* d_tick; int epoch, layer;   // granules [R][3D/2]; tag as in XAttnArgs
+  int* err;
+  WH_PROBE_FIELD
+};
+bool sattn_supported(int D, int H, int R, int n_ctx);
+hipError_t launch_sattn8(const SAttnArgs& a, hipStream_t stream);
+
 // ---- gemv.hip ------------------------------------------------------------------------------
 enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_COMBINE = 2 };
 enum { EPI_STORE = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3, EPI_F32 = 4 };
@@ -135,6 +170,7 @@ struct GemvArgs {
   void* kcache; void* vcache; int64_t cache_bs; const int* d_pos; int D;  // EPI_QKV: row r appends at *d_pos - lag[r]
   const int* lag;                                 // EPI_QKV: per-row position lag (ragged prompts); may be null
   int* bump; int bump_by;                         // optional: *bump += bump_by once per launch (position counter)
+  int* bump2;                                     // optional: *bump2 += 1 once per launch (the step tick of xattn.hip)
   int variant;                                    // 0 = shape heuristic; > 0 forces a kernel shape (tools/probe_decode)
   WH_PROBE_FIELD
 };

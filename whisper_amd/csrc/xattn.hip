@@ -1,0 +1,523 @@
+// xattn.hip — decoder cross attention of one decode step with its query projection INSIDE the launch (fp16, <= 8 rows).
+//
+// Reference ops: `cross_attn_ln` + `cross_attn.query` (whisper/model.py:39-50, 160-161) and `qkv_attention` over the
+// cached cross K/V at T = 1 (model.py:106-139).  The decode step used to run them as two dependent launches:
+// LN -> query projection (D x D weights, 3.7 us in the chain) and then the K/V stream (61 MB at 8 rows of large-v3,
+// 11.8 us).  The K/V stream does not depend on the query — only the arithmetic after it does — so here every workgroup
+// requests its whole K/V slice at entry (exactly as attn_decode_kernel does) and the projection runs UNDER that stream:
+//
+//   * grid (split, head, row) as before, 12 waves per workgroup: waves 0-7 hold the K/V tile ("KV waves"), waves 8-11
+//     are auxiliary;
+//   * the first D / 8 workgroups (dispatched first) are also PRODUCERS: their auxiliary waves compute one 8-feature
+//     group of q for all rows with the MFMA diagonal tile of gemv8_kernel (weights requested first, LayerNorm of two
+//     rows per wave in registers -> fp16 fragments in LDS -> 5 MFMAs -> cross-wave sum -> bias), scale by
+//     d_head^-0.5 (0.125, exact in fp16: model.py:118-121 applies d_head^-0.25 to q and k) and publish the 64 values
+//     as 32 GRANULES: 8-byte {2 x fp16, tag} words written by one write-through (sc1) store each;
+//   * every workgroup's first auxiliary wave polls the 32 granules of its (row, head) — relaxed agent-scope 8-byte loads,
+//     s_sleep between sweeps, bounded — and hands q to the KV waves through LDS and the workgroup barrier.  A granule is
+//     valid when its tag equals this launch's tag, so no flag, fence or counter reset is needed
+//     (MI355X_MICROARCH.md "handoff-1to1": 1-3 us on a streaming consumer CU, paid here under ~10 us of K/V stream).
+//     tag = ((tick + 1 + epoch) << 6) | (layer + 1): `tick` is a device counter bumped once per decode step by the
+//     step's last kernel and never reset, so tags never repeat during the life of a task.
+//
+// Producers never wait for anything, and they are the lowest-numbered workgroups, so consumers cannot starve them of
+// CU slots; every spin is bounded (a timeout sets *err and lets the workgroup finish with whatever q it has).
+// The arithmetic is that of gemv8_kernel<PRO_LN> + attn_decode_kernel<half>; q is bit-identical to the two-launch form,
+// the attention sums the same products with 8 instead of 4 waves' partial sums meeting in LDS (fp32: differences at the
+// 1e-7 level before the fp16 rounding of the output).  WH_NO_FUSED_XATTN=1 selects the two-launch form for A/B.
+#include "common.h"
+#include "kernels.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef unsigned long long u64;
+constexpr float XSCALE = 0.125f;      // d_head^-0.5 for d_head = 64
+constexpr int X_MAX_SPINS = 8192;
+
+__device__ __forceinline__ float qk_unit8(half8v q, half8v k) {
+  float d = __builtin_amdgcn_fdot2(half2v{q[0], q[1]}, half2v{k[0], k[1]}, 0.f, false);
+  d = __builtin_amdgcn_fdot2(half2v{q[2], q[3]}, half2v{k[2], k[3]}, d, false);
+  d = __builtin_amdgcn_fdot2(half2v{q[4], q[5]}, half2v{k[4], k[5]}, d, false);
+  d = __builtin_amdgcn_fdot2(half2v{q[6], q[7]}, half2v{k[6], k[7]}, d, false);
+  return d;
+}
+
+// ---- the projection of ONE 8-feature group by 4 auxiliary waves (the MFMA diagonal tile of gemv8_kernel<PRO_LN>) -------
+constexpr int P_NU = 5, P_KS = 4;       // K <= 1280: 20 blocks of 64 = 4 waves x 5 wave-loads
+
+// stage 1 (before the first barrier): request the wave's 5 wave-loads of weights (8 rows x 128 contiguous bytes each,
+// non-temporal; lane l = 16 c + 8 half + i), then LayerNorm rows aw and aw + 4 whole in registers (row-contiguous
+// loads; the affine part is folded into W / bias) and scatter them to LDS in MFMA fragment order
+__device__ __forceinline__ void proj_stage1(int aw, int lane, int g, const void* W, int K, const float* xf, int64_t xf_ld,
+                                            int R, half8v (&wa)[P_NU], half8v* xfrag) {
+  const int nblk = K >> 6;
+  const int idx = lane & 7, koff = ((lane >> 3) & 1) * 32 + (lane >> 4) * 8;
+  const uint32_t lane_off = ((uint32_t)(g * 8 + idx) * (uint32_t)K + (uint32_t)koff) * 2u;
+#pragma unroll
+  for (int u = 0; u < P_NU; ++u) {
+    int blk = aw + P_KS * u; if (blk > nblk - 1) blk = nblk - 1;          // clamped; masked through x == 0
+    wa[u] = __builtin_nontemporal_load((const half8v*)((const char*)W + (size_t)blk * 128 + lane_off));
+  }
+  const float invK = 1.0f / (float)K;
+  const uint32_t fbase = (uint32_t)((lane >> 4) * P_NU * 64 + 16 * ((lane >> 1) & 3) + 8 * ((lane >> 3) & 1)) * 16u + (uint32_t)(lane & 1) * 8u;
+  float4v v[2][P_NU];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = aw + 4 * i;
+    const char* src = (const char*)xf + (size_t)(row < R ? row : R - 1) * (size_t)xf_ld * 4;
+#pragma unroll
+    for (int j = 0; j < P_NU; ++j) {
+      int k = (j * 64 + lane) * 4; if (k > K - 4) k = K - 4;
+      v[i][j] = *(const float4v*)(src + (uint32_t)k * 4u);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = aw + 4 * i;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < P_NU; ++j) {
+      const float t = (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
+      sum += ((j * 64 + lane) * 4 < K) ? t : 0.f;
+    }
+    const float mean = wave_sum(sum) * invK;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < P_NU; ++j) {
+      if ((j * 64 + lane) * 4 < K) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][j][e] - mean; ss = __builtin_fmaf(d, d, ss); }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) * invK + 1e-5f);
+    const uint32_t rbase = fbase + (uint32_t)(row * 16);
+#pragma unroll
+    for (int j = 0; j < P_NU; ++j) {
+      const bool on = (j * 64 + lane) * 4 < K;
+      half4v o4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o4[e] = on ? (half_t)((v[i][j][e] - mean) * rstd) : (half_t)0.f;
+      *(half4v*)((char*)xfrag + rbase + (uint32_t)(j * 1024)) = o4;
+    }
+  }
+}
+
+// stage 2 (between the two barriers): 5 MFMAs against the x fragments, the two meaningful diagonal blocks summed, the
+// wave's 8 x 8 partial sums to pred[aw][feature][row]
+__device__ __forceinline__ void proj_stage2(int aw, int lane, const half8v (&wa)[P_NU], const half8v* xfrag, float (*pred)[8][8]) {
+  const bool diag = (lane >> 5) == ((lane >> 3) & 1);
+  float4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < P_NU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u], xfrag[(aw * P_NU + u) * 64 + lane], acc, 0, 0, 0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float z = diag ? acc[e] : 0.f;
+    z += lane_xor8(z);
+    float p, q; lane_swap32(z, p, q);
+    acc[e] = p + q;
+  }
+  if (lane < 32 && (lane & 15) < 8) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pred[aw][4 * (lane >> 4) + e][lane & 7] = acc[e];
+  }
+}
+
+// one wave fetches 32 granules (64 fp16) into LDS: relaxed agent-scope 8-byte loads until every tag matches; bounded
+__device__ __forceinline__ void fetch_granules(const u64* gp, uint32_t tag, int lane, uint32_t* dst, int* err) {
+  uint32_t data = 0;
+  int spins = 0;
+  for (;;) {
+    const u64 g = __hip_atomic_load(gp + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    data = (uint32_t)g;
+    const bool ok = (uint32_t)(g >> 32) == tag;
+    if (__all(ok)) break;
+    if (++spins >= X_MAX_SPINS) { if (lane == 0 && err) atomicAdd(err, 1); break; }
+    __builtin_amdgcn_s_sleep(4);
+  }
+  if (lane < 32) dst[lane] = data;
+}
+
+// a pair of fp16 values (this lane's and its xor-1 neighbour's) as one granule, written through to L2 by ONE 8-byte store
+__device__ __forceinline__ void publish_pair(u64* slot, half_t mine_h, int lane, bool even, bool on, uint32_t tag) {
+  const uint32_t mine = (uint32_t)__builtin_bit_cast(unsigned short, mine_h);
+  const uint32_t other = __float_as_uint(lane_xor1(__uint_as_float(mine)));
+  if (even && on) {
+    const u64 g = ((u64)tag << 32) | (u64)(mine | (other << 16));
+    __hip_atomic_store(slot, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Both kernels below are written as TWO role bodies under one wave-uniform branch — the KV waves and the auxiliary waves
+// never share a basic block — so that the register allocator sees each role's pressure on its own (the K/V tile of the
+// KV waves is 128 VGPRs; merged control flow carried it through the projection code: 209 VGPRs, one workgroup per CU).
+// Every role executes the same number of s_barrier instructions on every path (counted in the comments: B1 ... B5).
+
+// 8 KV waves x NL rounds of 64 keys (NL = 4 / 6 / 8: up to 512 keys per split) + 4 auxiliary waves.  The two-launch form
+// holds the same 512 keys in 4 waves x 16 rounds; here the tile must stay live across the hand-off barrier (the compiler
+// cannot retire K registers into scores early), and 16 rounds (156 VGPRs) would leave room for one workgroup per CU only:
+// with 8 rounds the kernel needs 80 VGPRs, two 12-wave workgroups fit a CU and all 480 workgroups of large-v3 x 8 rows are
+// resident at once — which is what keeps 61 MB of loads in flight.
+template <int NL>
+__global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
+  pin_kernargs(a);
+  constexpr int WAVES = 8;               // KV waves
+  constexpr int KPR = WAVES * 8;         // keys per round
+  __shared__ __attribute__((aligned(16))) half8v xfrag[P_KS * P_NU * 64];   // LayerNorm output, 8 rows, MFMA fragment order
+  __shared__ float pred[P_KS][8][8];     // producer: [auxiliary wave][feature][row] partial sums
+  __shared__ __attribute__((aligned(16))) uint32_t qsh[32];                 // q of this (row, head): 64 fp16, scaled
+  __shared__ float red[WAVES][64];
+  __shared__ float redm[WAVES], reds[WAVES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
+  const int S = a.splits, D = a.D;
+  const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const bool producer = wgid < (D >> 3); // workgroup-uniform: the first D / 8 workgroups (dispatched first)
+  WH_PROBE_AT(a, wgid, 0);
+
+  if (wave >= WAVES) {
+    // ================= auxiliary waves =================
+    const int aw = wave - WAVES;
+    const int tick = load_uniform_int(a.d_tick);
+    const uint32_t tag = ((uint32_t)(tick + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
+    if (producer) {
+      half8v wa[P_NU];
+      proj_stage1(aw, lane, wgid, a.W, D, a.xf, a.xf_ld, a.R, wa, xfrag);
+      __syncthreads();                               // B1
+      proj_stage2(aw, lane, wa, xfrag, pred);
+      __syncthreads();                               // B2
+      if (aw == 0) {                                 // 64 outputs: lane = 8 row + feature
+        const int er = lane >> 3, ej = lane & 7;
+        const int n = wgid * 8 + ej;
+        float val = a.bias[n];
+#pragma unroll
+        for (int k = 0; k < P_KS; ++k) val += pred[k][ej][er];
+        const half_t qh = (half_t)val;                 // what the two-launch form stores ...
+        const half_t qsc = (half_t)((float)qh * XSCALE);   // ... and what its attention kernel makes of it (exact)
+        publish_pair(a.qg + (size_t)er * (D >> 1) + (n >> 1), qsc, lane, (ej & 1) == 0, er < a.R, tag);
+      }
+    }
+    WH_PROBE_AT(a, wgid, 2);
+    // every workgroup: auxiliary wave 0 fetches the q granules of (row r, head h)
+    if (aw == 0) fetch_granules(a.qg + (size_t)r * (D >> 1) + h * 32, tag, lane, qsh, a.err);
+    __syncthreads();                                 // B3: q is in LDS
+    WH_PROBE_AT(a, wgid, 3);
+    __syncthreads();                                 // B4
+    __syncthreads();                                 // B5
+    return;
+  }
+
+  // ================= KV waves: the whole K / V slice of the split, requested before anything else =================
+  const int Tk = a.Tk;
+  int chunk = (Tk + S - 1) / S;
+  chunk = (chunk + KPR - 1) / KPR * KPR;
+  const int k0 = s * chunk;
+  int k1 = k0 + chunk; if (k1 > Tk) k1 = Tk;
+  const int nkeys = k1 > k0 ? k1 - k0 : 0;
+  const int cu = lane & 7, ks = lane >> 3;
+  const int kk0 = wave * 8 + ks;
+  half8v ku[NL], vu[NL];
+  {
+    const half_t* kp = (const half_t*)a.k + (int64_t)r * a.k_bs + h * 64 + cu * 8;
+    const half_t* vp = (const half_t*)a.v + (int64_t)r * a.v_bs + h * 64 + cu * 8;
+    const int klast = nkeys > 0 ? nkeys - 1 : 0;
+    const uint32_t ldk = (uint32_t)a.k_ld, ldv = (uint32_t)a.v_ld;
+    const uint32_t ok0 = (uint32_t)(k0 + kk0) * ldk, okl = (uint32_t)(k0 + klast) * ldk;
+    const uint32_t ov0 = (uint32_t)(k0 + kk0) * ldv, ovl = (uint32_t)(k0 + klast) * ldv;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      uint32_t o = ok0 + (uint32_t)(i * KPR) * ldk; if (o > okl) o = okl;
+      ku[i] = __builtin_nontemporal_load((const half8v*)(kp + o));
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      uint32_t o = ov0 + (uint32_t)(i * KPR) * ldv; if (o > ovl) o = ovl;
+      vu[i] = __builtin_nontemporal_load((const half8v*)(vp + o));
+    }
+  }
+  WH_PROBE_AT(a, wgid, 1);
+  if (producer) {
+    __syncthreads();                                 // B1
+    __syncthreads();                                 // B2
+  }
+  __syncthreads();                                   // B3: q is in LDS
+
+  // scores, softmax statistics, p . V (attn_decode_kernel, SKIP = false)
+  float sc[NL];
+  float mx = WH_NEG_INF;
+  {
+    const half8v qs = *(const half8v*)((const char*)qsh + cu * 16);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float d = qk_unit8(qs, ku[i]);
+      d = group8_sum(d);
+      sc[i] = (kk0 + i * KPR < nkeys) ? d : WH_NEG_INF;
+      mx = fmaxf(mx, sc[i]);
+    }
+    mx = across_groups8_max(mx);
+    if (lane == 0) redm[wave] = mx;
+  }
+  __syncthreads();                                   // B4
+  mx = redm[0];
+#pragma unroll
+  for (int w = 1; w < WAVES; ++w) mx = fmaxf(mx, redm[w]);
+  float acc[8];
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const float p = (sc[i] == WH_NEG_INF) ? 0.f : __expf(sc[i] - mx);
+    sum += p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(p, (float)vu[i][e], acc[e]);
+  }
+  sum = across_groups8_sum(sum);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = across_groups8_sum(acc[e]);
+  if (ks == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][cu * 8 + e] = acc[e];
+  }
+  if (lane == 0) reds[wave] = sum;
+  __syncthreads();                                   // B5
+  WH_PROBE_AT(a, wgid, 4);
+  if (tid < 64) {
+    float o = red[0][tid], l = reds[0];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) { o += red[w][tid]; l += reds[w]; }
+    if (S == 1) {
+      ((half_t*)a.out)[(int64_t)r * a.o_ld + h * 64 + tid] = (half_t)(o / l);
+    } else {
+      const int64_t pi = ((int64_t)s * a.R + r) * a.H + h;
+      ((half_t*)a.part_o)[pi * 64 + tid] = (half_t)(nkeys > 0 ? o / l : 0.f);
+      if (tid == 0) {
+        a.part_ml[pi * 2 + 0] = nkeys > 0 ? mx : WH_NEG_INF;
+        a.part_ml[pi * 2 + 1] = nkeys > 0 ? l : 0.f;
+      }
+    }
+  }
+  WH_PROBE_AT(a, wgid, 5);
+}
+
+// =====================================================================================================================
+// self attention of one decode step with its LayerNorm + QKV projection inside the launch (fp16, <= 8 rows).
+// `attn_ln` + `attn.query / key / value` (model.py:39-50, 152-153) + the KV-cache append (model.py:310-341) + the
+// single-query attention over the cache (model.py:114-139).  One workgroup per 8-feature group of the 3D outputs
+// (480 for large-v3): 4 auxiliary waves project (proj_stage1 / 2), auxiliary wave 0 writes the outputs — q scaled by
+// d_head^-0.5 as a granule; k, v unscaled as granules AND into the cache row of this step (for the steps to come).
+// The LAST H x R workgroups are also CONSUMERS of one (head, row): their 8 KV waves request the cached keys / values
+// of the earlier positions at entry (they do not depend on this step), three auxiliary waves then fetch the 3 x 32
+// granules of q and of the NEW key / value of their head, which take the place of the cache row in the register tile.
+// Consumers sit at the end of the dispatch order: when one is resident every producer has been dispatched, so no
+// occupancy can starve them.  In the other workgroups the 8 KV waves exit at once.
+// Arithmetic and order as gemv8_kernel<PRO_LN> (EPI_QKV) + attn_decode_kernel<half, 8, 8, true>: bit-identical.
+// 7 rounds x 64 keys cover n_text_ctx = 448 (the register tile has to stay live across the hand-off barrier; with 8
+// rounds the kernel spilled at the 80 VGPRs that let two 12-wave workgroups share a CU).
+// =====================================================================================================================
+__global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
+  pin_kernargs(a);
+  constexpr int NL = 7, WAVES = 8, KPR = WAVES * 8;      // 7 rounds x 64 keys = 448 cached positions = n_text_ctx
+  __shared__ __attribute__((aligned(16))) half8v xfrag[P_KS * P_NU * 64];
+  __shared__ float pred[P_KS][8][8];
+  __shared__ __attribute__((aligned(16))) uint32_t qkv_sh[3][32];           // q (scaled), new k, new v of (row, head)
+  __shared__ float red[WAVES][64];
+  __shared__ float redm[WAVES], reds[WAVES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = a.D, H = a.H, R = a.R;
+  const int wgid = blockIdx.x, nwg = gridDim.x;
+  const int cidx = wgid - (nwg - H * R);           // consumer index, >= 0 in the last H * R workgroups
+  const bool consumer = cidx >= 0;                 // workgroup-uniform
+  const int r = consumer ? cidx / H : 0, h = consumer ? cidx - (cidx / H) * H : 0;
+  WH_PROBE_AT(a, wgid, 0);
+
+  if (wave >= WAVES) {
+    // ================= auxiliary waves: the projection of feature group `wgid` (every workgroup) =================
+    const int aw = wave - WAVES;
+    const int tick = load_uniform_int(a.d_tick);
+    const uint32_t tag = ((uint32_t)(tick + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
+    const int vpos = aw == 0 ? load_agent_int(a.d_pos) : 0;           // used by the cache append only
+    half8v wa[P_NU];
+    proj_stage1(aw, lane, wgid, a.W, D, a.xf, a.xf_ld, R, wa, xfrag);
+    __syncthreads();                                 // B1
+    proj_stage2(aw, lane, wa, xfrag, pred);
+    __syncthreads();                                 // B2
+    if (aw == 0) {                                   // 64 outputs: lane = 8 row + feature
+      const int er = lane >> 3, ej = lane & 7;
+      const int n = wgid * 8 + ej;                   // output feature in [0, 3D)
+      float val = a.bias[n];
+#pragma unroll
+      for (int k = 0; k < P_KS; ++k) val += pred[k][ej][er];
+      const half_t vh = (half_t)val;
+      const bool on = er < R;
+      half_t pub = vh;
+      if (n < D) {
+        pub = (half_t)((float)vh * XSCALE);          // q: scaled for the attention (exact in fp16)
+        if (on && a.q_out) ((half_t*)a.q_out)[(int64_t)er * D + n] = vh;
+      } else if (on) {
+        const int rlag = a.lag ? a.lag[er] : 0;
+        const int64_t pos = (int64_t)vpos - rlag;
+        if (n < 2 * D) ((half_t*)a.kcache)[(int64_t)er * a.cache_bs + pos * D + (n - D)] = vh;
+        else ((half_t*)a.vcache)[(int64_t)er * a.cache_bs + pos * D + (n - 2 * D)] = vh;
+      }
+      publish_pair(a.qg + (size_t)er * (3 * D >> 1) + (n >> 1), pub, lane, (ej & 1) == 0, on, tag);
+    }
+    WH_PROBE_AT(a, wgid, 2);
+    if (!consumer) return;
+    // consumers: three auxiliary waves fetch the granules of q, new k, new v of (row r, head h)
+    if (aw < 3) fetch_granules(a.qg + (size_t)r * (3 * D >> 1) + aw * (D >> 1) + h * 32, tag, lane, qkv_sh[aw], a.err);
+    __syncthreads();                                 // B3
+    WH_PROBE_AT(a, wgid, 3);
+    __syncthreads();                                 // B4
+    __syncthreads();                                 // B5
+    return;
+  }
+
+  // ================= KV waves: only in consumer workgroups =================
+  if (!consumer) return;                             // (ended waves are not waited for by the barriers of the others)
+  const int vpos = load_agent_int(a.d_pos);
+  const int vlag = load_agent_int(a.lag ? a.lag + r : a.d_pos);
+  const int cu = lane & 7, ks = lane >> 3;
+  const int kk0 = wave * 8 + ks;
+  const int Tk = uniform(vpos) + 1 - (a.lag ? uniform(vlag) : 0);     // keys incl. the new one at index Tk - 1
+  const int nround = (Tk + KPR - 1) / KPR;
+  half8v ku[NL], vu[NL];
+  {
+    // the cached K / V of the earlier positions, requested before anything else
+    const half_t* kp = (const half_t*)a.kcache + (int64_t)r * a.cache_bs + h * 64 + cu * 8;
+    const half_t* vp = (const half_t*)a.vcache + (int64_t)r * a.cache_bs + h * 64 + cu * 8;
+    const uint32_t ld = (uint32_t)D;
+    const uint32_t last_old = Tk >= 2 ? (uint32_t)(Tk - 2) * ld : 0u;  // slots at or past the new key re-read an old row
+    const uint32_t o0 = (uint32_t)kk0 * ld;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      if (i < nround) {
+        uint32_t o = o0 + (uint32_t)(i * KPR) * ld; if (o > last_old) o = last_old;
+        ku[i] = __builtin_nontemporal_load((const half8v*)(kp + o));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      if (i < nround) {
+        uint32_t o = o0 + (uint32_t)(i * KPR) * ld; if (o > last_old) o = last_old;
+        vu[i] = __builtin_nontemporal_load((const half8v*)(vp + o));
+      }
+    }
+  }
+  WH_PROBE_AT(a, wgid, 1);
+  __syncthreads();                                   // B1
+  __syncthreads();                                   // B2
+  __syncthreads();                                   // B3: q, new k, new v are in LDS
+
+  float sc[NL];
+  float mx = WH_NEG_INF;
+  {
+    // the key this step appends sits at index Tk - 1: exactly one (round, key slot) of one wave takes it from the
+    // granules instead of the register tile (a select per round; the tile itself stays untouched)
+    const half8v qs = *(const half8v*)((const char*)qkv_sh[0] + cu * 16);
+    const half8v knew = *(const half8v*)((const char*)qkv_sh[1] + cu * 16);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      sc[i] = WH_NEG_INF;
+      if (i < nround) {
+        const int kidx = kk0 + i * KPR;
+        float d = qk_unit8(qs, kidx == Tk - 1 ? knew : ku[i]);
+        d = group8_sum(d);
+        sc[i] = (kidx < Tk) ? d : WH_NEG_INF;
+        mx = fmaxf(mx, sc[i]);
+      }
+    }
+    mx = across_groups8_max(mx);
+    if (lane == 0) redm[wave] = mx;
+  }
+  __syncthreads();                                   // B4
+  mx = redm[0];
+#pragma unroll
+  for (int w = 1; w < WAVES; ++w) mx = fmaxf(mx, redm[w]);
+  float acc[8];
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const half8v vnew = *(const half8v*)((const char*)qkv_sh[2] + cu * 16);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    if (i < nround) {
+      const float p = (sc[i] == WH_NEG_INF) ? 0.f : __expf(sc[i] - mx);
+      sum += p;
+      const half8v vv = (kk0 + i * KPR == Tk - 1) ? vnew : vu[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(p, (float)vv[e], acc[e]);
+    }
+  }
+  sum = across_groups8_sum(sum);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = across_groups8_sum(acc[e]);
+  if (ks == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][cu * 8 + e] = acc[e];
+  }
+  if (lane == 0) reds[wave] = sum;
+  __syncthreads();                                   // B5
+  WH_PROBE_AT(a, wgid, 4);
+  if (tid < 64) {
+    float o = red[0][tid], l = reds[0];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) { o += red[w][tid]; l += reds[w]; }
+    ((half_t*)a.out)[(int64_t)r * a.o_ld + h * 64 + tid] = (half_t)(o / l);
+  }
+  WH_PROBE_AT(a, wgid, 5);
+}
+
+}  // namespace
+
+namespace whk {
+
+bool xattn_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("WH_NO_FUSED_XATTN"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
+// the shapes the fused form takes: fp16 (checked by the caller), <= 8 rows, one row per audio, K = D <= 1280 in blocks
+// of 64, enough workgroups to host the D / 8 producers, a split that fits 16 rounds of 32 keys
+bool xattn_supported(int D, int H, int R, int kv_group, int Tk, int splits) {
+  if (!xattn_enabled()) return false;
+  if (R < 1 || R > 8 || kv_group != 1 || D % 64 != 0 || D > 1280 || H * 64 != D) return false;
+  if (splits < 1 || splits * H * R < D / 8) return false;
+  const int chunk = (Tk + splits - 1) / splits;
+  return (chunk + 63) / 64 <= 8;
+}
+
+// self attention + QKV projection: <= 8 rows, the cache fits the 512-key register tile, enough workgroups for the consumers
+bool sattn_supported(int D, int H, int R, int n_ctx) {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("WH_NO_FUSED_SATTN"); v = (e && e[0] == '1') ? 0 : 1; }
+  if (v != 1) return false;
+  if (R < 1 || R > 8 || D % 64 != 0 || D > 1280 || H * 64 != D || n_ctx > 448) return false;
+  return H * R <= 3 * D / 8;
+}
+
+hipError_t launch_sattn8(const SAttnArgs& a, hipStream_t stream) {
+  if ((int64_t)3 * a.D * a.D >= (1ll << 30) || (int64_t)a.D * 448 > 0x7fffffff) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sattn8_kernel, dim3(3 * a.D / 8), dim3(768), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_xattn8(const XAttnArgs& a, hipStream_t stream) {
+  if (!xattn_supported(a.D, a.H, a.R, 1, a.Tk, a.splits)) return hipErrorNotSupported;
+  if ((int64_t)a.k_ld * 2048 > 0x7fffffff || (int64_t)a.v_ld * 2048 > 0x7fffffff) return hipErrorInvalidValue;
+  if ((int64_t)a.D * a.D >= (1ll << 30)) return hipErrorInvalidValue;          // 32-bit lane offsets into W
+  const int chunk = (a.Tk + a.splits - 1) / a.splits;
+  const int rounds = (chunk + 63) / 64;
+  dim3 grid(a.splits, a.H, a.R), block(768);
+  if (rounds <= 4) hipLaunchKernelGGL((xattn8_kernel<4>), grid, block, 0, stream, a);
+  else if (rounds <= 6) hipLaunchKernelGGL((xattn8_kernel<6>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((xattn8_kernel<8>), grid, block, 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace whk

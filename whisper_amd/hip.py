@@ -18,6 +18,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwhisper
 
 WH_F32, WH_F16 = 0, 1
 WH_TASK_CAPTURE_Q = 1
+WH_TASK_TWO_LAUNCH_ATTN = 2
 WH_WEIGHTS_DEC_LN_FOLDED = 1
 WH_WEIGHTS_ENC_QK_SCALED = 2
 # sqrt(0.125 * log2 e): with it in both the query and the key projection, K.Q^T is the exp2 argument of the softmax
@@ -94,6 +95,7 @@ SIGNATURES = {
     "wh_task_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
     "wh_task_set_lag": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "wh_task_position": (C.c_int, [C.c_void_p]),
+    "wh_task_info": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "wh_task_greedy": (C.c_int, [C.c_void_p, C.POINTER(GreedyParams), C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "wh_task_beam": (C.c_int, [C.c_void_p, C.POINTER(BeamParams), C.c_void_p, C.c_int64, C.c_int, C.c_int,
@@ -481,12 +483,12 @@ class HipTask:
     tasks (workspace + captured step graph) for the next window of the same shape."""
 
     def __init__(self, model: HipModel, n_audio: int, n_group: int, max_prefill: int, capture_q: bool = False,
-                 stream: Optional[torch.cuda.Stream] = None):
+                 stream: Optional[torch.cuda.Stream] = None, two_launch_attention: bool = False):
         self.model = model
         self.n_audio, self.n_group, self.n_rows = n_audio, n_group, n_audio * n_group
         self.max_prefill = max_prefill
         self.capture_q = capture_q
-        flags = WH_TASK_CAPTURE_Q if capture_q else 0
+        flags = (WH_TASK_CAPTURE_Q if capture_q else 0) | (WH_TASK_TWO_LAUNCH_ATTN if two_launch_attention else 0)
         self.stream = stream if stream is not None else model.stream   # independent tasks may run on own streams
         with torch.cuda.device(model.device):
             need = lib().wh_task_workspace_bytes(model.handle, n_audio, n_group, max_prefill, flags)
@@ -590,6 +592,22 @@ class HipTask:
     @property
     def position(self) -> int:
         return lib().wh_task_position(self.handle)
+
+    @property
+    def fused_cross_attention(self) -> bool:
+        """the decode step runs LN -> cross query -> cross attention as one launch (csrc/xattn.hip)"""
+        return lib().wh_task_info(self.handle, 0, None) == 1
+
+    @property
+    def fused_self_attention(self) -> bool:
+        """the decode step runs LN -> QKV -> cache append -> self attention as one launch (csrc/xattn.hip)"""
+        return lib().wh_task_info(self.handle, 2, None) == 1
+
+    def handoff_timeouts(self) -> int:
+        """bounded hand-off spins of the fused cross attention that ran out (0 on a healthy device); synchronises"""
+        with self._call():
+            n = lib().wh_task_info(self.handle, 1, stream_ptr(self.stream))
+        return n
 
     def greedy(self, tokens: torch.Tensor, params: GreedyParams, sot_index: int, no_speech_token: int):
         """tokens: int64 [n_rows][>= sample_begin + max_steps], initial tokens in the first columns.
