@@ -140,9 +140,11 @@ int wh_encode(const wh_model *m, const void *mel, int mel_is_f16, int batch, voi
 /* ---- decoding task: PyTorchInference + kv_cache — whisper/decoding.py:144-176, model.py:310-341 */
 /* flags for wh_task_create */
 enum {
-  WH_TASK_CAPTURE_Q = 1,      /* keep cross-attention queries of every layer (word timestamps) */
-  WH_TASK_TWO_LAUNCH_ATTN = 2 /* decode step: projection and attention as separate launches even where the fused kernels of
-                               * csrc/xattn.hip apply (A/B and tests: the results must agree) */
+  WH_TASK_CAPTURE_Q = 1,         /* keep cross-attention queries of every layer (word timestamps) */
+  /* decode step: projection and attention as separate launches even where the fused kernels of csrc/xattn.hip apply
+   * (A/B and tests: the results must agree) — for the self attention / for the cross attention */
+  WH_TASK_TWO_LAUNCH_SELF = 2,
+  WH_TASK_TWO_LAUNCH_CROSS = 4
 };
 /* The workspace holds the cross-attention K/V of n_audio segments, the self-attention cache of n_audio * n_group rows
  * and the step buffers.  WH_F16 tasks with n_group > 1 (beam search) additionally hold a transposed copy of the

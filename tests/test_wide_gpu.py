@@ -68,11 +68,15 @@ def test_wide_prefill_and_steps(wide, gpu_device, dt, tol, B, G, T0):
 def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B):
     """csrc/xattn.hip: the decode step of <= 8 rows (fp16) runs LayerNorm + QKV projection + cache append + self
     attention as ONE launch and LayerNorm + query projection + cross attention as ONE launch (projection under the K/V
-    stream, q / new k / new v handed between workgroups as tagged 8-byte granules).  Against the same step with
-    projection and attention as separate launches (WH_TASK_TWO_LAUNCH_ATTN): prefill + 12 steps on the same tokens, the
-    logits agree (the projections are bit-identical; the cross attention sums its key range with 8 instead of 4 waves'
-    partial sums: 1e-3 on unit-scale logits), the arg-max ids are equal, the caches the fused kernel appends serve the
-    later steps, no hand-off spin ran out, and ragged rows (per-row lag) take the same path."""
+    stream; q / new k / new v handed between workgroups as tagged 8-byte granules).  Against the same step with
+    projection and attention as separate launches (WH_TASK_TWO_LAUNCH_*), prefill + 12 steps on the same tokens, ragged
+    rows (per-row lag) included:
+      * the fused SELF attention is bit-identical (same products, same order of sums);
+      * the fused CROSS attention reproduces q bit for bit and sums each key range with 8 instead of 4 waves' partial
+        sums: fp32 sums in another order flip the fp16 rounding of an attention output now and then (1 ulp), which the
+        later layers and steps carry on — the logits agree at the level of the fp16 engine's own rounding noise
+        (asserted: max 2e-2 = a third of its 6e-2 bound against the fp32 oracle, rms 2e-3);
+      * no bounded hand-off spin ran out."""
     dims = oracle.dims_for(name)
     sd = oracle.synthetic_state_dict(dims, seed=11)
     model = hip.HipModel(dims, hip.WH_F16, hip.pack_weights(sd, dims, hip.WH_F16, gpu_device))
@@ -81,11 +85,11 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B):
     T0 = 7
     toks = torch.randint(0, dims.n_vocab, (B, T0 + 12), generator=g).to(gpu_device)
     lag = [(3 * i) % 5 for i in range(B)] if B > 1 else None           # ragged prompts: rows sit at their own positions
-    outs = []
-    for two in (False, True):
-        task = hip.HipTask(model, B, 1, 8, two_launch_attention=two)
+
+    def run(two_self, two_cross):
+        task = hip.HipTask(model, B, 1, 8, two_launch_self=two_self, two_launch_cross=two_cross)
         try:
-            assert task.fused_cross_attention == (not two) and task.fused_self_attention == (not two)
+            assert task.fused_self_attention == (not two_self) and task.fused_cross_attention == (not two_cross)
             task.set_audio(feats)
             if lag is not None:
                 task.set_lag(lag)
@@ -93,14 +97,18 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B):
             for i in range(12):
                 got.append(task.step(toks[:, T0 + i]).float().cpu())
             assert task.handoff_timeouts() == 0
-            outs.append(torch.stack(got))
+            return torch.stack(got)
         finally:
             task.close()
-    fused, plain = outs
-    assert torch.isfinite(fused).all()
-    err = (fused - plain).abs().max().item()
-    assert err < 1e-3, err
-    assert torch.equal(fused.argmax(-1), plain.argmax(-1))
+
+    plain = run(True, True)
+    assert torch.isfinite(plain).all()
+    fused_self = run(False, True)
+    assert torch.equal(fused_self, plain), (fused_self - plain).abs().max().item()
+    for out in (run(True, False), run(False, False)):                 # fused cross attention alone, and both
+        d = (out - plain).abs()
+        assert d.max().item() < 2e-2 and (d.double() ** 2).mean().sqrt().item() < 2e-3, (d.max().item(), (d.double() ** 2).mean().sqrt().item())
+        assert (out.argmax(-1) == plain.argmax(-1)).float().mean().item() > 0.98
 
 
 @pytest.mark.parametrize("name,B,G", [("base", 20, 1), ("small", 4, 5), ("base", 48, 1)])

@@ -401,9 +401,9 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
     const int cap = attn_decode_capacity(m->dtype);
     t->self_splits = (m->d.n_text_ctx + cap - 1) / cap;
   }
-  t->fused_xattn = !(flags & WH_TASK_TWO_LAUNCH_ATTN) && m->dtype == WH_F16 && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) &&
+  t->fused_xattn = !(flags & WH_TASK_TWO_LAUNCH_CROSS) && m->dtype == WH_F16 && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) &&
                    xattn_supported(m->d.n_text_state, m->d.n_text_head, t->R, t->G, m->d.n_audio_ctx, t->cross_splits);
-  t->fused_sattn = !(flags & WH_TASK_TWO_LAUNCH_ATTN) && m->dtype == WH_F16 && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) && t->self_splits == 1 &&
+  t->fused_sattn = !(flags & WH_TASK_TWO_LAUNCH_SELF) && m->dtype == WH_F16 && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) && t->self_splits == 1 &&
                    sattn_supported(m->d.n_text_state, m->d.n_text_head, t->R, m->d.n_text_ctx);
   t->h_lag = (int*)calloc((size_t)t->R, sizeof(int));
   if (!t->h_lag) { delete t; return WH_ERR_ARG; }
