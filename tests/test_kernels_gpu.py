@@ -227,20 +227,28 @@ def test_dtw_backtrace_on_device(gpu_device, N, M):
     first = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
     assert np.array_equal(jumps.cpu().numpy(), fi[first])
     assert np.array_equal(dtw(torch.from_numpy(x).to(gpu_device)), want)
-    # a planted path: cost 1 everywhere except 0 along a random monotone walk (tests/test_timing.py:20-46)
-    steps = np.concatenate([np.zeros(M - 1, np.uint8), np.ones(N - 1, np.uint8)])
+    # the reference's known-answer generator (tests/test_timing.py:22-48): random costs in [0, 1), minus 1 along a planted
+    # monotone walk (a diagonal step wherever the walk turns a corner): dtw must recover exactly that walk
+    steps = np.concatenate([np.zeros(N - 1), np.ones(M - 1)])
     rng.shuffle(steps)
-    pi, pj = [0], [0]
-    for st in steps:
-        pi.append(pi[-1] + int(st == 1))
-        pj.append(pj[-1] + int(st == 0))
-    y = np.ones((N, M), np.float32)
-    y[pi, pj] = 0
+    y = rng.random((N, M)).astype(np.float32)
+    i, j, k, planted = 0, 0, 0, []
+    while True:
+        y[i, j] -= 1
+        planted.append((i, j))
+        if k == len(steps):
+            break
+        if k + 1 < len(steps) and steps[k] != steps[k + 1]:
+            i, j, k = i + 1, j + 1, k + 2
+            continue
+        if steps[k] == 0:
+            i += 1
+        if steps[k] == 1:
+            j += 1
+        k += 1
     got = dtw(torch.from_numpy(y).to(gpu_device))
     assert np.array_equal(got, oracle.dtw_path(y))
-    assert float(y[got[0], got[1]].sum()) == 0.0          # a zero-cost path (diagonal shortcuts past a corner tie with the planted one)
-    assert got[0][0] == 0 and got[1][0] == 0 and got[0][-1] == N - 1 and got[1][-1] == M - 1
-    assert np.all(np.diff(got[0]) >= 0) and np.all(np.diff(got[1]) >= 0)
+    assert np.array_equal(got, np.array(planted).T)
 
 
 def test_dtw_backtrace_batch_ragged(gpu_device):

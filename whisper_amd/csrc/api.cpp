@@ -563,18 +563,26 @@ static hipError_t proj_resid(const wh_model* m, const void* x, int64_t x_ld, int
 }
 
 // ---- prefill: T0 tokens per row through the GEMM path ------------------------------------------
+// leaders (beam search / best-of sampling, G > 1): the G rows of a segment start from the same tokens, so only ONE row
+// per segment — row b G of the caller's token matrix — runs through the decoder; it uses cache rows / logits rows
+// 0 .. B-1, and the caller replicates them to the rows of each group afterwards (replicate_leader_rows).  The reference
+// feeds all n_audio x n_group identical rows (decoding.py:734 repeat_interleave): same values, G times the work.
 static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride, int T0, const int32_t* sel_pos,
-                        int n_sel, float* logits_out, int64_t logits_row_ld, hipStream_t s) {
+                        int n_sel, float* logits_out, int64_t logits_row_ld, hipStream_t s, bool leaders = false) {
   const wh_model* m = t->m;
   const wh_dims& d = m->d;
   const int D = d.n_text_state, H = d.n_text_head, C = d.n_text_ctx, Ta = d.n_audio_ctx, V = d.n_vocab;
-  const int R = t->R, M = R * T0;
+  const int R = leaders ? t->B : t->R, M = R * T0;
+  const int Gp = leaders ? 1 : t->G;               // rows per audio in this pass
+  const int lag_step = leaders ? t->G : 1;         // row r of this pass is row r * lag_step of the task
+  if (leaders) token_stride *= t->G;
   const size_t es = m->esize;
   if (!t->audio_set) return WH_ERR_STATE;
   if (T0 <= 0 || T0 > t->Tmax || t->pos + T0 > C) return WH_ERR_ARG;
+  if (leaders && (t->pos != 0 || t->qcap)) return WH_ERR_STATE;
   if (t->lag_on) {
     if (t->pos != 0) return WH_ERR_STATE;
-    for (int r = 0; r < R; ++r) if (t->h_lag[r] >= T0) return WH_ERR_ARG;
+    for (int r = 0; r < R; ++r) if (t->h_lag[r * lag_step] >= T0) return WH_ERR_ARG;
   }
 
   const bool skinny = M <= SKINNY_ROWS && D <= 2048;
@@ -622,7 +630,7 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
       a.q = t->qkv; a.q_ld = D;
       a.k = cross_layer(t, l); a.k_ld = 2 * D; a.k_bs = (int64_t)Ta * 2 * D;
       a.v = (char*)cross_layer(t, l) + (size_t)D * es; a.v_ld = 2 * D; a.v_bs = a.k_bs;
-      a.H = H; a.R = M; a.kv_group = T0 * t->G; a.Tk = Ta; a.splits = ps;
+      a.H = H; a.R = M; a.kv_group = T0 * Gp; a.Tk = Ta; a.splits = ps;
       a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
       HIPCHK(launch_attn_decode(a, m->dtype, s));
       GemvArgs g; memset(&g, 0, sizeof(g));
@@ -637,7 +645,7 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
       a.k = cross_layer(t, l); a.k_ld = 2 * D; a.k_bs = (int64_t)Ta * 2 * D;
       a.v = (char*)cross_layer(t, l) + (size_t)D * es; a.v_ld = 2 * D; a.v_bs = a.k_bs;
       a.out = t->att; a.o_ld = D; a.o_bs = (int64_t)T0 * D;
-      a.H = H; a.Tq = T0; a.Tk = Ta; a.causal = 0; a.kv_group = t->G;
+      a.H = H; a.Tq = T0; a.Tk = Ta; a.causal = 0; a.kv_group = Gp;
       HIPCHK(launch_attn_generic(a, R, m->dtype, s));
     }
     if (skinny) {
@@ -656,7 +664,7 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
     std::vector<int> sel((size_t)R * n_sel);
     for (int r = 0; r < R; ++r)
       for (int i = 0; i < n_sel; ++i) {
-        const int p = (sel_pos ? sel_pos[i] : i) - (sel_pos ? t->h_lag[r] : 0);   // selected positions shift with the row
+        const int p = (sel_pos ? sel_pos[i] : i) - (sel_pos ? t->h_lag[r * lag_step] : 0);   // selected positions shift with the row
         if (p < 0 || p >= T0) return WH_ERR_ARG;
         sel[(size_t)r * n_sel + i] = r * T0 + p;
       }
@@ -705,7 +713,7 @@ static XAttnArgs xattn_args(const wh_task* t, int l, int epoch) {
   a.v = (char*)cross_layer(t, l) + (size_t)D * m->esize; a.v_ld = 2 * D; a.v_bs = a.k_bs;
   a.Tk = Ta; a.splits = t->cross_splits;
   a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
-  a.qg = t->xq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err;
+  a.qg = t->xq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err; a.mode = fused_mode();
   return a;
 }
 
@@ -722,7 +730,7 @@ static SAttnArgs sattn_args(const wh_task* t, int l, int epoch) {
   a.kcache = self_k_layer(t, l); a.vcache = self_v_layer(t, l); a.cache_bs = (int64_t)d.n_text_ctx * D;
   a.d_pos = t->d_pos; a.lag = t->d_lag; a.q_out = t->qbuf;
   a.out = t->att; a.o_ld = D;
-  a.qg = t->sq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err;
+  a.qg = t->sq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err; a.mode = fused_mode();
   return a;
 }
 
@@ -996,6 +1004,26 @@ extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* to
   return WH_OK;
 }
 
+// after a `leaders` prefill: cache rows 0 .. B-1 hold the T0 prompt positions of the B segments and logits rows 0 .. B-1
+// their selected logits; row b goes to rows b G .. b G + G - 1.  Descending b: the destination rows of segment b only
+// overlap source rows of segments above b, which have been replicated by then.
+static int replicate_leader_rows(wh_task* t, int T0, float* logits, int n_sel, hipStream_t s) {
+  const wh_dims& d = t->m->d;
+  const size_t es = t->m->esize;
+  const int64_t row_bytes = (int64_t)d.n_text_ctx * d.n_text_state * es;
+  const int64_t layer_bytes = (int64_t)t->R * row_bytes;
+  for (int b = t->B - 1; b >= 0; --b) {
+    HIPCHK(launch_replicate_row(t->self_k, layer_bytes, d.n_text_layer, row_bytes, b, b * t->G, t->G,
+                                (int64_t)T0 * d.n_text_state * es, s));
+    HIPCHK(launch_replicate_row(t->self_v, layer_bytes, d.n_text_layer, row_bytes, b, b * t->G, t->G,
+                                (int64_t)T0 * d.n_text_state * es, s));
+    if (logits)
+      HIPCHK(launch_replicate_row(logits, 0, 1, (int64_t)n_sel * d.n_vocab * 4, b, b * t->G, t->G,
+                                  (int64_t)n_sel * d.n_vocab * 4, s));
+  }
+  return WH_OK;
+}
+
 // ---- fused beam search loop --------------------------------------------------------------------------
 extern "C" int wh_task_beam(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int64_t token_stride, int sot_index,
                             int no_speech_token, float* sum_logprobs, float* no_speech_probs, int64_t* fin_tokens,
@@ -1022,8 +1050,12 @@ extern "C" int wh_task_beam(wh_task* t, const wh_beam_params* bp, int64_t* token
   const bool want_ns = no_speech_token >= 0 && no_speech_probs != nullptr;
   if (want_ns && sot_index != T0 - 1) { sel[0] = sot_index; sel[1] = T0 - 1; n_sel = 2; }
   else { sel[0] = T0 - 1; n_sel = 1; }
-  int rc = prefill_impl(t, tokens, token_stride, T0, sel, n_sel, t->logits, V, s);
+  // the G beams of a segment hold the same prompt: one row per segment through the decoder, then replicate (A/B:
+  // WH_BEAM_FULL_PREFILL=1 feeds all R rows as the reference does)
+  static const bool leaders = [] { const char* e = getenv("WH_BEAM_FULL_PREFILL"); return !(e && e[0] == '1'); }();
+  int rc = prefill_impl(t, tokens, token_stride, T0, sel, n_sel, t->logits, V, s, leaders);
   if (rc != WH_OK) return rc;
+  if (leaders) { rc = replicate_leader_rows(t, T0, t->logits, n_sel, s); if (rc != WH_OK) return rc; }
   if (want_ns) HIPCHK(launch_no_speech(t->logits, (int64_t)n_sel * V, R, V, no_speech_token, no_speech_probs, s));
   HIPCHK(hipMemsetAsync(sum_logprobs, 0, (size_t)R * 4, s));
   HIPCHK(hipMemsetAsync(fin_count, 0, (size_t)B * 4, s));

@@ -425,14 +425,36 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int s = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
   const int S = a.splits;
+  const int kvb0 = r / a.kv_group;
+  const int cu0 = lane % LPK, ks0 = lane / LPK;
+  const int64_t hs0 = a.kv_hs ? a.kv_hs : 64;
+  // Self attention (SKIP): the cached length lives on the device, and everything below — split bounds, the clamp of the
+  // load offsets — waits for that L2 round trip (~1 us of a 5.5 us launch).  The first EAG rounds of KEYS do not need it:
+  // with one split their addresses are fixed (keys 0 .. 2 KPR - 1 of the row; the cache row exists for all n_ctx
+  // positions), so they are requested right behind the position loads, unclamped.  Slots at or beyond the cached length
+  // may then hold anything (stale positions of an earlier clip) — their score is replaced by -inf below, and only keys are
+  // fetched this way (a masked VALUE would still enter the sum as 0 x NaN).
+  constexpr int EAG = SKIP ? 2 : 0;
+  const bool eager = SKIP && S == 1 && a.d_len != nullptr;
   int Tk = a.Tk;
+  int vn = 0, vl = 0;
   if (a.d_len) {                          // cached length and this row's lag: two independent agent-scope loads
     // (measured alternative: `s_load_dword ... glc` past the scalar cache — 1280 waves polling one word that way take
     // 38 us per launch instead of 5.6; the plain s_load is stale between launches, see load_agent_int)
-    const int vn = load_agent_int(a.d_len);
-    const int vl = load_agent_int(a.lag ? a.lag + r : a.d_len);
-    Tk = uniform(vn) + a.len_plus - (a.lag ? uniform(vl) : 0);
+    vn = load_agent_int(a.d_len);
+    vl = load_agent_int(a.lag ? a.lag + r : a.d_len);
   }
+  // q first (L2 hit, needed first): loads return in issue order
+  const unit_t qraw = *(const unit_t*)((const T*)a.q + (int64_t)r * a.q_ld + h * 64 + cu0 * UNIT);
+  asm volatile("" ::: "memory");
+  typename ET<T>::unit_t ku_e[EAG > 0 ? EAG : 1];
+  if (eager) {
+    const T* kpe = (const T*)a.k + (int64_t)kvb0 * a.k_bs + h * hs0 + cu0 * UNIT;
+#pragma unroll
+    for (int i = 0; i < EAG; ++i)
+      ku_e[i] = __builtin_nontemporal_load((const unit_t*)(kpe + (uint32_t)((i * WAVES + wave) * KPW + ks0) * (uint32_t)a.k_ld));
+  }
+  if (a.d_len) Tk = uniform(vn) + a.len_plus - (a.lag ? uniform(vl) : 0);
   int chunk = (Tk + S - 1) / S;
   chunk = (chunk + KPR - 1) / KPR * KPR;
   const int k0 = s * chunk;
@@ -450,9 +472,6 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArg
   const T* kp = (const T*)a.k + (int64_t)kvb * a.k_bs + h * hs + cu * UNIT;   // wave-uniform part folded by the compiler
   const T* vp = (const T*)a.v + (int64_t)kvb * a.v_bs + h * hs + cu * UNIT;
 
-  // q first (L2 hit, needed first): loads return in issue order
-  const unit_t qraw = *(const unit_t*)((const T*)a.q + (int64_t)r * a.q_ld + h * 64 + cu * UNIT);
-  asm volatile("" ::: "memory");
   // key of round i for this lane: kk_i = (i * WAVES + wave) * KPW + ks; element offset = (k0 + kk_i) * ld,
   // walked with a constant stride and clamped to the last valid key of the split (branch-free loads: a
   // zero-fill else-arm would make the compiler drain vmcnt at every join).  Rounds >= nround are skipped by a
@@ -465,7 +484,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArg
   unit_t ku[NL], vu[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
-    if (!SKIP || i < nround) {
+    if (i < EAG && eager) {
+      ku[i] = ku_e[i];
+    } else if (!SKIP || i < nround) {
       uint32_t o = ok0 + (uint32_t)(i * KPR) * ldk; if (o > okl) o = okl;
       ku[i] = __builtin_nontemporal_load((const unit_t*)(kp + o));
     }

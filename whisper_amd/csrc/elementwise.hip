@@ -197,6 +197,19 @@ __global__ __launch_bounds__(256) void permute_group_kernel(uint4v* __restrict__
 
 __global__ void add_int_kernel(int* p, int v) { *p += v; }
 
+// the first `used_words` 4-byte words of row `src_row` -> rows [dst_row0, dst_row0 + G) of every layer slab
+// (grid.y = layer): prompt positions / prefill logits of a segment's leader row to the rows of its beam group
+__global__ __launch_bounds__(256) void replicate_row_kernel(uint32_t* __restrict__ base, int64_t layer_words, int64_t row_words,
+                                                            int src_row, int dst_row0, int G, int64_t used_words) {
+  uint32_t* slab = base + (int64_t)blockIdx.y * layer_words;
+  const uint32_t* src = slab + (int64_t)src_row * row_words;
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < used_words; u += (int64_t)gridDim.x * 256) {
+    const uint32_t v = src[u];
+    for (int g = 0; g < G; ++g)
+      if (dst_row0 + g != src_row) slab[(int64_t)(dst_row0 + g) * row_words + u] = v;
+  }
+}
+
 }  // namespace
 
 namespace whk {
@@ -276,6 +289,18 @@ hipError_t launch_permute_groups(void* k_base, void* v_base, int n_layers, int64
   hipLaunchKernelGGL(permute_group_kernel<8>, dim3(bx, n_audio, n_layers * 2), dim3(256), 0, stream, (uint4v*)k_base,
                      (uint4v*)v_base, layer_bytes / 16, row_bytes / 16, used_units, src_idx, G, copy_from,
                      (int)(pos_bytes / 16));
+  return hipGetLastError();
+}
+
+hipError_t launch_replicate_row(void* base, int64_t layer_bytes, int n_layers, int64_t row_bytes, int src_row, int dst_row0,
+                                int G, int64_t used_bytes, hipStream_t stream) {
+  if (used_bytes <= 0 || G <= 0) return hipSuccess;
+  if ((layer_bytes | row_bytes | used_bytes) & 3) return hipErrorInvalidValue;
+  const int64_t words = used_bytes / 4;
+  int bx = (int)((words + 255) / 256);
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(replicate_row_kernel, dim3(bx, n_layers), dim3(256), 0, stream, (uint32_t*)base, layer_bytes / 4,
+                     row_bytes / 4, src_row, dst_row0, G, words);
   return hipGetLastError();
 }
 

@@ -63,6 +63,9 @@ hipError_t launch_gather_cache(const void* src, void* dst, const int* src_idx, i
 hipError_t launch_permute_groups(void* k_base, void* v_base, int n_layers, int64_t layer_bytes, int n_audio, int G,
                                  int64_t row_bytes, int64_t used_bytes, const int* src_idx, const int* copy_from,
                                  int64_t pos_bytes, hipStream_t stream);
+// the first used_bytes of row src_row -> rows [dst_row0, dst_row0 + G) in each of n_layers slabs (layer_bytes apart)
+hipError_t launch_replicate_row(void* base, int64_t layer_bytes, int n_layers, int64_t row_bytes, int src_row, int dst_row0,
+                                int G, int64_t used_bytes, hipStream_t stream);
 hipError_t launch_add_int(int* p, int v, hipStream_t stream);
 
 // ---- attention.hip -------------------------------------------------------------------------
@@ -129,9 +132,11 @@ struct XAttnArgs {
   void* part_o; float* part_ml;                   // splits > 1 (layouts of DecAttnArgs)
   // hand-off of q between workgroups: 8-byte granules {2 x fp16, tag} [R][D/2]; tag = ((*d_tick + 1 + epoch) << 6) | (layer + 1)
   unsigned long long* qg; const int* d_tick; int epoch, layer;
-  int* err;                                       // set to 1 when a bounded spin ran out (never on a healthy device)
+  int* err;                                       // counts bounded spins that ran out (never on a healthy device)
+  int mode;                                       // bit 0: scalar-path polls; bit 1: projection requests before K/V (fused_mode())
   WH_PROBE_FIELD
 };
+int fused_mode();
 bool xattn_supported(int D, int H, int R, int kv_group, int Tk, int splits);
 hipError_t launch_xattn8(const XAttnArgs& a, hipStream_t stream);
 // self attention of one decode step with LayerNorm + QKV projection + KV-cache append inside the launch
@@ -145,6 +150,7 @@ struct SAttnArgs {
   void* out; int64_t o_ld;                        // attention output [R][D]
   unsigned long long* qg; const int* d_tick; int epoch, layer;   // granules [R][3D/2]; tag as in XAttnArgs
   int* err;
+  int mode;                                       // bit 0: scalar-path polls
   WH_PROBE_FIELD
 };
 bool sattn_supported(int D, int H, int R, int n_ctx);

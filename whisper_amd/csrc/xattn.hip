@@ -46,11 +46,11 @@ __device__ __forceinline__ float qk_unit8(half8v q, half8v k) {
 // ---- the projection of ONE 8-feature group by 4 auxiliary waves (the MFMA diagonal tile of gemv8_kernel<PRO_LN>) -------
 constexpr int P_NU = 5, P_KS = 4;       // K <= 1280: 20 blocks of 64 = 4 waves x 5 wave-loads
 
-// stage 1 (before the first barrier): request the wave's 5 wave-loads of weights (8 rows x 128 contiguous bytes each,
-// non-temporal; lane l = 16 c + 8 half + i), then LayerNorm rows aw and aw + 4 whole in registers (row-contiguous
-// loads; the affine part is folded into W / bias) and scatter them to LDS in MFMA fragment order
-__device__ __forceinline__ void proj_stage1(int aw, int lane, int g, const void* W, int K, const float* xf, int64_t xf_ld,
-                                            int R, half8v (&wa)[P_NU], half8v* xfrag) {
+// stage 1a: request the wave's 5 wave-loads of weights (8 rows x 128 contiguous bytes each, non-temporal; lane l = 16 c +
+// 8 half + i) and rows aw, aw + 4 of the fp32 residual stream (row-contiguous: a wave-load = 1 KB of one row) — all the
+// memory requests of the projection, issued back to back
+__device__ __forceinline__ void proj_issue(int aw, int lane, int g, const void* W, int K, const float* xf, int64_t xf_ld,
+                                           int R, half8v (&wa)[P_NU], float4v (&v)[2][P_NU]) {
   const int nblk = K >> 6;
   const int idx = lane & 7, koff = ((lane >> 3) & 1) * 32 + (lane >> 4) * 8;
   const uint32_t lane_off = ((uint32_t)(g * 8 + idx) * (uint32_t)K + (uint32_t)koff) * 2u;
@@ -59,9 +59,6 @@ __device__ __forceinline__ void proj_stage1(int aw, int lane, int g, const void*
     int blk = aw + P_KS * u; if (blk > nblk - 1) blk = nblk - 1;          // clamped; masked through x == 0
     wa[u] = __builtin_nontemporal_load((const half8v*)((const char*)W + (size_t)blk * 128 + lane_off));
   }
-  const float invK = 1.0f / (float)K;
-  const uint32_t fbase = (uint32_t)((lane >> 4) * P_NU * 64 + 16 * ((lane >> 1) & 3) + 8 * ((lane >> 3) & 1)) * 16u + (uint32_t)(lane & 1) * 8u;
-  float4v v[2][P_NU];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = aw + 4 * i;
@@ -72,6 +69,13 @@ __device__ __forceinline__ void proj_stage1(int aw, int lane, int g, const void*
       v[i][j] = *(const float4v*)(src + (uint32_t)k * 4u);
     }
   }
+}
+
+// stage 1b: LayerNorm of the two rows whole in registers (the affine part is folded into W / bias) and scatter to LDS
+// in MFMA fragment order
+__device__ __forceinline__ void proj_ln(int aw, int lane, int K, const float4v (&v)[2][P_NU], half8v* xfrag) {
+  const float invK = 1.0f / (float)K;
+  const uint32_t fbase = (uint32_t)((lane >> 4) * P_NU * 64 + 16 * ((lane >> 1) & 3) + 8 * ((lane >> 3) & 1)) * 16u + (uint32_t)(lane & 1) * 8u;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = aw + 4 * i;
@@ -101,6 +105,13 @@ __device__ __forceinline__ void proj_stage1(int aw, int lane, int g, const void*
       *(half4v*)((char*)xfrag + rbase + (uint32_t)(j * 1024)) = o4;
     }
   }
+}
+
+__device__ __forceinline__ void proj_stage1(int aw, int lane, int g, const void* W, int K, const float* xf, int64_t xf_ld,
+                                            int R, half8v (&wa)[P_NU], half8v* xfrag) {
+  float4v v[2][P_NU];
+  proj_issue(aw, lane, g, W, K, xf, xf_ld, R, wa, v);
+  proj_ln(aw, lane, K, v, xfrag);
 }
 
 // stage 2 (between the two barriers): 5 MFMAs against the x fragments, the two meaningful diagonal blocks summed, the
@@ -138,6 +149,43 @@ __device__ __forceinline__ void fetch_granules(const u64* gp, uint32_t tag, int 
   if (lane < 32) dst[lane] = data;
 }
 
+// The same fetch through the SCALAR memory path (mode bit 0).  A CU serves its vector-memory requests in issue order, so
+// a poll issued behind a workgroup's K/V tile (128 KB per workgroup, two workgroups per CU) only returns when that stream
+// has drained — measured: the fused cross attention took exactly as long as its two launches.  s_load goes through the
+// scalar cache's own port to L2; `glc` makes every poll miss the scalar cache.  32 granules = 256 contiguous bytes =
+// four s_load_dwordx16 into 64 SGPRs; the tags are compared on the scalar ALU and lane j picks data dword 2 j.
+typedef int int16s __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void fetch_granules_scalar(const u64* gp, uint32_t tag, int lane, uint32_t* dst, int* err) {
+  const u64* p = gp;                     // wave-uniform by construction (block index, wave index)
+  int16s r0, r1, r2, r3;
+  int spins = 0;
+  for (;;) {
+    asm volatile("s_load_dwordx16 %0, %4, 0x0 glc\n\t"
+                 "s_load_dwordx16 %1, %4, 0x40 glc\n\t"
+                 "s_load_dwordx16 %2, %4, 0x80 glc\n\t"
+                 "s_load_dwordx16 %3, %4, 0xc0 glc\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=s"(r0), "=s"(r1), "=s"(r2), "=s"(r3) : "s"(p) : "memory");
+    bool ok = true;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      ok = ok && (uint32_t)r0[2 * e + 1] == tag && (uint32_t)r1[2 * e + 1] == tag && (uint32_t)r2[2 * e + 1] == tag &&
+           (uint32_t)r3[2 * e + 1] == tag;
+    if (ok) break;
+    if (++spins >= X_MAX_SPINS) { if (lane == 0 && err) atomicAdd(err, 1); break; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  uint32_t val = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    val = lane == e ? (uint32_t)r0[2 * e] : val;
+    val = lane == 8 + e ? (uint32_t)r1[2 * e] : val;
+    val = lane == 16 + e ? (uint32_t)r2[2 * e] : val;
+    val = lane == 24 + e ? (uint32_t)r3[2 * e] : val;
+  }
+  if (lane < 32) dst[lane] = val;
+}
+
 // a pair of fp16 values (this lane's and its xor-1 neighbour's) as one granule, written through to L2 by ONE 8-byte store
 __device__ __forceinline__ void publish_pair(u64* slot, half_t mine_h, int lane, bool even, bool on, uint32_t tag) {
   const uint32_t mine = (uint32_t)__builtin_bit_cast(unsigned short, mine_h);
@@ -161,7 +209,8 @@ __device__ __forceinline__ void publish_pair(u64* slot, half_t mine_h, int lane,
 template <int NL>
 __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
   pin_kernargs(a);
-  constexpr int WAVES = 8;               // KV waves
+  constexpr int WAVES = 8;               // KV waves (waves 4 .. 11); the auxiliary waves are waves 0 .. 3: launched first
+  constexpr int AUX = 4;
   constexpr int KPR = WAVES * 8;         // keys per round
   __shared__ __attribute__((aligned(16))) half8v xfrag[P_KS * P_NU * 64];   // LayerNorm output, 8 rows, MFMA fragment order
   __shared__ float pred[P_KS][8][8];     // producer: [auxiliary wave][feature][row] partial sums
@@ -175,23 +224,30 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
   const int S = a.splits, D = a.D;
   const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   const bool producer = wgid < (D >> 3); // workgroup-uniform: the first D / 8 workgroups (dispatched first)
+  // mode bit 1: in producer workgroups the KV waves hold their K/V requests until the auxiliary waves have issued the
+  // projection's (barrier B0) — a CU serves vector-memory requests in issue order
+  const bool b0 = producer && (a.mode & 2);
   WH_PROBE_AT(a, wgid, 0);
 
-  if (wave >= WAVES) {
+  if (wave < AUX) {
     // ================= auxiliary waves =================
-    const int aw = wave - WAVES;
+    const int aw = wave;
     const int tick = load_uniform_int(a.d_tick);
     const uint32_t tag = ((uint32_t)(tick + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
     if (producer) {
       half8v wa[P_NU];
-      proj_stage1(aw, lane, wgid, a.W, D, a.xf, a.xf_ld, a.R, wa, xfrag);
+      float4v xv[2][P_NU];
+      proj_issue(aw, lane, wgid, a.W, D, a.xf, a.xf_ld, a.R, wa, xv);
+      const float bias = a.bias[wgid * 8 + (lane & 7)];          // requested with the rest, used after the MFMAs
+      if (b0) __syncthreads();                       // B0
+      proj_ln(aw, lane, D, xv, xfrag);
       __syncthreads();                               // B1
       proj_stage2(aw, lane, wa, xfrag, pred);
       __syncthreads();                               // B2
       if (aw == 0) {                                 // 64 outputs: lane = 8 row + feature
         const int er = lane >> 3, ej = lane & 7;
         const int n = wgid * 8 + ej;
-        float val = a.bias[n];
+        float val = bias;
 #pragma unroll
         for (int k = 0; k < P_KS; ++k) val += pred[k][ej][er];
         const half_t qh = (half_t)val;                 // what the two-launch form stores ...
@@ -201,7 +257,11 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
     }
     WH_PROBE_AT(a, wgid, 2);
     // every workgroup: auxiliary wave 0 fetches the q granules of (row r, head h)
-    if (aw == 0) fetch_granules(a.qg + (size_t)r * (D >> 1) + h * 32, tag, lane, qsh, a.err);
+    if (aw == 0) {
+      const u64* gp = a.qg + (size_t)r * (D >> 1) + h * 32;
+      if (a.mode & 1) fetch_granules_scalar(gp, tag, lane, qsh, a.err);
+      else fetch_granules(gp, tag, lane, qsh, a.err);
+    }
     __syncthreads();                                 // B3: q is in LDS
     WH_PROBE_AT(a, wgid, 3);
     __syncthreads();                                 // B4
@@ -210,6 +270,7 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
   }
 
   // ================= KV waves: the whole K / V slice of the split, requested before anything else =================
+  const int kw = wave - AUX;             // KV wave index 0 .. 7
   const int Tk = a.Tk;
   int chunk = (Tk + S - 1) / S;
   chunk = (chunk + KPR - 1) / KPR * KPR;
@@ -217,8 +278,9 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
   int k1 = k0 + chunk; if (k1 > Tk) k1 = Tk;
   const int nkeys = k1 > k0 ? k1 - k0 : 0;
   const int cu = lane & 7, ks = lane >> 3;
-  const int kk0 = wave * 8 + ks;
+  const int kk0 = kw * 8 + ks;
   half8v ku[NL], vu[NL];
+  if (b0) __syncthreads();                           // B0: the projection's requests are out
   {
     const half_t* kp = (const half_t*)a.k + (int64_t)r * a.k_bs + h * 64 + cu * 8;
     const half_t* vp = (const half_t*)a.v + (int64_t)r * a.v_bs + h * 64 + cu * 8;
@@ -257,7 +319,7 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
       mx = fmaxf(mx, sc[i]);
     }
     mx = across_groups8_max(mx);
-    if (lane == 0) redm[wave] = mx;
+    if (lane == 0) redm[kw] = mx;
   }
   __syncthreads();                                   // B4
   mx = redm[0];
@@ -279,21 +341,21 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
   for (int e = 0; e < 8; ++e) acc[e] = across_groups8_sum(acc[e]);
   if (ks == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[wave][cu * 8 + e] = acc[e];
+    for (int e = 0; e < 8; ++e) red[kw][cu * 8 + e] = acc[e];
   }
-  if (lane == 0) reds[wave] = sum;
+  if (lane == 0) reds[kw] = sum;
   __syncthreads();                                   // B5
   WH_PROBE_AT(a, wgid, 4);
-  if (tid < 64) {
-    float o = red[0][tid], l = reds[0];
+  if (kw == 0) {
+    float o = red[0][lane], l = reds[0];
 #pragma unroll
-    for (int w = 1; w < WAVES; ++w) { o += red[w][tid]; l += reds[w]; }
+    for (int w = 1; w < WAVES; ++w) { o += red[w][lane]; l += reds[w]; }
     if (S == 1) {
-      ((half_t*)a.out)[(int64_t)r * a.o_ld + h * 64 + tid] = (half_t)(o / l);
+      ((half_t*)a.out)[(int64_t)r * a.o_ld + h * 64 + lane] = (half_t)(o / l);
     } else {
       const int64_t pi = ((int64_t)s * a.R + r) * a.H + h;
-      ((half_t*)a.part_o)[pi * 64 + tid] = (half_t)(nkeys > 0 ? o / l : 0.f);
-      if (tid == 0) {
+      ((half_t*)a.part_o)[pi * 64 + lane] = (half_t)(nkeys > 0 ? o / l : 0.f);
+      if (lane == 0) {
         a.part_ml[pi * 2 + 0] = nkeys > 0 ? mx : WH_NEG_INF;
         a.part_ml[pi * 2 + 1] = nkeys > 0 ? l : 0.f;
       }
@@ -369,7 +431,11 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
     WH_PROBE_AT(a, wgid, 2);
     if (!consumer) return;
     // consumers: three auxiliary waves fetch the granules of q, new k, new v of (row r, head h)
-    if (aw < 3) fetch_granules(a.qg + (size_t)r * (3 * D >> 1) + aw * (D >> 1) + h * 32, tag, lane, qkv_sh[aw], a.err);
+    if (aw < 3) {
+      const u64* gp = a.qg + (size_t)r * (3 * D >> 1) + aw * (D >> 1) + h * 32;
+      if (a.mode & 1) fetch_granules_scalar(gp, tag, lane, qkv_sh[aw], a.err);
+      else fetch_granules(gp, tag, lane, qkv_sh[aw], a.err);
+    }
     __syncthreads();                                 // B3
     WH_PROBE_AT(a, wgid, 3);
     __syncthreads();                                 // B4
@@ -480,6 +546,14 @@ bool xattn_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("WH_NO_FUSED_XATTN"); v = (e && e[0] == '1') ? 0 : 1; }
   return v == 1;
+}
+
+// developer switch WH_FUSED_MODE (bits): 1 = granules fetched through the scalar memory path, 2 = producer workgroups issue
+// the projection's requests before their K/V requests
+int fused_mode() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("WH_FUSED_MODE"); v = e ? atoi(e) & 3 : 0; }
+  return v;
 }
 
 // the shapes the fused form takes: fp16 (checked by the caller), <= 8 rows, one row per audio, K = D <= 1280 in blocks
