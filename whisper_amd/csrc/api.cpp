@@ -713,7 +713,7 @@ static XAttnArgs xattn_args(const wh_task* t, int l, int epoch) {
   a.v = (char*)cross_layer(t, l) + (size_t)D * m->esize; a.v_ld = 2 * D; a.v_bs = a.k_bs;
   a.Tk = Ta; a.splits = t->cross_splits;
   a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
-  a.qg = t->xq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err; a.mode = fused_mode();
+  a.qg = t->xq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err; a.mode = fused_mode(0);
   return a;
 }
 
@@ -730,7 +730,7 @@ static SAttnArgs sattn_args(const wh_task* t, int l, int epoch) {
   a.kcache = self_k_layer(t, l); a.vcache = self_v_layer(t, l); a.cache_bs = (int64_t)d.n_text_ctx * D;
   a.d_pos = t->d_pos; a.lag = t->d_lag; a.q_out = t->qbuf;
   a.out = t->att; a.o_ld = D;
-  a.qg = t->sq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err; a.mode = fused_mode();
+  a.qg = t->sq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err; a.mode = fused_mode(1);
   return a;
 }
 

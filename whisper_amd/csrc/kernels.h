@@ -133,10 +133,10 @@ struct XAttnArgs {
   // hand-off of q between workgroups: 8-byte granules {2 x fp16, tag} [R][D/2]; tag = ((*d_tick + 1 + epoch) << 6) | (layer + 1)
   unsigned long long* qg; const int* d_tick; int epoch, layer;
   int* err;                                       // counts bounded spins that ran out (never on a healthy device)
-  int mode;                                       // bit 0: scalar-path polls; bit 1: projection requests before K/V (fused_mode())
+  int mode;                                       // bit 0: granules fetched through the scalar memory path (fused_mode())
   WH_PROBE_FIELD
 };
-int fused_mode();
+int fused_mode(int kind);
 bool xattn_supported(int D, int H, int R, int kv_group, int Tk, int splits);
 hipError_t launch_xattn8(const XAttnArgs& a, hipStream_t stream);
 // self attention of one decode step with LayerNorm + QKV projection + KV-cache append inside the launch

@@ -1,30 +1,40 @@
-// xattn.hip — decoder cross attention of one decode step with its query projection INSIDE the launch (fp16, <= 8 rows).
+// xattn.hip — the two attention blocks of one decode step with their LayerNorm + projection INSIDE the launch (fp16, <= 8
+// rows): xattn8_kernel (cross attention) and sattn8_kernel (self attention + KV-cache append).
 //
 // Reference ops: `cross_attn_ln` + `cross_attn.query` (whisper/model.py:39-50, 160-161) and `qkv_attention` over the
-// cached cross K/V at T = 1 (model.py:106-139).  The decode step used to run them as two dependent launches:
-// LN -> query projection (D x D weights, 3.7 us in the chain) and then the K/V stream (61 MB at 8 rows of large-v3,
-// 11.8 us).  The K/V stream does not depend on the query — only the arithmetic after it does — so here every workgroup
-// requests its whole K/V slice at entry (exactly as attn_decode_kernel does) and the projection runs UNDER that stream:
+// cached cross K/V at T = 1 (model.py:106-139); `attn_ln` + `attn.query/key/value` + the cache append (model.py:152-153,
+// 310-341) + the single-query attention over the cache.  The decode step used to run each as two dependent launches
+// (LN -> projection, then attention).  The cross-attention K/V stream (61 MB at 8 rows of large-v3, 11.7 us) does not
+// depend on the query — only the arithmetic after it does — so here every workgroup requests its K/V slice at entry and
+// the projection runs UNDER that stream:
 //
-//   * grid (split, head, row) as before, 12 waves per workgroup: waves 0-7 hold the K/V tile ("KV waves"), waves 8-11
-//     are auxiliary;
+//   * grid (split, head, row) as before, 12 waves per workgroup: waves 0-3 are auxiliary, waves 4-11 hold the K/V tile
+//     ("KV waves");
 //   * the first D / 8 workgroups (dispatched first) are also PRODUCERS: their auxiliary waves compute one 8-feature
 //     group of q for all rows with the MFMA diagonal tile of gemv8_kernel (weights requested first, LayerNorm of two
 //     rows per wave in registers -> fp16 fragments in LDS -> 5 MFMAs -> cross-wave sum -> bias), scale by
 //     d_head^-0.5 (0.125, exact in fp16: model.py:118-121 applies d_head^-0.25 to q and k) and publish the 64 values
 //     as 32 GRANULES: 8-byte {2 x fp16, tag} words written by one write-through (sc1) store each;
-//   * every workgroup's first auxiliary wave polls the 32 granules of its (row, head) — relaxed agent-scope 8-byte loads,
-//     s_sleep between sweeps, bounded — and hands q to the KV waves through LDS and the workgroup barrier.  A granule is
-//     valid when its tag equals this launch's tag, so no flag, fence or counter reset is needed
-//     (MI355X_MICROARCH.md "handoff-1to1": 1-3 us on a streaming consumer CU, paid here under ~10 us of K/V stream).
+//   * every workgroup's first auxiliary wave polls the 32 granules of its (row, head) — bounded — and hands q to the KV
+//     waves through LDS and the workgroup barrier.  A granule is valid when its tag equals this launch's tag, so no flag,
+//     fence or counter reset is needed (MI355X_MICROARCH.md "handoff-1to1").
 //     tag = ((tick + 1 + epoch) << 6) | (layer + 1): `tick` is a device counter bumped once per decode step by the
 //     step's last kernel and never reset, so tags never repeat during the life of a task.
 //
-// Producers never wait for anything, and they are the lowest-numbered workgroups, so consumers cannot starve them of
-// CU slots; every spin is bounded (a timeout sets *err and lets the workgroup finish with whatever q it has).
-// The arithmetic is that of gemv8_kernel<PRO_LN> + attn_decode_kernel<half>; q is bit-identical to the two-launch form,
-// the attention sums the same products with 8 instead of 4 waves' partial sums meeting in LDS (fp32: differences at the
-// 1e-7 level before the fp16 rounding of the output).  WH_NO_FUSED_XATTN=1 selects the two-launch form for A/B.
+// What the GPU taught (profiles/r03_probe_tail_fusion.txt): a CU serves its vector-memory requests in ISSUE ORDER.  With
+// the auxiliary waves behind the KV waves (first version) the projection's loads and the polls sat behind 256 KB of K/V
+// requests per CU and the fused launch took exactly as long as its two halves (15.4 = 11.7 + 3.7 us).  Hence: the
+// auxiliary waves are the FIRST waves of the workgroup (their requests go out ahead of the K/V tile), the bias is
+// requested with the weights, and the cross attention polls through the SCALAR memory path (s_load ... glc: its own port
+// to L2, not queued behind the tile): 13.4 us per launch, and the step loses two launch boundaries per layer
+// (1532 -> ~1460 us per token).
+//
+// Producers never wait for anything and are the lowest-numbered workgroups (cross) / consumers are the highest-numbered
+// (self), so a resident consumer implies dispatched producers; every spin is bounded (a timeout counts in *err and lets
+// the workgroup finish with whatever it has — bench.py and the tests assert the count is 0).
+// q is bit-identical to the two-launch form; the fused self attention is bit-identical altogether; the fused cross
+// attention sums each key range with 8 instead of 4 waves' partial sums (fp32 association only).
+// A/B: WH_NO_FUSED_XATTN=1 / WH_NO_FUSED_SATTN=1 (process) or WH_TASK_TWO_LAUNCH_CROSS / _SELF (per task).
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
@@ -224,9 +234,6 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
   const int S = a.splits, D = a.D;
   const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   const bool producer = wgid < (D >> 3); // workgroup-uniform: the first D / 8 workgroups (dispatched first)
-  // mode bit 1: in producer workgroups the KV waves hold their K/V requests until the auxiliary waves have issued the
-  // projection's (barrier B0) — a CU serves vector-memory requests in issue order
-  const bool b0 = producer && (a.mode & 2);
   WH_PROBE_AT(a, wgid, 0);
 
   if (wave < AUX) {
@@ -239,7 +246,6 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
       float4v xv[2][P_NU];
       proj_issue(aw, lane, wgid, a.W, D, a.xf, a.xf_ld, a.R, wa, xv);
       const float bias = a.bias[wgid * 8 + (lane & 7)];          // requested with the rest, used after the MFMAs
-      if (b0) __syncthreads();                       // B0
       proj_ln(aw, lane, D, xv, xfrag);
       __syncthreads();                               // B1
       proj_stage2(aw, lane, wa, xfrag, pred);
@@ -280,7 +286,6 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
   const int cu = lane & 7, ks = lane >> 3;
   const int kk0 = kw * 8 + ks;
   half8v ku[NL], vu[NL];
-  if (b0) __syncthreads();                           // B0: the projection's requests are out
   {
     const half_t* kp = (const half_t*)a.k + (int64_t)r * a.k_bs + h * 64 + cu * 8;
     const half_t* vp = (const half_t*)a.v + (int64_t)r * a.v_bs + h * 64 + cu * 8;
@@ -548,12 +553,17 @@ bool xattn_enabled() {
   return v == 1;
 }
 
-// developer switch WH_FUSED_MODE (bits): 1 = granules fetched through the scalar memory path, 2 = producer workgroups issue
-// the projection's requests before their K/V requests
-int fused_mode() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("WH_FUSED_MODE"); v = e ? atoi(e) & 3 : 0; }
-  return v;
+// how the granules are fetched: through the scalar memory path (default for the cross attention, whose consumer CUs are
+// saturated with vector-memory requests: 13.4 vs 14.1 us per launch) or with vector loads (default for the self attention:
+// 10.5 vs 10.9 us).  Developer switches: WH_XATTN_VECTOR_POLL=1, WH_SATTN_SCALAR_POLL=1.
+int fused_mode(int kind) {      // kind 0: cross attention, 1: self attention
+  static int v[2] = {-1, -1};
+  if (v[kind] < 0) {
+    const char* e = getenv(kind == 0 ? "WH_XATTN_VECTOR_POLL" : "WH_SATTN_SCALAR_POLL");
+    const bool flip = e && e[0] == '1';
+    v[kind] = kind == 0 ? (flip ? 0 : 1) : (flip ? 1 : 0);
+  }
+  return v[kind];
 }
 
 // the shapes the fused form takes: fp16 (checked by the caller), <= 8 rows, one row per audio, K = D <= 1280 in blocks
