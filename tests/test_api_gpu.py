@@ -286,18 +286,22 @@ def test_transcribe_golden(setup):
                 "no_speech_prob", "words"} <= set(s)
 
 
-@pytest.mark.parametrize("cond", [False, True])
-def test_transcribe_batch_equals_sequential(setup, cond):
+@pytest.mark.parametrize("cond,beam", [(False, None), (True, None), (True, 3)])
+def test_transcribe_batch_equals_sequential(setup, cond, beam):
     """transcribe_batch (lock-step batching over files) must return exactly what transcribe() returns
     file by file — same tokens, seeks, boundaries, word times — for files of different lengths (1, 2 and 3 windows),
-    with and without conditioning on the previous window (with it, prompts diverge and rounds fall back to groups
-    of identical prompts).  fp32 strict engine: the batched and single decodes are compared for exact equality."""
+    with and without conditioning on the previous window (with it, prompts diverge: rows of different prompt lengths
+    share one device-side call, every row at its own positions), greedy and beam search (beam 3: the ragged rows go
+    through wh_task_beam with a lag per segment; the shared-history cache permutation is off there).  fp32 strict
+    engine: the batched and single decodes are compared for exact equality."""
     key, dims, sd, model, mel = setup
     files = [audio(31, 200000), np.concatenate([audio(32), audio(33, 240000)]),
              np.concatenate([audio(34), audio(35), audio(36, 100000)]), audio(37, 480000)]
     kw = dict(temperature=0.0, fp16=False, language="en", sample_len=12, word_timestamps=True,
               condition_on_previous_text=cond, no_speech_threshold=None, logprob_threshold=None,
               compression_ratio_threshold=None)
+    if beam:
+        kw["beam_size"] = beam
     want = [model.transcribe(a, **kw) for a in files]
     got = model.transcribe_batch(files, **kw)
     assert len(got) == len(want)

@@ -9,10 +9,10 @@ import sys
 
 # bench name -> regex on "mangled name grid=(...)" rows (large-v3, 8 clips, fp16)
 PATTERNS = {
-    # round 3: LN + query projection + cross attention in one launch (xattn.hip); the two-launch form otherwise
-    "attn_decode_cross": r"(xattn8_kernel<16>|xattn8_kernelILi16E|attn_decode_kernelIDF16_Li16ELi4ELb0E.*grid=\(768,20,8\))",
-    "attn_decode_self": r"attn_decode_kernelIDF16_Li8ELi8ELb1E.*grid=\(512,20,8\)",
-    # gemv8_kernel<PRO, GS, KS, NU, CSm, XW, NRT> (round 2): LN = 1, PLAIN = 0, COMBINE = 2
+    # round 3: LN + projection + attention in one launch (xattn.hip); the two-launch kernels otherwise
+    "attn_decode_cross": r"(xattn8_kernel<8>|xattn8_kernelILi8E|attn_decode_kernelIDF16_Li16ELi4ELb0E.*grid=\(768,20,8\))",
+    "attn_decode_self": r"(sattn8_kernel|attn_decode_kernelIDF16_Li8ELi8ELb1E.*grid=\(512,20,8\))",
+    # gemv8_kernel<PRO, GS, KS, NU, CSm, XW, NRT>: LN = 1, PLAIN = 0, COMBINE = 2 (qkv / cq only in the two-launch form)
     "gemv_qkv": r"gemv8_kernel<1, 2, 4, 5, 1, 8, 1>",
     "gemv_fc1": r"gemv8_kernel<1, 3, 4, 5, 1, 4, 1>",
     "gemv_fc2": r"gemv8_kernel<0, 1, 16, 5, 1, 0, 1>",
@@ -42,7 +42,7 @@ def main():
         fk = [k for k in fetch if re.search(pat, k)]
         wk = [k for k in write if re.search(pat, k)]
         if not fk or not wk:
-            print(f"no rows for {name}", file=sys.stderr)
+            print(f"no rows for {name} (not launched in this configuration)", file=sys.stderr)
             continue
         fk, wk = max(fk, key=lambda k: fetch[k][1]), max(wk, key=lambda k: write[k][1])
         f_kb, n = fetch[fk]
