@@ -39,6 +39,14 @@
 #include "kernels.h"
 #include <stdlib.h>
 
+// developer probe (tools/probe_fused.cpp, -DWH_PROBE): lane 0 of the calling wave stamps slot `i` of its workgroup's record —
+// slots 0-3 by auxiliary wave 0, slots 4-7 by the first K/V wave
+#ifdef WH_PROBE
+#define XPROBE(args, wg, i) do { if ((args).probe && lane == 0) (args).probe[(size_t)(wg) * 8 + (i)] = clock64(); } while (0)
+#else
+#define XPROBE(args, wg, i) do {} while (0)
+#endif
+
 namespace {
 
 typedef unsigned long long u64;
@@ -234,11 +242,11 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
   const int S = a.splits, D = a.D;
   const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   const bool producer = wgid < (D >> 3); // workgroup-uniform: the first D / 8 workgroups (dispatched first)
-  WH_PROBE_AT(a, wgid, 0);
 
   if (wave < AUX) {
     // ================= auxiliary waves =================
     const int aw = wave;
+    if (aw == 0) XPROBE(a, wgid, 0);
     const int tick = load_uniform_int(a.d_tick);
     const uint32_t tag = ((uint32_t)(tick + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
     if (producer) {
@@ -261,15 +269,15 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
         publish_pair(a.qg + (size_t)er * (D >> 1) + (n >> 1), qsc, lane, (ej & 1) == 0, er < a.R, tag);
       }
     }
-    WH_PROBE_AT(a, wgid, 2);
+    if (aw == 0) XPROBE(a, wgid, 1);                 // producers: published
     // every workgroup: auxiliary wave 0 fetches the q granules of (row r, head h)
     if (aw == 0) {
       const u64* gp = a.qg + (size_t)r * (D >> 1) + h * 32;
       if (a.mode & 1) fetch_granules_scalar(gp, tag, lane, qsh, a.err);
       else fetch_granules(gp, tag, lane, qsh, a.err);
+      XPROBE(a, wgid, 2);                            // q fetched
     }
     __syncthreads();                                 // B3: q is in LDS
-    WH_PROBE_AT(a, wgid, 3);
     __syncthreads();                                 // B4
     __syncthreads();                                 // B5
     return;
@@ -304,12 +312,13 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
       vu[i] = __builtin_nontemporal_load((const half8v*)(vp + o));
     }
   }
-  WH_PROBE_AT(a, wgid, 1);
+  if (kw == 0) XPROBE(a, wgid, 4);                   // K/V requests issued
   if (producer) {
     __syncthreads();                                 // B1
     __syncthreads();                                 // B2
   }
   __syncthreads();                                   // B3: q is in LDS
+  if (kw == 0) XPROBE(a, wgid, 5);
 
   // scores, softmax statistics, p . V (attn_decode_kernel, SKIP = false)
   float sc[NL];
@@ -326,6 +335,7 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
     mx = across_groups8_max(mx);
     if (lane == 0) redm[kw] = mx;
   }
+  if (kw == 0) XPROBE(a, wgid, 6);                   // scores done: the keys have arrived
   __syncthreads();                                   // B4
   mx = redm[0];
 #pragma unroll
@@ -350,7 +360,6 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
   }
   if (lane == 0) reds[kw] = sum;
   __syncthreads();                                   // B5
-  WH_PROBE_AT(a, wgid, 4);
   if (kw == 0) {
     float o = red[0][lane], l = reds[0];
 #pragma unroll
@@ -365,8 +374,8 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
         a.part_ml[pi * 2 + 1] = nkeys > 0 ? l : 0.f;
       }
     }
+    XPROBE(a, wgid, 7);
   }
-  WH_PROBE_AT(a, wgid, 5);
 }
 
 // =====================================================================================================================
@@ -400,11 +409,11 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
   const int cidx = wgid - (nwg - H * R);           // consumer index, >= 0 in the last H * R workgroups
   const bool consumer = cidx >= 0;                 // workgroup-uniform
   const int r = consumer ? cidx / H : 0, h = consumer ? cidx - (cidx / H) * H : 0;
-  WH_PROBE_AT(a, wgid, 0);
 
   if (wave >= WAVES) {
     // ================= auxiliary waves: the projection of feature group `wgid` (every workgroup) =================
     const int aw = wave - WAVES;
+    if (aw == 0) XPROBE(a, wgid, 0);
     const int tick = load_uniform_int(a.d_tick);
     const uint32_t tag = ((uint32_t)(tick + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
     const int vpos = aw == 0 ? load_agent_int(a.d_pos) : 0;           // used by the cache append only
@@ -432,17 +441,17 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
         else ((half_t*)a.vcache)[(int64_t)er * a.cache_bs + pos * D + (n - 2 * D)] = vh;
       }
       publish_pair(a.qg + (size_t)er * (3 * D >> 1) + (n >> 1), pub, lane, (ej & 1) == 0, on, tag);
+      XPROBE(a, wgid, 1);                            // published
     }
-    WH_PROBE_AT(a, wgid, 2);
     if (!consumer) return;
     // consumers: three auxiliary waves fetch the granules of q, new k, new v of (row r, head h)
     if (aw < 3) {
       const u64* gp = a.qg + (size_t)r * (3 * D >> 1) + aw * (D >> 1) + h * 32;
       if (a.mode & 1) fetch_granules_scalar(gp, tag, lane, qkv_sh[aw], a.err);
       else fetch_granules(gp, tag, lane, qkv_sh[aw], a.err);
+      if (aw == 0) XPROBE(a, wgid, 2);               // q fetched
     }
     __syncthreads();                                 // B3
-    WH_PROBE_AT(a, wgid, 3);
     __syncthreads();                                 // B4
     __syncthreads();                                 // B5
     return;
@@ -479,10 +488,11 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
       }
     }
   }
-  WH_PROBE_AT(a, wgid, 1);
+  if (wave == 0) XPROBE(a, wgid, 4);                 // cached K/V requested
   __syncthreads();                                   // B1
   __syncthreads();                                   // B2
   __syncthreads();                                   // B3: q, new k, new v are in LDS
+  if (wave == 0) XPROBE(a, wgid, 5);
 
   float sc[NL];
   float mx = WH_NEG_INF;
@@ -533,14 +543,13 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
   }
   if (lane == 0) reds[wave] = sum;
   __syncthreads();                                   // B5
-  WH_PROBE_AT(a, wgid, 4);
   if (tid < 64) {
     float o = red[0][tid], l = reds[0];
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) { o += red[w][tid]; l += reds[w]; }
     ((half_t*)a.out)[(int64_t)r * a.o_ld + h * 64 + tid] = (half_t)(o / l);
+    XPROBE(a, wgid, 7);
   }
-  WH_PROBE_AT(a, wgid, 5);
 }
 
 }  // namespace
