@@ -111,6 +111,53 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B):
         assert (out.argmax(-1) == plain.argmax(-1)).float().mean().item() > 0.98
 
 
+@pytest.mark.parametrize("B,T0", [(2, 150), (3, 61), (1, 448)])
+def test_prefill_flash_cross_attention(wide, gpu_device, B, T0):
+    """Tasks that keep the cross-attention queries (word timestamps: ~200 teacher-forced tokens per clip) hold a
+    transposed copy of the cross-attention V, and their prefill runs the T0 x 1500 cross attention of every row on the
+    matrix-core flash kernel (the encoder's, with separate query / key counts) instead of the generic one.  fp16 engine at
+    D = 1280: logits of ALL T0 positions against the oracle (6e-2, the engine's bound) and against the same prefill
+    through the generic kernel (a task without the transposed V): 2e-2 / rms 2e-3 — and the captured queries still give
+    the alignment heads' QK (wh_task_cross_qk) as before."""
+    dims, sd, om, models = wide
+    model = models[hip.WH_F16]
+    feats = _feats(dims, B, seed=90 + T0)
+    g = torch.Generator().manual_seed(T0)
+    toks = torch.randint(0, dims.n_vocab, (B, T0), generator=g)
+    with torch.no_grad():
+        want = om.decoder(toks, feats)
+    outs = []
+    for capture in (True, False):
+        task = hip.HipTask(model, B, 1, max(T0, 8), capture_q=capture)
+        try:
+            task.set_audio(feats.to(gpu_device).half().contiguous())
+            outs.append(task.prefill(toks.to(gpu_device).contiguous()).float().cpu())
+            if capture:
+                qk = task.cross_qk(B - 1, [0, 1], [3, 19], 0, T0).cpu()
+                if T0 <= 200:
+                    # the batched alignment core (QK of 20 (layer, head) pairs on the matrix cores -> softmax / z-norm /
+                    # median / head mean) against the single-clip entry points (vector-ALU QK) on the same task
+                    layers, heads = [1] * 20, list(range(20))
+                    frames = [1500 - 100 * i for i in range(B)]
+                    cost, _ = task.align_batch(layers, heads, [T0] * B, frames, 7, 2)
+                    for r in range(B):
+                        one = hip.align_matrix(task.cross_qk(r, layers, heads, 0, T0), frames[r], 7, 2, T0 - 1)
+                        assert (cost[r, :, : frames[r]] - one).abs().max().item() < 2e-3, r
+        finally:
+            task.close()
+    flash, generic = outs
+    assert torch.isfinite(flash).all()
+    assert (flash - want).abs().max().item() < 6e-2
+    d = (flash - generic).abs()
+    assert d.max().item() < 2e-2 and (d.double() ** 2).mean().sqrt().item() < 2e-3, (d.max().item(),)
+    # QK of two (layer, head) pairs for the last row vs the oracle's scores (model.py:118-121 scaling, before softmax)
+    with torch.no_grad():
+        om.decoder(toks[B - 1:], feats[B - 1:], None, keep_qk=True)
+    for i, (l, h) in enumerate(((0, 3), (1, 19))):
+        ref = om.last_qk[l][0, h]
+        assert (qk[i] - ref).abs().max().item() < 5e-2 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("name,B,G", [("base", 20, 1), ("small", 4, 5), ("base", 48, 1)])
 def test_mid_width_steps_many_rows(gpu_device, name, B, G):
     """17..48 rows at D = 512 / 768 (fp16 engine): the 48-row LayerNorm projection (FC1: N >= 2048) and the 48-row logits

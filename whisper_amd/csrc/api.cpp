@@ -341,6 +341,11 @@ static void task_carve(wh_task* t, void* base) {
     const int chunk = (((int)Ta + S - 1) / S + 127) / 128 * 128;       // attn_decode_group_mfma_kernel's key chunk
     t->vt_ld = S * chunk;
     t->cross_vt = c.take(L * t->B * D * (size_t)t->vt_ld * es);
+  } else if ((t->flags & WH_TASK_CAPTURE_Q) && m->dtype == WH_F16) {
+    // word-timestamp tasks teacher-force ~200 tokens per clip: their prefill's cross attention (T0 x 1500 per row) runs
+    // on the matrix-core flash kernel, which wants V transposed as well
+    t->vt_ld = ((int)Ta + 127) / 128 * 128;
+    t->cross_vt = c.take(L * t->B * D * (size_t)t->vt_ld * es);
   }
   t->self_k = c.take(L * R * C * D * es);
   t->self_v = c.take(L * R * C * D * es);
@@ -586,6 +591,10 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
   }
 
   const bool skinny = M <= SKINNY_ROWS && D <= 2048;
+  // one row per audio (alignment tasks; beam search through its leader rows) and a transposed V: flash cross attention
+  static const bool no_flash = [] { const char* e = getenv("WH_NO_PREFILL_FLASH"); return e && e[0] == '1'; }();   // A/B switch
+  const bool flash_cross = !skinny && !no_flash && m->dtype == WH_F16 && t->cross_vt && Gp == 1 && R == t->B &&
+                           t->vt_ld >= (Ta + 63) / 64 * 64;
   HIPCHK(launch_embed(tokens, token_stride, R, T0, m->w.tok_emb, m->w.dec_pos, t->d_pos, nullptr, D, V, t->x, m->dtype, s));
   for (int l = 0; l < d.n_text_layer; ++l) {
     const wh_layer_weights& L = m->dec[l];
@@ -639,6 +648,12 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
       g.W = L.cout_w; g.bias = L.cout_b; g.N = D; g.K = D; g.R = M;
       g.epi = EPI_RESID; g.resid = t->x; g.resid_ld = D;
       HIPCHK(launch_gemv(g, m->dtype, s));
+    } else if (flash_cross) {
+      // T0 queries x 1500 keys per row on the encoder's flash-attention kernel (MFMA; unscaled q / k: it applies
+      // d_head^-0.5 itself): the generic kernel took 1.4 ms per layer for 32 rows x 205 tokens (profiles/r03_kernel_stats_extras.csv)
+      HIPCHK(launch_attn_flash_f16(t->qkv, D, (int64_t)T0 * D, cross_layer(t, l), 2 * D, (int64_t)Ta * 2 * D,
+                                   (char*)t->cross_vt + (size_t)l * t->B * D * t->vt_ld * es, t->vt_ld, (int64_t)D * t->vt_ld,
+                                   t->att, D, (int64_t)T0 * D, R, H, Ta, 0, s, T0));
     } else {
       AttnArgs a; memset(&a, 0, sizeof(a));
       a.q = t->qkv; a.q_ld = D; a.q_bs = (int64_t)T0 * D;

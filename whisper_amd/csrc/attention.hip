@@ -154,7 +154,7 @@ template <bool PRESCALED, bool VTP = true>
 __global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f16_kernel(
     const half_t* __restrict__ q, int64_t q_ld, int64_t q_bs, const half_t* __restrict__ k, int64_t k_ld,
     int64_t k_bs, const half_t* __restrict__ vt, int64_t vt_ld, int64_t vt_bs, half_t* __restrict__ out,
-    int64_t o_ld, int64_t o_bs, int T) {
+    int64_t o_ld, int64_t o_bs, int T, int Tq) {      // T keys, Tq queries (encoder: Tq == T; decoder prefill: T0 x 1500)
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];   // [buf][K | Vt][64 rows x 128 B]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f
   // Q fragments (B operand of S^T = K Q^T): lane (q, hi) holds Q[q][16 s + 8 hi .. +7], s = 0..3
   half8v qf[4];
   {
-    const int qr = qrow < T ? qrow : T - 1;
+    const int qr = qrow < Tq ? qrow : Tq - 1;
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = *(const half8v*)(qp + (int64_t)qr * q_ld + 16 * s + 8 * hi);
   }
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(FW * 64, WH_FLASH_WAVES_PER_SIMD) void attn_flash_f
     l_tot = l_a + l_b;
   }
   const float inv = 1.0f / l_tot;
-  if (qrow < T) {
+  if (qrow < Tq) {
     half_t* op = out + (int64_t)b * o_bs + (int64_t)qrow * o_ld + h * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -873,6 +873,49 @@ __global__ void cross_qk_batch_kernel(const T* __restrict__ qcap, int64_t q_laye
   out[(((int64_t)r * n_pairs + p) * Tmax + t) * Tk + j] = s * SCALE;
 }
 
+// The same score planes on the matrix cores (fp16).  The kernel above re-reads a clip's 1500 keys of a head for every
+// one of the ~200 tokens (100 GB of L2 reads for 8 clips x 320 pairs: 6.4-7.9 ms per launch in
+// profiles/r03_kernel_stats_extras.csv); here a workgroup owns 64 tokens x 128 frames of one (row, pair) plane: each wave
+// keeps its 16 tokens' q as the A operand (2 x 8 halves per lane) and walks 8 sub-tiles of 16 frames, K rows straight from
+// global memory in B-fragment layout (lane = frame, 16 bytes of the head row), two v_mfma_f32_16x16x32_f16 per sub-tile.
+// out[token 4 (lane >> 4) + e][frame lane & 15] = acc[e] * d_head^-0.5: 16 lanes write 64 contiguous bytes of a token row.
+__global__ __launch_bounds__(256) void cross_qk_batch_mfma_kernel(const half_t* __restrict__ qcap, int64_t q_layer_stride,
+                                                                  int64_t q_row_stride, int D, const half_t* __restrict__ cross_kv,
+                                                                  int64_t kv_layer_stride, int64_t kv_audio_stride, int kv_group,
+                                                                  const int* __restrict__ layers, const int* __restrict__ heads,
+                                                                  int n_pairs, const int* __restrict__ ntok, int Tmax, int Tk,
+                                                                  float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.z / n_pairs, p = blockIdx.z - r * n_pairs;
+  const int nt = ntok[r];
+  const int t0 = blockIdx.y * 64 + wave * 16;
+  if (blockIdx.y * 64 >= nt) return;               // workgroup-uniform: token tile beyond this clip
+  const int l = layers[p], head = heads[p];
+  const int tq = t0 + (lane & 15);
+  const half_t* q = qcap + l * q_layer_stride + r * q_row_stride + (int64_t)(tq < nt ? tq : nt - 1) * D + head * 64 + 8 * (lane >> 4);
+  const half8v qa0 = *(const half8v*)q, qa1 = *(const half8v*)(q + 32);
+  const half_t* kbase = cross_kv + l * kv_layer_stride + (r / kv_group) * kv_audio_stride + head * 64 + 8 * (lane >> 4);
+  float* orow = out + (((int64_t)r * n_pairs + p) * Tmax) * Tk;
+  const int j0 = blockIdx.x * 128;
+#pragma unroll 2
+  for (int sub = 0; sub < 8; ++sub) {
+    const int j = j0 + sub * 16 + (lane & 15);
+    if (j0 + sub * 16 >= Tk) break;                // wave-uniform
+    const half_t* kr = kbase + (int64_t)(j < Tk ? j : Tk - 1) * 2 * D;
+    const half8v kb0 = *(const half8v*)kr, kb1 = *(const half8v*)(kr + 32);
+    float4v acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa0, kb0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa1, kb1, acc, 0, 0, 0);
+    if (j < Tk) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int t = t0 + 4 * (lane >> 4) + e;
+        if (t < nt) orow[(int64_t)t * Tk + j] = acc[e] * SCALE;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 namespace whk {
@@ -882,6 +925,13 @@ hipError_t launch_cross_qk_batch(const void* qcap, int64_t q_layer_stride, int64
                                  const int* d_heads, int n_pairs, const int* d_ntok, int R, int Tmax, int Tk, float* out,
                                  int dtype, hipStream_t stream) {
   if ((int64_t)R * n_pairs > 65535) return hipErrorInvalidValue;
+  static const bool valu_qk = [] { const char* e = getenv("WH_QK_VALU"); return e && e[0] == '1'; }();   // A/B switch
+  if (dtype == 1 && !valu_qk && D % 8 == 0) {
+    dim3 mgrid((Tk + 127) / 128, (Tmax + 63) / 64, R * n_pairs);
+    hipLaunchKernelGGL(cross_qk_batch_mfma_kernel, mgrid, dim3(256), 0, stream, (const half_t*)qcap, q_layer_stride, q_row_stride, D,
+                       (const half_t*)cross_kv, kv_layer_stride, kv_audio_stride, kv_group, d_layers, d_heads, n_pairs, d_ntok, Tmax, Tk, out);
+    return hipGetLastError();
+  }
   dim3 grid((Tk + 255) / 256, Tmax, R * n_pairs), block(256);
   if (dtype == 1)
     hipLaunchKernelGGL((cross_qk_batch_kernel<half_t>), grid, block, 0, stream, (const half_t*)qcap, q_layer_stride, q_row_stride, D,
@@ -901,11 +951,13 @@ hipError_t launch_attn_generic(const AttnArgs& a, int batch, int dtype, hipStrea
 
 hipError_t launch_attn_flash_f16(const void* q, int64_t q_ld, int64_t q_bs, const void* k, int64_t k_ld,
                                  int64_t k_bs, const void* vt, int64_t vt_ld, int64_t vt_bs, void* out,
-                                 int64_t o_ld, int64_t o_bs, int B, int H, int T, int prescaled, hipStream_t stream) {
-  dim3 grid((T + FQ - 1) / FQ, H, B), block(FW * 64);
+                                 int64_t o_ld, int64_t o_bs, int B, int H, int T, int prescaled, hipStream_t stream,
+                                 int Tq) {
+  if (Tq <= 0) Tq = T;                               // encoder self attention: as many queries as keys
+  dim3 grid((Tq + FQ - 1) / FQ, H, B), block(FW * 64);
 #define WH_FLASH_LAUNCH(P, V)                                                                                          \
   hipLaunchKernelGGL((attn_flash_f16_kernel<P, V>), grid, block, 0, stream, (const half_t*)q, q_ld, q_bs,              \
-                     (const half_t*)k, k_ld, k_bs, (const half_t*)vt, vt_ld, vt_bs, (half_t*)out, o_ld, o_bs, T)
+                     (const half_t*)k, k_ld, k_bs, (const half_t*)vt, vt_ld, vt_bs, (half_t*)out, o_ld, o_bs, T, Tq)
   // prescaled: bit 0 = q, k carry the softmax scale; bit 1 (tools/probe_gemm only) = plain V^T tile layout in LDS
   switch (prescaled & 3) {
     case 0: WH_FLASH_LAUNCH(false, true); break;

@@ -86,7 +86,7 @@ hipError_t launch_attn_generic(const AttnArgs& a, int batch, int dtype, hipStrea
 // prescaled: q and k each carry sqrt(0.125 * log2 e) already (WH_WEIGHTS_ENC_QK_SCALED)
 hipError_t launch_attn_flash_f16(const void* q, int64_t q_ld, int64_t q_bs, const void* k, int64_t k_ld,
                                  int64_t k_bs, const void* vt, int64_t vt_ld, int64_t vt_bs, void* out,
-                                 int64_t o_ld, int64_t o_bs, int B, int H, int T, int prescaled, hipStream_t stream);
+                                 int64_t o_ld, int64_t o_bs, int B, int H, int T, int prescaled, hipStream_t stream, int Tq = 0);
 // single-query decode attention with split-K partials
 struct DecAttnArgs {
   const void* q; int64_t q_ld;                    // [R][H*64]

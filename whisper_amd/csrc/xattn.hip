@@ -214,10 +214,23 @@ __device__ __forceinline__ void publish_pair(u64* slot, half_t mine_h, int lane,
   }
 }
 
+// barrier among `n_waves_total / per-phase` auxiliary waves through an LDS arrival counter: lane 0 of each wave adds 1 after
+// the wave's own LDS writes (in-order in the LDS pipe; release fence for the compiler), everyone spins until the counter
+// reaches `target` (cumulative over the phases), acquire fence before the reads that follow
+__device__ __forceinline__ void aux_barrier(int* cnt, int target, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  int spins = 0;
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && ++spins < (1 << 20))
+    __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // Both kernels below are written as TWO role bodies under one wave-uniform branch — the KV waves and the auxiliary waves
 // never share a basic block — so that the register allocator sees each role's pressure on its own (the K/V tile of the
 // KV waves is 128 VGPRs; merged control flow carried it through the projection code: 209 VGPRs, one workgroup per CU).
-// Every role executes the same number of s_barrier instructions on every path (counted in the comments: B1 ... B5).
+// Every role executes the same number of s_barrier instructions on every path (counted in the comments: B0 ... B5); the
+// two synchronisation points inside the cross-attention projection are LDS arrival counters among the auxiliary waves.
 
 // 8 KV waves x NL rounds of 64 keys (NL = 4 / 6 / 8: up to 512 keys per split) + 4 auxiliary waves.  The two-launch form
 // holds the same 512 keys in 4 waves x 16 rounds; here the tile must stay live across the hand-off barrier (the compiler
@@ -235,6 +248,7 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t qsh[32];                 // q of this (row, head): 64 fp16, scaled
   __shared__ float red[WAVES][64];
   __shared__ float redm[WAVES], reds[WAVES];
+  __shared__ int aux_cnt;                // arrival counter of the auxiliary waves (producer workgroups)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -242,22 +256,31 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
   const int S = a.splits, D = a.D;
   const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   const bool producer = wgid < (D >> 3); // workgroup-uniform: the first D / 8 workgroups (dispatched first)
+  // Producer workgroups: the two synchronisation points INSIDE the projection involve the 4 auxiliary waves only (an LDS
+  // arrival counter, aux_barrier) — probe_fused showed the K/V waves still issuing their 16 loads 4 us into the launch
+  // (the CU's request queue pushes back), and a workgroup barrier there held the MFMA stage until then: q was published
+  // after 5.9 us instead of ~2.5.  The counter needs a defined start: one workgroup barrier at entry, before any request.
+  if (producer) {
+    if (tid == 0) aux_cnt = 0;
+    __syncthreads();                                 // B0
+  }
 
   if (wave < AUX) {
     // ================= auxiliary waves =================
     const int aw = wave;
     if (aw == 0) XPROBE(a, wgid, 0);
-    const int tick = load_uniform_int(a.d_tick);
-    const uint32_t tag = ((uint32_t)(tick + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
+    const int vtick = load_agent_int(a.d_tick);      // requested first, read (below) behind the projection's requests
+    uint32_t tag;
     if (producer) {
       half8v wa[P_NU];
       float4v xv[2][P_NU];
       proj_issue(aw, lane, wgid, a.W, D, a.xf, a.xf_ld, a.R, wa, xv);
       const float bias = a.bias[wgid * 8 + (lane & 7)];          // requested with the rest, used after the MFMAs
+      tag = ((uint32_t)(uniform(vtick) + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
       proj_ln(aw, lane, D, xv, xfrag);
-      __syncthreads();                               // B1
+      aux_barrier(&aux_cnt, AUX, lane);              // the 4 auxiliary waves only: the K/V waves are still issuing
       proj_stage2(aw, lane, wa, xfrag, pred);
-      __syncthreads();                               // B2
+      aux_barrier(&aux_cnt, 2 * AUX, lane);
       if (aw == 0) {                                 // 64 outputs: lane = 8 row + feature
         const int er = lane >> 3, ej = lane & 7;
         const int n = wgid * 8 + ej;
@@ -268,6 +291,8 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
         const half_t qsc = (half_t)((float)qh * XSCALE);   // ... and what its attention kernel makes of it (exact)
         publish_pair(a.qg + (size_t)er * (D >> 1) + (n >> 1), qsc, lane, (ej & 1) == 0, er < a.R, tag);
       }
+    } else {
+      tag = ((uint32_t)(uniform(vtick) + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
     }
     if (aw == 0) XPROBE(a, wgid, 1);                 // producers: published
     // every workgroup: auxiliary wave 0 fetches the q granules of (row r, head h)
@@ -313,10 +338,6 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
     }
   }
   if (kw == 0) XPROBE(a, wgid, 4);                   // K/V requests issued
-  if (producer) {
-    __syncthreads();                                 // B1
-    __syncthreads();                                 // B2
-  }
   __syncthreads();                                   // B3: q is in LDS
   if (kw == 0) XPROBE(a, wgid, 5);
 
@@ -414,18 +435,22 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
     // ================= auxiliary waves: the projection of feature group `wgid` (every workgroup) =================
     const int aw = wave - WAVES;
     if (aw == 0) XPROBE(a, wgid, 0);
-    const int tick = load_uniform_int(a.d_tick);
-    const uint32_t tag = ((uint32_t)(tick + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
-    const int vpos = aw == 0 ? load_agent_int(a.d_pos) : 0;           // used by the cache append only
+    // everything the epilogue needs is requested here, ahead of the weights: the tick, the position, this lane's bias
+    // and its row's lag (a load issued in the epilogue would be one more dependent L2 round trip at the end)
+    const int vtick = load_agent_int(a.d_tick);
+    const int vpos = load_agent_int(a.d_pos);                         // used by the cache append only
+    const float bias = a.bias[wgid * 8 + (lane & 7)];
+    const int rlag = (a.lag && (lane >> 3) < R) ? a.lag[lane >> 3] : 0;
     half8v wa[P_NU];
     proj_stage1(aw, lane, wgid, a.W, D, a.xf, a.xf_ld, R, wa, xfrag);
+    const uint32_t tag = ((uint32_t)(uniform(vtick) + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
     __syncthreads();                                 // B1
     proj_stage2(aw, lane, wa, xfrag, pred);
     __syncthreads();                                 // B2
     if (aw == 0) {                                   // 64 outputs: lane = 8 row + feature
       const int er = lane >> 3, ej = lane & 7;
       const int n = wgid * 8 + ej;                   // output feature in [0, 3D)
-      float val = a.bias[n];
+      float val = bias;
 #pragma unroll
       for (int k = 0; k < P_KS; ++k) val += pred[k][ej][er];
       const half_t vh = (half_t)val;
@@ -435,7 +460,6 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
         pub = (half_t)((float)vh * XSCALE);          // q: scaled for the attention (exact in fp16)
         if (on && a.q_out) ((half_t*)a.q_out)[(int64_t)er * D + n] = vh;
       } else if (on) {
-        const int rlag = a.lag ? a.lag[er] : 0;
         const int64_t pos = (int64_t)vpos - rlag;
         if (n < 2 * D) ((half_t*)a.kcache)[(int64_t)er * a.cache_bs + pos * D + (n - D)] = vh;
         else ((half_t*)a.vcache)[(int64_t)er * a.cache_bs + pos * D + (n - 2 * D)] = vh;
