@@ -33,7 +33,12 @@ enum {
   WH_ERR_WORKSPACE = 2,  /* workspace too small */
   WH_ERR_HIP = 3,        /* a HIP runtime call failed; see wh_last_hip_error() */
   WH_ERR_STATE = 4,      /* call sequence violation (e.g. step before prefill) */
-  WH_ERR_LIMIT = 5       /* exceeds a compiled-in limit (rows, LDS) */
+  WH_ERR_LIMIT = 5,      /* exceeds a compiled-in limit (rows, LDS) */
+  WH_ERR_HANDOFF = 6     /* a bounded in-kernel hand-off spin of the fused decode-step launches ran out (csrc/xattn.hip):
+                          * the results of the call are NOT valid.  Never seen on a healthy, unshared device; a GPU
+                          * time-sliced between processes may stretch a spin past its bound — create the task with
+                          * WH_TASK_TWO_LAUNCH_SELF | WH_TASK_TWO_LAUNCH_CROSS there.  wh_task_greedy / wh_task_beam check
+                          * the counter before they return; after host-driven wh_task_step calls ask wh_task_info(t, 1). */
 };
 
 /* element type of weights / activations / KV caches. Accumulation is always fp32. */

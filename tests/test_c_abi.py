@@ -32,6 +32,7 @@ def test_status_strings_and_version():
     assert lib.wh_abi_version() == 1
     assert lib.wh_status_string(0) == b"ok"
     assert b"workspace" in lib.wh_status_string(2)
+    assert b"hand-off" in lib.wh_status_string(6) and lib.wh_status_string(99) == b"unknown status"
 
 
 def test_argument_validation_without_gpu():

@@ -35,6 +35,7 @@ extern "C" const char* wh_status_string(int s) {
     case WH_ERR_HIP: return "HIP runtime error";
     case WH_ERR_STATE: return "invalid call sequence";
     case WH_ERR_LIMIT: return "compiled-in limit exceeded";
+    case WH_ERR_HANDOFF: return "in-kernel hand-off timed out (results invalid)";
     default: return "unknown status";
   }
 }
@@ -301,6 +302,7 @@ struct wh_task {
   unsigned long long* xq_gran; int* d_tick; int* d_err;
   unsigned long long* sq_gran;   // the same for self attention + QKV projection (q, new k, new v)
   bool fused_xattn, fused_sattn;
+  int err_seen;                  // hand-off timeouts already reported to a caller
   size_t total;
 };
 
@@ -1010,7 +1012,10 @@ extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* to
     }
   }
   HIPCHK(hipMemcpyAsync(t->h_poll, t->d_alive, 4, hipMemcpyDeviceToHost, s));
+  int* h_err = t->h_poll + t->B + 8;                                               // pinned: past the per-segment flags
+  HIPCHK(hipMemcpyAsync(h_err, t->d_err, 4, hipMemcpyDeviceToHost, s));            // fused launches: hand-off timeouts
   HIPCHK(hipStreamSynchronize(s));
+  if ((t->fused_xattn || t->fused_sattn) && *h_err != t->err_seen) { t->err_seen = *h_err; return WH_ERR_HANDOFF; }
   alive = *t->h_poll;
   (void)done;
   // the sampler that appended token index c ran with ntok == c; "completed" first holds at c = alive + 1
@@ -1142,10 +1147,12 @@ extern "C" int wh_task_beam(wh_task* t, const wh_beam_params* bp, int64_t* token
       pending = true;
     }
   }
-  int applied = 0;
+  int applied = 0, err_now = 0;
   HIPCHK(hipMemcpyAsync(&applied, d_applied, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(&err_now, t->d_err, 4, hipMemcpyDeviceToHost, s));
   if (cur == 1) HIPCHK(hipMemcpyAsync(buf[0], buf[1], (size_t)R * token_stride * 8, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipStreamSynchronize(s));
+  if ((t->fused_xattn || t->fused_sattn) && err_now != t->err_seen) { t->err_seen = err_now; return WH_ERR_HANDOFF; }
   *n_tokens_out = T0 + applied;
   return WH_OK;
 }

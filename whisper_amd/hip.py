@@ -141,6 +141,9 @@ def lib():
     return _LIB
 
 
+WH_ERR_HANDOFF = 6
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         L = lib()
