@@ -149,7 +149,8 @@ enum {
   /* decode step: projection and attention as separate launches even where the fused kernels of csrc/xattn.hip apply
    * (A/B and tests: the results must agree) — for the self attention / for the cross attention */
   WH_TASK_TWO_LAUNCH_SELF = 2,
-  WH_TASK_TWO_LAUNCH_CROSS = 4
+  WH_TASK_TWO_LAUNCH_CROSS = 4,
+  WH_TASK_TWO_LAUNCH_OUT = 8     /* keep attn.out + residual as its own launch behind the fused self-attention launch */
 };
 /* The workspace holds the cross-attention K/V of n_audio segments, the self-attention cache of n_audio * n_group rows
  * and the step buffers.  WH_F16 tasks with n_group > 1 (beam search) additionally hold a transposed copy of the
@@ -193,7 +194,8 @@ int wh_task_set_lag(wh_task *t, const int32_t *lag, void *stream);
 int wh_task_position(const wh_task *t);
 /* Introspection for tests and the benchmark.  what = 0: 1 when this task's decode step runs the cross attention with its
  * LayerNorm + query projection inside the same launch (csrc/xattn.hip: fp16, <= 8 rows, one row per audio), else 0.
- * what = 2: the same question for self attention + QKV projection + cache append (sattn8_kernel).
+ * what = 2: the same question for self attention + QKV projection + cache append (sattn8_kernel); what = 3: that launch
+ * also applies attn.out + the residual add.
  * what = 1: number of bounded hand-off spins that ran out in that kernel since the task was created (always 0 on a
  * healthy device; reads device memory, i.e. synchronises `stream`).  Negative on error. */
 int wh_task_info(wh_task *t, int what, void *stream);

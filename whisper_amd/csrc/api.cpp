@@ -301,7 +301,9 @@ struct wh_task {
   // fused query projection + cross attention (xattn.hip; fp16, <= 8 rows): q granules, the step tick, the error word
   unsigned long long* xq_gran; int* d_tick; int* d_err;
   unsigned long long* sq_gran;   // the same for self attention + QKV projection (q, new k, new v)
-  bool fused_xattn, fused_sattn;
+  unsigned long long* so_gran;   // ... and for the attention outputs handed to attn.out inside the same launch
+  float* x2;                     // second residual-stream buffer: the fused self-attention launch reads x and writes x2 (or back)
+  bool fused_xattn, fused_sattn, fused_out;   // fused_out: attn.out + residual inside the self-attention launch
   int err_seen;                  // hand-off timeouts already reported to a caller
   size_t total;
 };
@@ -379,6 +381,8 @@ static void task_carve(wh_task* t, void* base) {
   t->qcap = (t->flags & WH_TASK_CAPTURE_Q) ? c.take(L * R * C * D * es) : nullptr;
   t->xq_gran = (unsigned long long*)c.take(R * (D / 2) * 8);
   t->sq_gran = (unsigned long long*)c.take(R * (3 * D / 2) * 8);
+  t->so_gran = (unsigned long long*)c.take(R * (D / 2) * 8);
+  t->x2 = (float*)c.take(R * D * 4);
   t->d_tick = (int*)c.take(256);
   t->d_err = t->d_tick + 16;
   t->total = align_up(c.off, 256);
@@ -412,6 +416,10 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
                    xattn_supported(m->d.n_text_state, m->d.n_text_head, t->R, t->G, m->d.n_audio_ctx, t->cross_splits);
   t->fused_sattn = !(flags & WH_TASK_TWO_LAUNCH_SELF) && m->dtype == WH_F16 && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) && t->self_splits == 1 &&
                    sattn_supported(m->d.n_text_state, m->d.n_text_head, t->R, m->d.n_text_ctx);
+  {
+    static const bool no_out = [] { const char* e = getenv("WH_NO_FUSED_OUT"); return e && e[0] == '1'; }();   // A/B switch
+    t->fused_out = t->fused_sattn && !no_out && !(flags & WH_TASK_TWO_LAUNCH_OUT);
+  }
   t->h_lag = (int*)calloc((size_t)t->R, sizeof(int));
   if (!t->h_lag) { delete t; return WH_ERR_ARG; }
   // no device work here: the position counter and the lag array are zeroed by the first wh_task_reset, which the
@@ -440,6 +448,7 @@ extern "C" int wh_task_info(wh_task* t, int what, void* stream) {
   if (!t) return -1;
   if (what == 0) return t->fused_xattn ? 1 : 0;
   if (what == 2) return t->fused_sattn ? 1 : 0;
+  if (what == 3) return t->fused_out ? 1 : 0;
   if (what == 1) {                       // hand-off timeouts of the fused cross attention since the task was created
     if (t->needs_reset) return 0;
     int v = 0;
@@ -465,6 +474,7 @@ static int task_reset_impl(wh_task* t, void* stream_) {
     // only ever counts up afterwards, so tags never repeat while the task lives)
     HIPCHK(hipMemsetAsync(t->xq_gran, 0, (size_t)t->R * (t->m->d.n_text_state / 2) * 8, s));
     HIPCHK(hipMemsetAsync(t->sq_gran, 0, (size_t)t->R * (3 * t->m->d.n_text_state / 2) * 8, s));
+    HIPCHK(hipMemsetAsync(t->so_gran, 0, (size_t)t->R * (t->m->d.n_text_state / 2) * 8, s));
     HIPCHK(hipMemsetAsync(t->d_tick, 0, 256, s));
     if (t->cross_vt)        // pad columns of the transposed cross-attention V: finite forever after (wh_task_set_audio)
       HIPCHK(hipMemsetAsync(t->cross_vt, 0, (size_t)t->m->d.n_text_layer * t->B * t->m->d.n_text_state * t->vt_ld * t->m->esize, s));
@@ -720,13 +730,13 @@ extern "C" int wh_task_prefill(wh_task* t, const int64_t* tokens, int64_t token_
 
 static inline void* cross_layer(const wh_task* t, int l);
 // arguments of the fused LN -> cross query -> cross attention launch of layer l (xattn.hip)
-static XAttnArgs xattn_args(const wh_task* t, int l, int epoch) {
+static XAttnArgs xattn_args(const wh_task* t, int l, int epoch, const float* x_in) {
   const wh_model* m = t->m;
   const wh_dims& d = m->d;
   const int D = d.n_text_state, Ta = d.n_audio_ctx;
   const wh_layer_weights& L = m->dec[l];
   XAttnArgs a; memset(&a, 0, sizeof(a));
-  a.xf = t->x; a.xf_ld = D; a.W = L.cq_w; a.bias = L.cq_b; a.D = D; a.H = d.n_text_head; a.R = t->R;
+  a.xf = x_in; a.xf_ld = D; a.W = L.cq_w; a.bias = L.cq_b; a.D = D; a.H = d.n_text_head; a.R = t->R;
   a.k = cross_layer(t, l); a.k_ld = 2 * D; a.k_bs = (int64_t)Ta * 2 * D;
   a.v = (char*)cross_layer(t, l) + (size_t)D * m->esize; a.v_ld = 2 * D; a.v_bs = a.k_bs;
   a.Tk = Ta; a.splits = t->cross_splits;
@@ -738,13 +748,16 @@ static XAttnArgs xattn_args(const wh_task* t, int l, int epoch) {
 static inline void* self_k_layer(const wh_task* t, int l);
 static inline void* self_v_layer(const wh_task* t, int l);
 // arguments of the fused LN -> QKV -> cache append -> self attention launch of layer l (xattn.hip)
-static SAttnArgs sattn_args(const wh_task* t, int l, int epoch) {
+// x_in: the residual stream the layer starts from; x_out (or null): where x_in + attn.out(attention) goes when the output
+// projection runs inside the same launch
+static SAttnArgs sattn_args(const wh_task* t, int l, int epoch, const float* x_in, float* x_out) {
   const wh_model* m = t->m;
   const wh_dims& d = m->d;
   const int D = d.n_text_state;
   const wh_layer_weights& L = m->dec[l];
   SAttnArgs a; memset(&a, 0, sizeof(a));
-  a.xf = t->x; a.xf_ld = D; a.W = L.qkv_w; a.bias = L.qkv_b; a.D = D; a.H = d.n_text_head; a.R = t->R;
+  a.xf = x_in; a.xf_ld = D; a.W = L.qkv_w; a.bias = L.qkv_b; a.D = D; a.H = d.n_text_head; a.R = t->R;
+  a.out_w = L.out_w; a.out_b = L.out_b; a.x_out = x_out; a.og = t->so_gran;
   a.kcache = self_k_layer(t, l); a.vcache = self_v_layer(t, l); a.cache_bs = (int64_t)d.n_text_ctx * D;
   a.d_pos = t->d_pos; a.lag = t->d_lag; a.q_out = t->qbuf;
   a.out = t->att; a.o_ld = D;
@@ -761,16 +774,22 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
   const size_t es = m->esize;
   if (!embedded)
     HIPCHK(launch_embed(t->step_tokens, 1, R, 1, m->w.tok_emb, m->w.dec_pos, t->d_pos, t->d_lag, D, V, t->x, m->dtype, s));
+  // the residual stream of the step: starts in t->x (embedding / the sampler's x_next); a self-attention launch that also
+  // applies attn.out writes the OTHER buffer (its LayerNorm input is still being read), so the pointer alternates
+  float* xc = t->x;
+  float* xo = t->x2;
   for (int l = 0; l < d.n_text_layer; ++l) {
     const wh_layer_weights& L = m->dec[l];
     GemvArgs g;
+    bool out_done = false;
     if (t->fused_sattn) {
-      // LN -> QKV -> cache append -> self attention as ONE launch (xattn.hip, sattn8_kernel)
-      HIPCHK(launch_sattn8(sattn_args(t, l, 0), s));
+      // LN -> QKV -> cache append -> self attention [-> attn.out + residual] as ONE launch (xattn.hip, sattn8_kernel)
+      HIPCHK(launch_sattn8(sattn_args(t, l, 0, xc, t->fused_out ? xo : nullptr), s));
+      if (t->fused_out) { float* tmp = xc; xc = xo; xo = tmp; out_done = true; }
     } else {
     // LN -> QKV, K/V appended in place at *d_pos
     memset(&g, 0, sizeof(g));
-    g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.attn_ln_w; g.ln_b = L.attn_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
+    g.pro = PRO_LN; g.xf = xc; g.xf_ld = D; g.ln_w = L.attn_ln_w; g.ln_b = L.attn_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
     g.W = L.qkv_w; g.bias = L.qkv_b; g.N = 3 * D; g.K = D; g.R = R;
     g.epi = EPI_QKV; g.y = t->qbuf; g.y_ld = D;
     g.kcache = self_k_layer(t, l); g.vcache = self_v_layer(t, l); g.cache_bs = (int64_t)C * D; g.d_pos = t->d_pos; g.D = D;
@@ -787,6 +806,7 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
       HIPCHK(launch_attn_decode(a, m->dtype, s));
     }
     }
+    if (!out_done) {
     memset(&g, 0, sizeof(g));
     if (t->self_splits > 1) {
       g.pro = PRO_COMBINE; g.part_o = t->part_o; g.part_ml = t->part_ml; g.splits = t->self_splits; g.H = H;
@@ -794,16 +814,17 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
       g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D;
     }
     g.W = L.out_w; g.bias = L.out_b; g.N = D; g.K = D; g.R = R;
-    g.epi = EPI_RESID; g.resid = t->x; g.resid_ld = D;
+    g.epi = EPI_RESID; g.resid = xc; g.resid_ld = D;
     HIPCHK(launch_gemv(g, m->dtype, s));
+    }
     if (t->fused_xattn) {
       // LN -> cross query -> cross attention as ONE launch: the K/V stream starts at kernel entry, the projection runs
       // under it and reaches the K/V waves through tagged granules (xattn.hip)
-      HIPCHK(launch_xattn8(xattn_args(t, l, 0), s));
+      HIPCHK(launch_xattn8(xattn_args(t, l, 0, xc), s));
     } else {
     // LN -> cross query
     memset(&g, 0, sizeof(g));
-    g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.cross_ln_w; g.ln_b = L.cross_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
+    g.pro = PRO_LN; g.xf = xc; g.xf_ld = D; g.ln_w = L.cross_ln_w; g.ln_b = L.cross_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
     g.W = L.cq_w; g.bias = L.cq_b; g.N = D; g.K = D; g.R = R;
     g.epi = EPI_STORE; g.y = t->qbuf; g.y_ld = D;
     HIPCHK(launch_gemv(g, m->dtype, s));
@@ -833,23 +854,23 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
       g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D;
     }
     g.W = L.cout_w; g.bias = L.cout_b; g.N = D; g.K = D; g.R = R;
-    g.epi = EPI_RESID; g.resid = t->x; g.resid_ld = D;
+    g.epi = EPI_RESID; g.resid = xc; g.resid_ld = D;
     HIPCHK(launch_gemv(g, m->dtype, s));
     // LN -> MLP
     memset(&g, 0, sizeof(g));
-    g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.mlp_ln_w; g.ln_b = L.mlp_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
+    g.pro = PRO_LN; g.xf = xc; g.xf_ld = D; g.ln_w = L.mlp_ln_w; g.ln_b = L.mlp_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
     g.W = L.fc1_w; g.bias = L.fc1_b; g.N = 4 * D; g.K = D; g.R = R;
     g.epi = EPI_GELU; g.y = t->h; g.y_ld = 4 * D;
     HIPCHK(launch_gemv(g, m->dtype, s));
     memset(&g, 0, sizeof(g));
     g.pro = PRO_PLAIN; g.x = t->h; g.x_ld = 4 * D;
     g.W = L.fc2_w; g.bias = L.fc2_b; g.N = D; g.K = 4 * D; g.R = R;
-    g.epi = EPI_RESID; g.resid = t->x; g.resid_ld = D;
+    g.epi = EPI_RESID; g.resid = xc; g.resid_ld = D;
     HIPCHK(launch_gemv(g, m->dtype, s));
   }
   {
     GemvArgs g; memset(&g, 0, sizeof(g));
-    g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = m->w.dec_ln_w; g.ln_b = m->w.dec_ln_b;
+    g.pro = PRO_LN; g.xf = xc; g.xf_ld = D; g.ln_w = m->w.dec_ln_w; g.ln_b = m->w.dec_ln_b;
     g.W = m->w.tok_emb; g.bias = nullptr; g.N = V; g.K = D; g.R = R;
     g.epi = EPI_F32; g.y = t->logits; g.y_ld = V;
     g.bump = t->d_pos; g.bump_by = 1;         // the last kernel of the step advances the position counter
@@ -1183,7 +1204,7 @@ static int bench_issue(wh_task* t, int kind, int iters, double* bytes_per_launch
       case 1: if (t->fused_xattn) {
         // the fused launch: the tag of launch i is unique within the graph (epoch = i); one add behind the chain keeps
         // replays apart
-        HIPCHK(launch_xattn8(xattn_args(t, l, i), s));
+        HIPCHK(launch_xattn8(xattn_args(t, l, i, t->x), s));
         if (i == iters - 1) HIPCHK(launch_add_int(t->d_tick, iters, s));
         bytes = (double)t->B * 2.0 * Ta * D * es + (double)D * D * es;
       } else {
@@ -1197,9 +1218,9 @@ static int bench_issue(wh_task* t, int kind, int iters, double* bytes_per_launch
         bytes = (double)t->B * 2.0 * Ta * D * es;
       } break;
       case 2: if (t->fused_sattn) {
-        HIPCHK(launch_sattn8(sattn_args(t, l, i), s));
+        HIPCHK(launch_sattn8(sattn_args(t, l, i, t->x, t->fused_out ? t->x2 : nullptr), s));
         if (i == iters - 1) HIPCHK(launch_add_int(t->d_tick, iters, s));
-        bytes = (double)R * t->pos * 2.0 * D * es + 3.0 * D * D * es;
+        bytes = (double)R * t->pos * 2.0 * D * es + (t->fused_out ? 4.0 : 3.0) * D * D * es;
       } else {
         DecAttnArgs a; memset(&a, 0, sizeof(a));
         a.q = t->qbuf; a.q_ld = D;

@@ -147,7 +147,10 @@ struct SAttnArgs {
   void* kcache; void* vcache; int64_t cache_bs;   // this layer's self K / V [R][n_ctx][D]; row r appends at *d_pos - lag[r]
   const int* d_pos; const int* lag;               // lag may be null
   void* q_out;                                    // optional: the unscaled q rows [R][D] (what the two-launch form leaves)
-  void* out; int64_t o_ld;                        // attention output [R][D]
+  void* out; int64_t o_ld;                        // attention output [R][D] (when x_out is null)
+  // optional third stage, attn.out + residual in the same launch: x_out[r][:] = xf[r][:] + out_w . attention[r] + out_b
+  // (x_out must not alias xf); og = granules [R][D/2] the attention workgroups hand their outputs over in
+  const void* out_w; const float* out_b; float* x_out; unsigned long long* og;
   unsigned long long* qg; const int* d_tick; int epoch, layer;   // granules [R][3D/2]; tag as in XAttnArgs
   int* err;
   int mode;                                       // bit 0: scalar-path polls

@@ -422,6 +422,9 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t qkv_sh[3][32];           // q (scaled), new k, new v of (row, head)
   __shared__ float red[WAVES][64];
   __shared__ float redm[WAVES], reds[WAVES];
+  __shared__ __attribute__((aligned(16))) half8v xfrag2[P_KS * P_NU * 64];  // output projection: attention rows, fragment order
+  __shared__ float pred2[P_KS][8][8];
+  __shared__ int cnt_aux, cnt_out;                 // arrival counters (output-projection workgroups)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -430,6 +433,18 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
   const int cidx = wgid - (nwg - H * R);           // consumer index, >= 0 in the last H * R workgroups
   const bool consumer = cidx >= 0;                 // workgroup-uniform
   const int r = consumer ? cidx / H : 0, h = consumer ? cidx - (cidx / H) * H : 0;
+  // Third stage (x_out != null): `attn.out` + the residual add (model.py:153) in the same launch.  The FIRST D / 8
+  // workgroups — never consumers — use their 8 otherwise idle K/V waves for it: waves 0-3 request the 8 x D weight rows
+  // of feature group `wgid` at entry, waves 4-7 gather the attention output of all rows and heads from the granules the
+  // consumers publish (a.og) into LDS in MFMA fragment order; 5 MFMAs per weight wave, bias + residual, fp32 store into the
+  // OTHER residual buffer (x_out; the launch's own LayerNorm input a.xf is still being read by late workgroups).
+  // Inside these workgroups nothing uses the workgroup barrier after B0: the two groups of waves synchronise through LDS
+  // arrival counters (aux_barrier), so neither waits for the other.
+  const bool out_wg = a.x_out != nullptr && wgid < (D >> 3);
+  if (out_wg) {
+    if (tid == 0) { cnt_aux = 0; cnt_out = 0; }
+    __syncthreads();                               // B0
+  }
 
   if (wave >= WAVES) {
     // ================= auxiliary waves: the projection of feature group `wgid` (every workgroup) =================
@@ -444,9 +459,9 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
     half8v wa[P_NU];
     proj_stage1(aw, lane, wgid, a.W, D, a.xf, a.xf_ld, R, wa, xfrag);
     const uint32_t tag = ((uint32_t)(uniform(vtick) + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
-    __syncthreads();                                 // B1
+    if (out_wg) aux_barrier(&cnt_aux, 4, lane); else __syncthreads();          // B1
     proj_stage2(aw, lane, wa, xfrag, pred);
-    __syncthreads();                                 // B2
+    if (out_wg) aux_barrier(&cnt_aux, 8, lane); else __syncthreads();          // B2
     if (aw == 0) {                                   // 64 outputs: lane = 8 row + feature
       const int er = lane >> 3, ej = lane & 7;
       const int n = wgid * 8 + ej;                   // output feature in [0, 3D)
@@ -481,10 +496,91 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
     return;
   }
 
+  // ================= waves 0-7 of the first D / 8 workgroups: output projection + residual =================
+  if (out_wg) {
+    const int ow = wave;
+    const int vtick = load_agent_int(a.d_tick);
+    half8v wa[P_NU];
+    float e_res = 0.f, e_bias = 0.f;
+    if (ow < 4) {
+      // weight waves: the 8 x D rows of feature group `wgid` of attn.out, requested at entry (lane l = 16 c + 8 half + i)
+      const int nblk = D >> 6;
+      const int idx = lane & 7, koff = ((lane >> 3) & 1) * 32 + (lane >> 4) * 8;
+      const uint32_t lane_off = ((uint32_t)(wgid * 8 + idx) * (uint32_t)D + (uint32_t)koff) * 2u;
+#pragma unroll
+      for (int u = 0; u < P_NU; ++u) {
+        int blk = ow + P_KS * u; if (blk > nblk - 1) blk = nblk - 1;
+        wa[u] = __builtin_nontemporal_load((const half8v*)((const char*)a.out_w + (size_t)blk * 128 + lane_off));
+      }
+      if (ow == 0) {                                 // epilogue operands: lane = 8 row + feature
+        const int er = lane >> 3, n = wgid * 8 + (lane & 7);
+        e_bias = a.out_b[n];
+        e_res = a.xf[(int64_t)(er < R ? er : R - 1) * a.xf_ld + n];
+      }
+    }
+    const uint32_t tag = ((uint32_t)(uniform(vtick) + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
+    if (ow >= 4) {
+      // gather waves: rows 2 g, 2 g + 1.  Their 2 x 160 fragment units are zeroed first (rows >= R and K blocks >= D / 64
+      // stay zero), then every granule {2 fp16 of (row, k), tag} lands as one ds_write_b32 at the fragment position of k:
+      // unit ((k >> 6) % 4) * 5 + (k >> 6) / 4, lane 16 ((k & 31) >> 3) + 8 ((k & 63) >> 5) + row, element k & 7
+      const int g = ow - 4;
+      half8v z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (half_t)0.f;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int idx = lane + 64 * i;               // 0 .. 319
+        const int row = 2 * g + idx / 160, j = idx % 160;
+        xfrag2[(j >> 3) * 64 + (j & 7) * 8 + row] = z;
+      }
+      // no polling while nothing can have been published: wait for this workgroup's own projection (LDS counter)
+      int spins = 0;
+      while (__hip_atomic_load(&cnt_aux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 8 && ++spins < (1 << 20))
+        __builtin_amdgcn_s_sleep(2);
+      const int ngr = D >> 1;                        // granules per row
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = 2 * g + rr;
+        if (row >= R) break;                         // wave-uniform
+        const u64* gp = a.og + (size_t)row * ngr;
+        for (int gi0 = 0; gi0 < ngr; gi0 += 64) {
+          const int gi = gi0 + lane;
+          const bool live = gi < ngr;
+          uint32_t data = 0;
+          int sp = 0;
+          for (;;) {
+            const u64 gv = __hip_atomic_load(gp + (live ? gi : ngr - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            data = (uint32_t)gv;
+            if (__all((uint32_t)(gv >> 32) == tag)) break;
+            if (++sp >= X_MAX_SPINS) { if (lane == 0 && a.err) atomicAdd(a.err, 1); break; }
+            __builtin_amdgcn_s_sleep(8);
+          }
+          if (live) {
+            const int k = 2 * gi, blk = k >> 6;
+            const uint32_t unit = (uint32_t)(((blk & 3) * P_NU + (blk >> 2)) * 64 + 16 * ((k & 31) >> 3) + 8 * ((k & 63) >> 5) + row);
+            *(uint32_t*)((char*)xfrag2 + unit * 16u + (uint32_t)(k & 7) * 2u) = data;
+          }
+        }
+      }
+    }
+    aux_barrier(&cnt_out, 8, lane);                  // fragments of all 8 rows are in LDS
+    if (ow < 4) proj_stage2(ow, lane, wa, xfrag2, pred2);
+    aux_barrier(&cnt_out, 16, lane);
+    if (ow == 0) {
+      const int er = lane >> 3, ej = lane & 7;
+      float v = e_bias;
+#pragma unroll
+      for (int k = 0; k < P_KS; ++k) v += pred2[k][ej][er];
+      if (er < R) a.x_out[(int64_t)er * a.xf_ld + wgid * 8 + ej] = e_res + v;
+      XPROBE(a, wgid, 6);                            // output projection stored
+    }
+    return;
+  }
+
   // ================= KV waves: only in consumer workgroups =================
   if (!consumer) return;                             // (ended waves are not waited for by the barriers of the others)
   const int vpos = load_agent_int(a.d_pos);
   const int vlag = load_agent_int(a.lag ? a.lag + r : a.d_pos);
+  const int vtk = load_agent_int(a.d_tick);          // for the tag of the output granules: requested now, read at the end
   const int cu = lane & 7, ks = lane >> 3;
   const int kk0 = wave * 8 + ks;
   const int Tk = uniform(vpos) + 1 - (a.lag ? uniform(vlag) : 0);     // keys incl. the new one at index Tk - 1
@@ -571,7 +667,13 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
     float o = red[0][tid], l = reds[0];
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) { o += red[w][tid]; l += reds[w]; }
-    ((half_t*)a.out)[(int64_t)r * a.o_ld + h * 64 + tid] = (half_t)(o / l);
+    const half_t ov = (half_t)(o / l);
+    if (a.x_out) {                                   // to the output-projection workgroups of this launch
+      const uint32_t tag2 = ((uint32_t)(vtk + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
+      publish_pair(a.og + (size_t)r * (D >> 1) + h * 32 + (tid >> 1), ov, lane, (tid & 1) == 0, true, tag2);
+    } else {
+      ((half_t*)a.out)[(int64_t)r * a.o_ld + h * 64 + tid] = ov;
+    }
     XPROBE(a, wgid, 7);
   }
 }
