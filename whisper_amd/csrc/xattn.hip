@@ -435,8 +435,8 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
   const int r = consumer ? cidx / H : 0, h = consumer ? cidx - (cidx / H) * H : 0;
   // Third stage (x_out != null): `attn.out` + the residual add (model.py:153) in the same launch.  The FIRST D / 8
   // workgroups — never consumers — use their 8 otherwise idle K/V waves for it: waves 0-3 request the 8 x D weight rows
-  // of feature group `wgid` at entry, waves 4-7 gather the attention output of all rows and heads from the granules the
-  // consumers publish (a.og) into LDS in MFMA fragment order; 5 MFMAs per weight wave, bias + residual, fp32 store into the
+  // of feature group `wgid` at entry, each of the 8 waves gathers the attention output of ONE row (all heads) from the
+  // granules the consumers publish (a.og) into LDS in MFMA fragment order; 5 MFMAs per weight wave, bias + residual, fp32 store into the
   // OTHER residual buffer (x_out; the launch's own LayerNorm input a.xf is still being read by late workgroups).
   // Inside these workgroups nothing uses the workgroup barrier after B0: the two groups of waves synchronise through LDS
   // arrival counters (aux_barrier), so neither waits for the other.
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
 
   // ================= waves 0-7 of the first D / 8 workgroups: output projection + residual =================
   if (out_wg) {
-    const int ow = wave;
+    const int ow = wave;                             // also the attention row this wave gathers
     const int vtick = load_agent_int(a.d_tick);
     half8v wa[P_NU];
     float e_res = 0.f, e_bias = 0.f;
@@ -519,52 +519,60 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
       }
     }
     const uint32_t tag = ((uint32_t)(uniform(vtick) + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
-    if (ow >= 4) {
-      // gather waves: rows 2 g, 2 g + 1.  Their 2 x 160 fragment units are zeroed first (rows >= R and K blocks >= D / 64
-      // stay zero), then every granule {2 fp16 of (row, k), tag} lands as one ds_write_b32 at the fragment position of k:
-      // unit ((k >> 6) % 4) * 5 + (k >> 6) / 4, lane 16 ((k & 31) >> 3) + 8 ((k & 63) >> 5) + row, element k & 7
-      const int g = ow - 4;
+    // ---- every one of the 8 waves gathers ONE attention row (row = wave).  Its 160 fragment units are zeroed first (a row
+    // >= R and K blocks >= D / 64 stay zero), then every granule {2 fp16 of (row, k), tag} lands as one ds_write_b32 at the
+    // fragment position of k: unit ((k >> 6) % 4) * 5 + (k >> 6) / 4, lane 16 ((k & 31) >> 3) + 8 ((k & 63) >> 5) + row,
+    // element k & 7.  The 10 granules of a lane (10 sweeps of 64 over the row) are requested back to back and checked
+    // together: a pass costs one L2 round trip, not ten (the first version polled sweep by sweep: + 9 us per launch).
+    {
       half8v z;
 #pragma unroll
       for (int e = 0; e < 8; ++e) z[e] = (half_t)0.f;
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int idx = lane + 64 * i;               // 0 .. 319
-        const int row = 2 * g + idx / 160, j = idx % 160;
-        xfrag2[(j >> 3) * 64 + (j & 7) * 8 + row] = z;
+      for (int i = 0; i < 3; ++i) {
+        const int j = lane + 64 * i;                 // 0 .. 159: (K-block unit, (c, half) slot)
+        if (j < 160) xfrag2[(j >> 3) * 64 + (j & 7) * 8 + ow] = z;
       }
-      // no polling while nothing can have been published: wait for this workgroup's own projection (LDS counter)
+    }
+    if (ow < R) {                                    // wave-uniform
+      // no polling while nothing can have been published: wait for this workgroup's own projection (LDS counter), then
+      // about as long again — the consumers still have their attention to do
       int spins = 0;
       while (__hip_atomic_load(&cnt_aux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 8 && ++spins < (1 << 20))
         __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(48);
       const int ngr = D >> 1;                        // granules per row
-      for (int rr = 0; rr < 2; ++rr) {
-        const int row = 2 * g + rr;
-        if (row >= R) break;                         // wave-uniform
-        const u64* gp = a.og + (size_t)row * ngr;
-        for (int gi0 = 0; gi0 < ngr; gi0 += 64) {
-          const int gi = gi0 + lane;
-          const bool live = gi < ngr;
-          uint32_t data = 0;
-          int sp = 0;
-          for (;;) {
-            const u64 gv = __hip_atomic_load(gp + (live ? gi : ngr - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            data = (uint32_t)gv;
-            if (__all((uint32_t)(gv >> 32) == tag)) break;
-            if (++sp >= X_MAX_SPINS) { if (lane == 0 && a.err) atomicAdd(a.err, 1); break; }
-            __builtin_amdgcn_s_sleep(8);
-          }
-          if (live) {
-            const int k = 2 * gi, blk = k >> 6;
-            const uint32_t unit = (uint32_t)(((blk & 3) * P_NU + (blk >> 2)) * 64 + 16 * ((k & 31) >> 3) + 8 * ((k & 63) >> 5) + row);
-            *(uint32_t*)((char*)xfrag2 + unit * 16u + (uint32_t)(k & 7) * 2u) = data;
-          }
+      constexpr int NSW = 10;                        // sweeps of 64 granules per row (D <= 1280)
+      const u64* gp = a.og + (size_t)ow * ngr;
+      uint32_t data[NSW];
+      int sp = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < NSW; ++i) {
+          const int gi = i * 64 + lane;
+          const u64 gv = __hip_atomic_load(gp + (gi < ngr ? gi : ngr - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          data[i] = (uint32_t)gv;
+          ok = ok && (gi >= ngr || (uint32_t)(gv >> 32) == tag);
+        }
+        if (__all(ok)) break;
+        if (++sp >= X_MAX_SPINS) { if (lane == 0 && a.err) atomicAdd(a.err, 1); break; }
+        __builtin_amdgcn_s_sleep(4);
+      }
+#pragma unroll
+      for (int i = 0; i < NSW; ++i) {
+        const int gi = i * 64 + lane;
+        if (gi < ngr) {
+          const int k = 2 * gi, blk = k >> 6;
+          const uint32_t unit = (uint32_t)(((blk & 3) * P_NU + (blk >> 2)) * 64 + 16 * ((k & 31) >> 3) + 8 * ((k & 63) >> 5) + ow);
+          *(uint32_t*)((char*)xfrag2 + unit * 16u + (uint32_t)(k & 7) * 2u) = data[i];
         }
       }
     }
     aux_barrier(&cnt_out, 8, lane);                  // fragments of all 8 rows are in LDS
-    if (ow < 4) proj_stage2(ow, lane, wa, xfrag2, pred2);
-    aux_barrier(&cnt_out, 16, lane);
+    if (ow >= 4) return;
+    proj_stage2(ow, lane, wa, xfrag2, pred2);
+    aux_barrier(&cnt_out, 12, lane);                 // the 4 weight waves
     if (ow == 0) {
       const int er = lane >> 3, ej = lane & 7;
       float v = e_bias;
