@@ -71,9 +71,9 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B):
     stream; q / new k / new v handed between workgroups as tagged 8-byte granules).  Against the same step with
     projection and attention as separate launches (WH_TASK_TWO_LAUNCH_*), prefill + 12 steps on the same tokens, ragged
     rows (per-row lag) included:
-      * the fused SELF attention is bit-identical (same products, same order of sums) — with and without the third stage
-        (attn.out + residual add by the otherwise idle waves of the first D / 8 workgroups, attention outputs handed over
-        as granules, result into the second residual buffer);
+      * the fused SELF attention is bit-identical (same products, same order of sums) — also with the experimental third
+        stage (attn.out + residual add by the otherwise idle waves of the first D / 8 workgroups, attention outputs handed
+        over as granules, result into the second residual buffer: correct, but slower than its own launch, off by default);
       * the fused CROSS attention reproduces q bit for bit and sums each key range with 8 instead of 4 waves' partial
         sums: fp32 sums in another order flip the fp16 rounding of an attention output now and then (1 ulp), which the
         later layers and steps carry on — the logits agree at the level of the fp16 engine's own rounding noise
@@ -88,11 +88,11 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B):
     toks = torch.randint(0, dims.n_vocab, (B, T0 + 12), generator=g).to(gpu_device)
     lag = [(3 * i) % 5 for i in range(B)] if B > 1 else None           # ragged prompts: rows sit at their own positions
 
-    def run(two_self, two_cross, two_out=False):
-        task = hip.HipTask(model, B, 1, 8, two_launch_self=two_self, two_launch_cross=two_cross, two_launch_out=two_out)
+    def run(two_self, two_cross, fuse_out=False):
+        task = hip.HipTask(model, B, 1, 8, two_launch_self=two_self, two_launch_cross=two_cross, fuse_out=fuse_out)
         try:
             assert task.fused_self_attention == (not two_self) and task.fused_cross_attention == (not two_cross)
-            assert task.fused_out_projection == (not two_self and not two_out)
+            assert task.fused_out_projection == (not two_self and fuse_out)
             task.set_audio(feats)
             if lag is not None:
                 task.set_lag(lag)
@@ -106,9 +106,9 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B):
 
     plain = run(True, True)
     assert torch.isfinite(plain).all()
-    for two_out in (True, False):        # self attention fused without / with attn.out + residual in the same launch
-        fused_self = run(False, True, two_out)
-        assert torch.equal(fused_self, plain), (two_out, (fused_self - plain).abs().max().item())
+    for fuse_out in (False, True):       # self attention fused without / with attn.out + residual in the same launch
+        fused_self = run(False, True, fuse_out)
+        assert torch.equal(fused_self, plain), (fuse_out, (fused_self - plain).abs().max().item())
     for out in (run(True, False), run(False, False)):                 # fused cross attention alone, and both
         d = (out - plain).abs()
         assert d.max().item() < 2e-2 and (d.double() ** 2).mean().sqrt().item() < 2e-3, (d.max().item(), (d.double() ** 2).mean().sqrt().item())

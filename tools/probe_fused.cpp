@@ -53,6 +53,10 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&bias, (size_t)3 * D * 4)); fill_float(bias, 3 * D, 0.1f);
   CK(hipMalloc(&xg, (size_t)R * (D / 2) * 8)); CK(hipMemset(xg, 0, (size_t)R * (D / 2) * 8));
   CK(hipMalloc(&sg, (size_t)R * (3 * D / 2) * 8)); CK(hipMemset(sg, 0, (size_t)R * (3 * D / 2) * 8));
+  unsigned long long* og; CK(hipMalloc(&og, (size_t)R * (D / 2) * 8)); CK(hipMemset(og, 0, (size_t)R * (D / 2) * 8));
+  half_t* Wo; CK(hipMalloc(&Wo, (size_t)L * D * D * 2)); fill_half(Wo, (size_t)L * D * D, 0.05f);
+  float* x2; CK(hipMalloc(&x2, (size_t)R * D * 4));
+  const bool with_out = getenv("PROBE_NO_OUT") == nullptr;
   CK(hipMalloc(&d_tick, 256)); CK(hipMemset(d_tick, 0, 256)); d_err = d_tick + 16;
   CK(hipMalloc(&d_pos, 256)); CK(hipMemcpy(d_pos, &pos, 4, hipMemcpyHostToDevice));
 
@@ -74,6 +78,7 @@ int main(int argc, char** argv) {
     a.kcache = sk + (size_t)l * R * C * D; a.vcache = sv + (size_t)l * R * C * D; a.cache_bs = (int64_t)C * D;
     a.d_pos = d_pos; a.lag = nullptr; a.q_out = qbuf; a.out = att; a.o_ld = D;
     a.qg = sg; a.d_tick = d_tick; a.epoch = i; a.layer = l; a.err = d_err; a.mode = whk::fused_mode(1);
+    if (with_out) { a.out_w = Wo + (size_t)l * D * D; a.out_b = bias; a.x_out = x2; a.og = og; }
     a.probe = i == N - 1 ? d_probe : nullptr;
     return a;
   };
@@ -150,6 +155,11 @@ int main(int argc, char** argv) {
       printf("    cycles from aux entry (medians): published %lld | q fetched: producer WGs %lld, others %lld | K/V issued %lld | "
              "past hand-off barrier %lld | scores done %lld | stored %lld (max %lld)\n",
              med(pub), med(fetch_p), med(fetch_o), med(kvis), med(bar), med(sco), med(end), end.empty() ? -1 : end.back());
+      if (c.kind == 3 && with_out) {
+        std::vector<long long> outp;
+        for (int w = 0; w < D / 8; ++w) { const long long* q = &p[(size_t)w * 8]; if (q[0] && q[6]) outp.push_back(q[6] - q[0]); }
+        printf("    output projection stored (first D/8 workgroups): median %lld max %lld\n", med(outp), outp.empty() ? -1 : outp.back());
+      }
     }
     CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
   }

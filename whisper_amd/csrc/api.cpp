@@ -417,8 +417,11 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
   t->fused_sattn = !(flags & WH_TASK_TWO_LAUNCH_SELF) && m->dtype == WH_F16 && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) && t->self_splits == 1 &&
                    sattn_supported(m->d.n_text_state, m->d.n_text_head, t->R, m->d.n_text_ctx);
   {
-    static const bool no_out = [] { const char* e = getenv("WH_NO_FUSED_OUT"); return e && e[0] == '1'; }();   // A/B switch
-    t->fused_out = t->fused_sattn && !no_out && !(flags & WH_TASK_TWO_LAUNCH_OUT);
+    // attn.out inside the self-attention launch: built, bit-identical, and slower than its own launch (the gather of 160
+    // (row, head) outputs by the projection workgroups costs ~4 us after the attention, and its polling slows the
+    // projection phase of the same launch): off unless asked for (WH_FUSED_OUT=1 / WH_TASK_FUSE_OUT)
+    static const bool env_out = [] { const char* e = getenv("WH_FUSED_OUT"); return e && e[0] == '1'; }();
+    t->fused_out = t->fused_sattn && (env_out || (flags & WH_TASK_FUSE_OUT));
   }
   t->h_lag = (int*)calloc((size_t)t->R, sizeof(int));
   if (!t->h_lag) { delete t; return WH_ERR_ARG; }

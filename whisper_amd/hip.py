@@ -20,7 +20,7 @@ WH_F32, WH_F16 = 0, 1
 WH_TASK_CAPTURE_Q = 1
 WH_TASK_TWO_LAUNCH_SELF = 2
 WH_TASK_TWO_LAUNCH_CROSS = 4
-WH_TASK_TWO_LAUNCH_OUT = 8
+WH_TASK_FUSE_OUT = 8
 WH_WEIGHTS_DEC_LN_FOLDED = 1
 WH_WEIGHTS_ENC_QK_SCALED = 2
 # sqrt(0.125 * log2 e): with it in both the query and the key projection, K.Q^T is the exp2 argument of the softmax
@@ -489,13 +489,13 @@ class HipTask:
 
     def __init__(self, model: HipModel, n_audio: int, n_group: int, max_prefill: int, capture_q: bool = False,
                  stream: Optional[torch.cuda.Stream] = None, two_launch_self: bool = False, two_launch_cross: bool = False,
-                 two_launch_out: bool = False):
+                 fuse_out: bool = False):
         self.model = model
         self.n_audio, self.n_group, self.n_rows = n_audio, n_group, n_audio * n_group
         self.max_prefill = max_prefill
         self.capture_q = capture_q
         flags = ((WH_TASK_CAPTURE_Q if capture_q else 0) | (WH_TASK_TWO_LAUNCH_SELF if two_launch_self else 0)
-                 | (WH_TASK_TWO_LAUNCH_CROSS if two_launch_cross else 0) | (WH_TASK_TWO_LAUNCH_OUT if two_launch_out else 0))
+                 | (WH_TASK_TWO_LAUNCH_CROSS if two_launch_cross else 0) | (WH_TASK_FUSE_OUT if fuse_out else 0))
         self.stream = stream if stream is not None else model.stream   # independent tasks may run on own streams
         with torch.cuda.device(model.device):
             need = lib().wh_task_workspace_bytes(model.handle, n_audio, n_group, max_prefill, flags)
