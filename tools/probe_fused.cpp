@@ -35,7 +35,8 @@ static void fill_float(float* d, size_t n, float scale) {
 static long long med(std::vector<long long>& v) { if (v.empty()) return -1; std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 
 int main(int argc, char** argv) {
-  const int D = 1280, H = 20, R = 8, L = 8, N = 32, Ta = 1500, C = 448, S = 3;
+  const int D = 1280, H = 20, R = 8, N = 32, Ta = 1500, C = 448, S = 3;
+  const int L = getenv("PROBE_L") ? atoi(getenv("PROBE_L")) : 8;   // distinct layers the chain rotates through (8: 0.5 GB of cross K/V; 32: 2 GB, as the step)
   const int pos = argc > 1 ? atoi(argv[1]) : 112;
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -141,24 +142,34 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(p.data(), d_probe, p.size() * 8, hipMemcpyDeviceToHost));
       const int nprod = c.kind == 1 ? D / 8 : nwg;              // producers: first D/8 (cross) / all (self)
       const int cons0 = c.kind == 1 ? 0 : nwg - H * R;           // consumers: all (cross) / last H*R (self)
-      std::vector<long long> pub, fetch_p, fetch_o, kvis, bar, sco, end;
+      // stamps are wall_clock64() (100 MHz, chip-wide): absolute times from the first workgroup's entry, in microseconds
+      long long t0 = 0;
+      for (int w = 0; w < nwg; ++w) { const long long e = p[(size_t)w * 8]; if (e && (!t0 || e < t0)) t0 = e; }
+      std::vector<long long> ent, pub, fetch, kvis, bar, sco, end;
       for (int w = 0; w < nwg; ++w) {
         const long long* q = &p[(size_t)w * 8];
         if (!q[0]) continue;
-        if (w < nprod && q[1]) pub.push_back(q[1] - q[0]);
-        if (w >= cons0 && q[2]) ((c.kind == 1 && w < nprod) ? fetch_p : fetch_o).push_back(q[2] - q[0]);
-        if (w >= cons0 && q[4]) kvis.push_back(q[4] - q[0]);
-        if (w >= cons0 && q[5]) bar.push_back(q[5] - q[0]);
-        if (w >= cons0 && q[6]) sco.push_back(q[6] - q[0]);
-        if (w >= cons0 && q[7]) end.push_back(q[7] - q[0]);
+        ent.push_back(q[0] - t0);
+        if (w < nprod && q[1]) pub.push_back(q[1] - t0);
+        if (w >= cons0 && q[2]) fetch.push_back(q[2] - t0);
+        if (w >= cons0 && q[4]) kvis.push_back(q[4] - t0);
+        if (w >= cons0 && q[5]) bar.push_back(q[5] - t0);
+        if (w >= cons0 && q[6] && !(c.kind == 3 && with_out && w < D / 8)) sco.push_back(q[6] - t0);
+        if (w >= cons0 && q[7]) end.push_back(q[7] - t0);
       }
-      printf("    cycles from aux entry (medians): published %lld | q fetched: producer WGs %lld, others %lld | K/V issued %lld | "
-             "past hand-off barrier %lld | scores done %lld | stored %lld (max %lld)\n",
-             med(pub), med(fetch_p), med(fetch_o), med(kvis), med(bar), med(sco), med(end), end.empty() ? -1 : end.back());
+      auto row = [&](const char* name, std::vector<long long>& v) {
+        if (v.empty()) return;
+        std::sort(v.begin(), v.end());
+        const size_t n = v.size();
+        printf("    %-26s min %5.2f  p10 %5.2f  median %5.2f  p90 %5.2f  max %5.2f us  (%zu workgroups)\n", name, v[0] * 0.01,
+               v[n / 10] * 0.01, v[n / 2] * 0.01, v[n * 9 / 10] * 0.01, v[n - 1] * 0.01, n);
+      };
+      row("entry", ent); row("q published", pub); row("q fetched", fetch); row("K/V requested", kvis);
+      row("past hand-off barrier", bar); row("scores done", sco); row("stored", end);
       if (c.kind == 3 && with_out) {
         std::vector<long long> outp;
-        for (int w = 0; w < D / 8; ++w) { const long long* q = &p[(size_t)w * 8]; if (q[0] && q[6]) outp.push_back(q[6] - q[0]); }
-        printf("    output projection stored (first D/8 workgroups): median %lld max %lld\n", med(outp), outp.empty() ? -1 : outp.back());
+        for (int w = 0; w < D / 8; ++w) { const long long* q = &p[(size_t)w * 8]; if (q[0] && q[6]) outp.push_back(q[6] - t0); }
+        row("output projection stored", outp);
       }
     }
     CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));

@@ -29,7 +29,8 @@ static void fill_float(float* d, size_t n, float scale) {
 }
 
 int main(int argc, char** argv) {
-  const int D = 1280, H = 20, R = argc > 1 ? atoi(argv[1]) : 8, L = 8, N = 64;
+  const int D = 1280, H = 20, R = argc > 1 ? atoi(argv[1]) : 8, N = 64;
+  const int L = getenv("PROBE_L") ? atoi(getenv("PROBE_L")) : 8;   // distinct layers of weights the chain rotates through (1: cache-resident)
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   long long* d_probe; CK(hipMalloc(&d_probe, 8192 * 8 * 8)); CK(hipMemset(d_probe, 0, 8192 * 8 * 8));
@@ -56,6 +57,7 @@ int main(int argc, char** argv) {
     {"plain->fc2 resid (Dx4D)", whk::PRO_PLAIN, whk::EPI_RESID, D, 4 * D, (size_t)10 * D * D},
   };
   for (const Case& c : cases) for (int variant : {0, 99}) {
+    if (variant == 99 && getenv("PROBE_MFMA_ONLY")) continue;
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     bool ok = true;

@@ -7,6 +7,13 @@ typedef _Float16 half_t;
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+// The decode step's weight stream: every byte is read once per step by one CU -> non-temporal.  -DWH_PLAIN_WEIGHT_LOADS builds
+// the A/B variant with the default cache policy (tools/README.md; profiles/r03_probe_weight_policy.txt).
+#ifdef WH_PLAIN_WEIGHT_LOADS
+#define WH_WEIGHT_LOAD(p) (*(p))
+#else
+#define WH_WEIGHT_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));

@@ -821,7 +821,7 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       int blk = kw + KS * u; if (blk > nblk - 1) blk = nblk - 1;          // wave-uniform; clamped, masked through x == 0
-      wa[u] = __builtin_nontemporal_load((const half8v*)((const char*)a.W + (size_t)blk * 128 + lane_off));
+      wa[u] = WH_WEIGHT_LOAD((const half8v*)((const char*)a.W + (size_t)blk * 128 + lane_off));
     }
     if (PRO == whk::PRO_PLAIN) {
 #pragma unroll

@@ -42,7 +42,7 @@
 // developer probe (tools/probe_fused.cpp, -DWH_PROBE): lane 0 of the calling wave stamps slot `i` of its workgroup's record —
 // slots 0-3 by auxiliary wave 0, slots 4-7 by the first K/V wave
 #ifdef WH_PROBE
-#define XPROBE(args, wg, i) do { if ((args).probe && lane == 0) (args).probe[(size_t)(wg) * 8 + (i)] = clock64(); } while (0)
+#define XPROBE(args, wg, i) do { if ((args).probe && lane == 0) (args).probe[(size_t)(wg) * 8 + (i)] = wall_clock64(); } while (0)   /* 100 MHz, one clock for the whole chip */
 #else
 #define XPROBE(args, wg, i) do {} while (0)
 #endif
@@ -75,7 +75,7 @@ __device__ __forceinline__ void proj_issue(int aw, int lane, int g, const void* 
 #pragma unroll
   for (int u = 0; u < P_NU; ++u) {
     int blk = aw + P_KS * u; if (blk > nblk - 1) blk = nblk - 1;          // clamped; masked through x == 0
-    wa[u] = __builtin_nontemporal_load((const half8v*)((const char*)W + (size_t)blk * 128 + lane_off));
+    wa[u] = WH_WEIGHT_LOAD((const half8v*)((const char*)W + (size_t)blk * 128 + lane_off));
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
