@@ -334,6 +334,24 @@ def main():
             log(f"public API leg: {api_ms:.1f} ms per pass ({api_ms / ms_per_step:.3f} x direct), tokens equal: {same}")
 
             extras = {}
+            # the headline is N = 224 (worst case); N = 64 is the speech-typical length of a 30 s window
+            if N != 64:
+                o64 = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=64, suppress_tokens=[-1, tok.eot])
+
+                def pass64():
+                    return whisper_amd.decode(wmodel, whisper_amd.log_mel_spectrogram(audio, dims.n_mels), o64)
+
+                pass64()
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    pass64()
+                torch.cuda.synchronize(device)
+                ms64 = (time.perf_counter() - t0) / 3 * 1e3
+                extras["greedy_sample_len_64"] = {"clips": B, "steps": 64, "ms_per_pass": round(ms64, 2),
+                                                  "audio_s_per_s": round(B * 30.0 / (ms64 / 1e3), 1),
+                                                  "path": "whisper_amd.decode (public API), log-mel + encoder + 64 forced steps"}
+                log(f"greedy, 64 steps: {ms64:.1f} ms per pass = {B * 30.0 / (ms64 / 1e3):.0f} audio-s/s")
             # BASELINE configs[3] shape: beam search (beam 5) on this GPU's clips, device-side beam loop
             if args.beam >= 2:
                 bopts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=args.beam_steps, beam_size=args.beam,
