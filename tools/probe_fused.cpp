@@ -164,6 +164,20 @@ int main(int argc, char** argv) {
         printf("    %-26s min %5.2f  p10 %5.2f  median %5.2f  p90 %5.2f  max %5.2f us  (%zu workgroups)\n", name, v[0] * 0.01,
                v[n / 10] * 0.01, v[n / 2] * 0.01, v[n * 9 / 10] * 0.01, v[n - 1] * 0.01, n);
       };
+      if (c.kind == 3) {                                          // self attention: publish time by third of the grid
+        for (int part = 0; part < 3; ++part) {
+          std::vector<long long> e3, p3;
+          for (int w = part * (nwg / 3); w < (part + 1) * (nwg / 3); ++w) {
+            const long long* q = &p[(size_t)w * 8];
+            if (!q[0]) continue;
+            e3.push_back(q[0] - t0);
+            if (q[1]) p3.push_back(q[1] - t0);
+          }
+          char nm[64];
+          snprintf(nm, sizeof(nm), "  entry, wg third %d", part); row(nm, e3);
+          snprintf(nm, sizeof(nm), "  published, third %d", part); row(nm, p3);
+        }
+      }
       row("entry", ent); row("q published", pub); row("q fetched", fetch); row("K/V requested", kvis);
       row("past hand-off barrier", bar); row("scores done", sco); row("stored", end);
       if (c.kind == 3 && with_out) {
