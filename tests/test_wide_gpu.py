@@ -64,8 +64,9 @@ def test_wide_prefill_and_steps(wide, gpu_device, dt, tol, B, G, T0):
         task.close()
 
 
-@pytest.mark.parametrize("name,B", [("wide-v3", 8), ("wide-v3", 3), ("wide-v3", 1), ("micro-v3", 8), ("w768", 5)])
-def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B):
+@pytest.mark.parametrize("name,B,T0", [("wide-v3", 8, 7), ("wide-v3", 3, 7), ("wide-v3", 1, 7), ("micro-v3", 8, 7), ("w768", 5, 7),
+                                       ("wide-v3", 8, 436), ("wide-v3", 2, 385)])
+def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B, T0):
     """csrc/xattn.hip: the decode step of <= 8 rows (fp16) runs LayerNorm + QKV projection + cache append + self
     attention as ONE launch and LayerNorm + query projection + cross attention as ONE launch (projection under the K/V
     stream; q / new k / new v handed between workgroups as tagged 8-byte granules).  Against the same step with
@@ -84,12 +85,14 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B):
     model = hip.HipModel(dims, hip.WH_F16, hip.pack_weights(sd, dims, hip.WH_F16, gpu_device))
     feats = _feats(dims, B, seed=40 + B).to(gpu_device).half().contiguous()
     g = torch.Generator().manual_seed(8)
-    T0 = 7
+    # T0 = 436: the 12 steps end at position 447 = n_text_ctx - 1, the last slot of the 7th 64-key round of the fused self
+    # attention (and of the cache); T0 = 385: the steps cross from the 6th into the 7th round
+    assert T0 + 12 <= dims.n_text_ctx
     toks = torch.randint(0, dims.n_vocab, (B, T0 + 12), generator=g).to(gpu_device)
     lag = [(3 * i) % 5 for i in range(B)] if B > 1 else None           # ragged prompts: rows sit at their own positions
 
     def run(two_self, two_cross, fuse_out=False):
-        task = hip.HipTask(model, B, 1, 8, two_launch_self=two_self, two_launch_cross=two_cross, fuse_out=fuse_out)
+        task = hip.HipTask(model, B, 1, max(8, T0), two_launch_self=two_self, two_launch_cross=two_cross, fuse_out=fuse_out)
         try:
             assert task.fused_self_attention == (not two_self) and task.fused_cross_attention == (not two_cross)
             assert task.fused_out_projection == (not two_self and fuse_out)
