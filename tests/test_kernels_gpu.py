@@ -190,6 +190,59 @@ def test_fused_greedy(micro, gpu_device, name, with_ts):
         task.close()
 
 
+def test_fused_greedy_to_the_end_of_the_context(micro, gpu_device):
+    """Maximum size: EOT suppressed and sample_len = n_text_ctx - prompt, so the loop runs until the token row is full
+    (decoding.py:699-705 stops at `tokens.shape[-1] > n_ctx`).  fp32 engine vs the oracle: the same number of tokens and
+    the same ids over all 445 steps, 2 rows; the fp16 engine (fused step kernels: the last cache slot, the last key round)
+    runs the same loop to the same length without a hand-off timeout, starts like the fp32 engine and samples allowed ids only."""
+    dims, sd, om, models = micro["micro-v3"]
+    B = 2
+    init = [50258, 50259, 50258 + 1 + (dims.n_vocab - 51765 - 1) + 1]
+    T0 = len(init)
+    n_steps = dims.n_text_ctx - T0
+    r0 = _rules(dims, T0, True)
+    rules = oracle.SamplingRules(sample_begin=T0, sot_index=0, eot=r0.eot, n_ctx=dims.n_text_ctx, timestamp_begin=r0.timestamp_begin,
+                                 no_timestamps=r0.no_timestamps, max_initial_timestamp_index=50, suppress_blank=True,
+                                 blank_token=220, suppress_tokens=sorted(set(list(r0.suppress_tokens) + [r0.eot])),
+                                 no_speech=r0.no_speech)
+    feats = _feats(om, dims, B, seed=23)
+    want = oracle.greedy_decode(om, feats, init, n_steps, rules)
+    assert want["tokens"].shape[1] == dims.n_text_ctx
+    mask = torch.zeros(dims.n_vocab, dtype=torch.uint8)
+    mask[rules.suppress_tokens] = 1
+    mask = mask.to(gpu_device)
+    got = {}
+    for dt in (hip.WH_F32, hip.WH_F16):
+        task = hip.HipTask(models[dt], B, 1, 8)
+        try:
+            task.set_audio(feats.to(gpu_device, torch.float16 if dt == hip.WH_F16 else torch.float32).contiguous())
+            tokens = torch.zeros(B, T0 + n_steps + 1, dtype=torch.int64, device=gpu_device)
+            tokens[:, :T0] = torch.tensor(init)
+            p = hip.GreedyParams(sample_begin=T0, max_steps=n_steps, n_ctx=dims.n_text_ctx, eot=rules.eot,
+                                 timestamp_begin=rules.timestamp_begin, no_timestamps=rules.no_timestamps,
+                                 max_initial_timestamp_index=50, suppress_blank=1, blank_token=220, suppress_mask=mask.data_ptr())
+            n, sum_lp, nsp = task.greedy(tokens, p, 0, rules.no_speech)
+            torch.cuda.synchronize()
+            assert n == dims.n_text_ctx, n
+            assert task.handoff_timeouts() == 0
+            got[dt] = tokens[:, :n].cpu()
+            # the cache holds n - 1 positions (the last sampled token has not been fed): one more step fills the last slot,
+            # the one after it is refused, not written out of bounds
+            assert task.position == dims.n_text_ctx - 1
+            assert torch.isfinite(task.step(tokens[:, n - 1].contiguous())).all()
+            with pytest.raises(hip.HipError):
+                task.step(tokens[:, n - 1].contiguous())
+        finally:
+            task.close()
+    assert torch.equal(got[hip.WH_F32], want["tokens"])
+    # random weights: the logits are nearly flat, so the fp16 engine leaves the fp32 path at its first flipped near-tie
+    # (parity of the fp16 engine is tests/test_wide_gpu.py's subject); here: same start, and every sampled id is allowed
+    g16 = got[hip.WH_F16]
+    assert torch.equal(g16[:, :T0 + 4], got[hip.WH_F32][:, :T0 + 4])
+    assert int(g16.min()) >= 0 and int(g16.max()) < dims.n_vocab
+    assert not bool(torch.isin(g16[:, T0:], torch.tensor(rules.suppress_tokens)).any())
+
+
 @pytest.mark.parametrize("shape", [(10,), (1, 15), (4, 5, 345), (6, 12, 240, 512)])
 def test_median_filter(gpu_device, shape):
     """shapes and widths of the reference's tests/test_timing.py:14-19,67-84; exact (order statistics)."""
