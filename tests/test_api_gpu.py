@@ -286,6 +286,39 @@ def test_transcribe_golden(setup):
                 "no_speech_prob", "words"} <= set(s)
 
 
+E = np.load(os.path.join(os.path.dirname(__file__), "golden", "edge_cases.npz"))
+EDGE = {
+    "empty": lambda: np.zeros(0, dtype=np.float32),
+    "short": lambda: audio(31, 4960),
+    "tail": lambda: audio(32, 16000 * 31),
+    "silence": lambda: np.zeros(16000 * 12, dtype=np.float32),
+}
+
+
+@pytest.mark.parametrize("case", list(EDGE))
+def test_transcribe_edge_cases(setup, case):
+    """model.transcribe() on degenerate inputs against the LIVE reference (tests/golden/make_golden_edge.py): no samples at
+    all (no window, no segment), 0.31 s of signal, a 31 s clip whose second window is a 1 s tail, 12 s of zeros.  fp32
+    engine: segment count, token ids, seeks and bounds exact; no_speech_prob / avg_logprob to 1e-3."""
+    key, dims, sd, model, mel = setup
+    r = model.transcribe(EDGE[case](), temperature=0.0, fp16=False, language="en", sample_len=12,
+                         condition_on_previous_text=True)
+    p = f"{key}_{case}"
+    assert set(r) == {"text", "segments", "language"}
+    assert len(r["segments"]) == int(E[p + "_n_segments"][0])
+    assert [t for s in r["segments"] for t in s["tokens"]] == E[p + "_tokens"].tolist()
+    assert len(r["text"]) == int(E[p + "_text_len"][0])
+    if r["segments"]:
+        bounds = np.array([[s["seek"], s["start"], s["end"]] for s in r["segments"]])
+        assert np.array_equal(bounds[:, 0], E[p + "_bounds"][:, 0])
+        assert np.abs(bounds[:, 1:] - E[p + "_bounds"][:, 1:]).max() < 1e-6
+        stats = np.array([[s["no_speech_prob"], s["avg_logprob"]] for s in r["segments"]])
+        assert np.abs(stats - E[p + "_stats"]).max() < 1e-3
+    if case == "empty" and model.is_multilingual:       # language detection on a window that is all padding
+        r2 = model.transcribe(np.zeros(0, dtype=np.float32), temperature=0.0, fp16=False, sample_len=4)
+        assert r2["language"] == str(E[f"{key}_empty_detected_language"][0]) and r2["segments"] == []
+
+
 @pytest.mark.parametrize("cond,beam", [(False, None), (True, None), (True, 3)])
 def test_transcribe_batch_equals_sequential(setup, cond, beam):
     """transcribe_batch (lock-step batching over files) must return exactly what transcribe() returns
