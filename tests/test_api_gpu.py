@@ -352,6 +352,24 @@ def test_transcribe_batch_equals_sequential(setup, cond, beam):
     assert n_windows >= 6
 
 
+def test_transcribe_batch_with_degenerate_files(setup):
+    """transcribe_batch over a list that mixes an EMPTY clip, a 0.31 s clip, silence and a two-window file (default
+    thresholds on: the no-speech / log-prob branches and the temperature ladder are live): every file's result equals its
+    own transcribe() — the empty file contributes no window and leaves the lock-step schedule of the others untouched."""
+    key, dims, sd, model, mel = setup
+    files = [EDGE["empty"](), EDGE["short"](), EDGE["silence"](), EDGE["tail"](), EDGE["empty"]()]
+    kw = dict(temperature=0.0, fp16=False, language="en", sample_len=12, condition_on_previous_text=True)
+    want = [model.transcribe(a, **kw) for a in files]
+    got = model.transcribe_batch(files, **kw)
+    assert len(got) == len(want) == 5
+    for g, w in zip(got, want):
+        assert g["language"] == w["language"] and g["text"] == w["text"]
+        assert [s["tokens"] for s in g["segments"]] == [s["tokens"] for s in w["segments"]]
+        assert [(s["seek"], s["start"], s["end"]) for s in g["segments"]] == [(s["seek"], s["start"], s["end"]) for s in w["segments"]]
+    assert got[0]["segments"] == [] and got[4]["segments"] == [] and got[0]["text"] == ""
+    assert model.transcribe_batch([], **kw) == []
+
+
 def test_temperature_fallback_runs_sampling_path(setup):
     """transcribe.py:184-224: a window whose greedy result trips the log-prob threshold is re-decoded at the next
     temperature (sampling, drawn on the device); best_of > 1 exercises the grouped rows."""
