@@ -35,9 +35,11 @@ def micro(gpu_device):
 
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n_mels", [80, 128])
-@pytest.mark.parametrize("shape", [(1, 480000), (2, 160000), (1, 16000 * 7 + 80)])
+@pytest.mark.parametrize("shape", [(1, 480000), (2, 160000), (1, 16000 * 7 + 80), (3, 640), (1, 201), (1, 16000 * 95 + 7)])
 def test_log_mel(gpu_device, n_mels, shape):
-    """fp32; atol 1e-4 (restatement-vs-torch.stft noise is 5.8e-5)."""
+    """fp32; atol 1e-4 (restatement-vs-torch.stft noise is 5.8e-5).  Sizes: one 30 s window, ragged
+    frame counts (1000 and 700 frames against 16 frames per workgroup), 4 frames, the shortest input reflect padding
+    accepts (201 samples: one frame, every tap reflected), and a 95 s file (9500 frames, global maximum over 594 workgroups)."""
     B, n = shape
     a = np.stack([_audio(10 + b, n) for b in range(B)])
     filt = oracle.mel_filterbank(n_mels)
