@@ -179,6 +179,33 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(whk::GemmArgs p
   OutT* C = (OutT*)p.C + bz * p.c_bs;
   const float* R = p.res ? p.res + bz * p.r_bs : nullptr;
   const bool vec_ok = ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0);
+  if (vec_ok && R && p.act == 0 && n0 + BN <= p.N && !p.serial_epilogue) {
+    // Residual GEMMs whose tile lies inside N (`attn.out`, `mlp.2`: N = 1280): branch-free, the four float4 of a 16-row band
+    // requested together before any is added (two bands at once spill at the 128 VGPRs of a 16-wave workgroup).  The general loop below asks for one
+    // float4, waits, stores, 16 times over — 16 (here: 4) dependent HBM round trips per wave at the moment every CU of a single-
+    // round GEMM is in its epilogue: 16 of the 55 us of `attn.out`.  Rows beyond M re-read row M - 1 and store nothing.
+#pragma unroll
+    for (int tm = 0; tm < FM; ++tm) {
+      const int m = m0 + wm * (FM * 16) + tm * 16 + (lane & 15);
+      const int mc = m < p.M ? m : p.M - 1;
+      const int rm = (p.res_mod > 0) ? (mc % p.res_mod) : mc;
+      const float* rrow = R + (int64_t)rm * p.ldr + n0 + wn * (FN * 16) + (lane >> 4) * 4;
+      float4v r4[FN];
+#pragma unroll
+      for (int tn = 0; tn < FN; ++tn) r4[tn] = *(const float4v*)(rrow + tn * 16);
+      const float bm = bmpre[tm];
+      OutT* crow = C + (int64_t)m * p.ldc + n0 + wn * (FN * 16) + (lane >> 4) * 4;
+#pragma unroll
+      for (int tn = 0; tn < FN; ++tn) {
+        float4v v = acc[tn][tm];
+        v += bpre[tn];
+        v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
+        v += r4[tn];
+        if (m < p.M) Out4<OutT>::store(crow + tn * 16, v);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int tm = 0; tm < FM; ++tm) {
     const int m = m0 + wm * (FM * 16) + tm * 16 + (lane & 15);
@@ -526,6 +553,7 @@ hipError_t launch_shape(const whk::GemmArgs& a, int batch, hipStream_t stream) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
+  { const char* e = getenv("WH_GEMM_SERIAL_EPILOGUE"); p.serial_epilogue = (e && e[0] == '1') ? 1 : 0; }   // A/B switch
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
   hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, WGM, WGN>), grid, dim3(WGM * WGN * 64), LDS, stream, p);
   return hipGetLastError();

@@ -33,6 +33,7 @@ struct GemmArgs {
   int act;                                      // 0 none, 1 exact GELU
   int M, N, K;
   int tiles_m, tiles_n, persistent;             // filled by the launcher
+  int serial_epilogue;                          // filled by the launcher: A/B switch WH_GEMM_SERIAL_EPILOGUE=1 (gemm.hip)
   WH_PROBE_FIELD
 };
 hipError_t launch_gemm(const GemmArgs& a, int dtype, int out_f32, int batch, hipStream_t stream);
