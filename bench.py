@@ -305,7 +305,8 @@ def main():
                            "step_frac": round(step["GBps"] / HBM_PEAK_GBS, 4), "step_avg_us": step["avg_us"],
                            "step_bytes": step["bytes"], "all_kernels": kern}
     if rank == 0:
-        out["handoff_timeouts"] = task.handoff_timeouts()      # fused cross attention: bounded spins that ran out (must be 0)
+        out["handoff_timeouts"] = task.handoff_timeouts()      # fused step kernels: bounded spins that ran out (must be 0)
+        out["handoff_fallbacks"] = task.handoff_fallbacks      # loops re-run on the two-launch kernels because of them (must be 0)
     task.close()
 
     # ---- the same workload through the public drop-in surface ----------------------------------------------------

@@ -36,9 +36,12 @@ enum {
   WH_ERR_LIMIT = 5,      /* exceeds a compiled-in limit (rows, LDS) */
   WH_ERR_HANDOFF = 6     /* a bounded in-kernel hand-off spin of the fused decode-step launches ran out (csrc/xattn.hip):
                           * the results of the call are NOT valid.  Never seen on a healthy, unshared device; a GPU
-                          * time-sliced between processes may stretch a spin past its bound — create the task with
-                          * WH_TASK_TWO_LAUNCH_SELF | WH_TASK_TWO_LAUNCH_CROSS there.  wh_task_greedy / wh_task_beam check
-                          * the counter before they return; after host-driven wh_task_step calls ask wh_task_info(t, 1). */
+                          * time-sliced between processes may stretch a spin past its bound.  wh_task_greedy /
+                          * wh_task_beam do not return it: they check the counter before they return, and on a time-out
+                          * move the task to the two-launch kernels for good (which wait for nothing) and re-run the loop
+                          * from the prompt (wh_task_info(t, 4) counts these re-runs).  After host-driven wh_task_step
+                          * calls ask wh_task_info(t, 1); create the task with WH_TASK_TWO_LAUNCH_SELF |
+                          * WH_TASK_TWO_LAUNCH_CROSS to stay off the fused kernels from the start. */
 };
 
 /* element type of weights / activations / KV caches. Accumulation is always fp32. */
@@ -199,7 +202,9 @@ int wh_task_position(const wh_task *t);
  * what = 2: the same question for self attention + QKV projection + cache append (sattn8_kernel); what = 3: that launch
  * also applies attn.out + the residual add.
  * what = 1: number of bounded hand-off spins that ran out in that kernel since the task was created (always 0 on a
- * healthy device; reads device memory, i.e. synchronises `stream`).  Negative on error. */
+ * healthy device; reads device memory, i.e. synchronises `stream`).  what = 4: number of times wh_task_greedy /
+ * wh_task_beam re-ran a loop on the two-launch kernels after such a time-out (the answers to 0, 2, 3 are 0 from then on).
+ * Negative on error. */
 int wh_task_info(wh_task *t, int what, void *stream);
 
 /*

@@ -527,6 +527,28 @@ def test_device_beam_search_equals_host_loop(setup, gpu_device, kw):
         assert np.allclose([v for d in ff for v in d.values()], [v for d in hf for v in d.values()], atol=1e-4)
 
 
+def test_beam_search_survives_a_handoff_timeout(setup, gpu_device, monkeypatch):
+    """2 clips x beam 4 = 8 rows in the fp16 engine: the step runs the fused self-attention launch.  With every hand-off
+    forced to time out (WH_HANDOFF_TEST_TIMEOUT=1, fresh task) wh_task_beam re-runs the search on the two-launch kernels
+    inside the call; decode() returns what it returns without the time-outs (the fused self attention is bit-identical
+    to the two-launch form, so ids and scores agree exactly)."""
+    key, dims, sd, model, mel = setup
+    mels = _prompted_mels(dims, gpu_device, 2)
+    opts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=12, beam_size=4)
+    eng = model.engine(torch.float16)
+    eng.drop_cached_tasks()
+    want = whisper_amd.decode(model, mels, opts)
+    eng.drop_cached_tasks()                                  # the next task captures its step graph with the test bit
+    monkeypatch.setenv("WH_HANDOFF_TEST_TIMEOUT", "1")
+    got = whisper_amd.decode(model, mels, opts)
+    monkeypatch.delenv("WH_HANDOFF_TEST_TIMEOUT")
+    cached = [t for t in eng._task_cache if t.n_rows == 8]
+    assert cached and cached[-1].handoff_fallbacks == 1 and not cached[-1].fused_self_attention
+    eng.drop_cached_tasks()
+    for g, w in zip(got, want):
+        assert g.tokens == w.tokens and g.avg_logprob == w.avg_logprob and g.no_speech_prob == w.no_speech_prob
+
+
 def test_device_sampling(setup, gpu_device):
     """Temperature sampling inside the fused loop (GreedyDecoder.update at T > 0, decoding.py:281-293; SURVEY.md §8f
     rank 2).  The reference draws from torch's generator, so parity is distributional:

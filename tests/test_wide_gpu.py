@@ -118,6 +118,55 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B, T0):
         assert (out.argmax(-1) == plain.argmax(-1)).float().mean().item() > 0.98
 
 
+def test_handoff_timeout_falls_back_to_two_launch_kernels(gpu_device, monkeypatch):
+    """A hand-off spin that runs out (forced here: WH_HANDOFF_TEST_TIMEOUT=1 lets every consumer give up after its first
+    poll) must not cost the result: wh_task_greedy counts the time-outs, moves the task to the two-launch kernels, re-runs
+    the loop from the prompt and returns exactly what a two-launch task returns; the task stays off the fused kernels and
+    works normally afterwards.  Same for a beam task with <= 8 rows."""
+    from whisper_amd.tokenizer import get_tokenizer
+    dims = oracle.dims_for("wide-v3")
+    sd = oracle.synthetic_state_dict(dims, seed=11)
+    model = hip.HipModel(dims, hip.WH_F16, hip.pack_weights(sd, dims, hip.WH_F16, gpu_device))
+    tok = get_tokenizer(True, num_languages=dims.n_vocab - 51765 - 1, language="en", task="transcribe")
+    init = list(tok.sot_sequence)
+    T0, N, B = len(init), 24, 4
+    feats = _feats(dims, B, seed=77).to(gpu_device).half().contiguous()
+    mask = torch.zeros(dims.n_vocab, dtype=torch.uint8, device=gpu_device)
+    mask[tok.eot] = 1
+    params = hip.GreedyParams(sample_begin=T0, max_steps=N, n_ctx=dims.n_text_ctx, eot=tok.eot, timestamp_begin=tok.timestamp_begin,
+                              no_timestamps=tok.no_timestamps, max_initial_timestamp_index=50, suppress_blank=1,
+                              blank_token=tok.encode(" ")[0], suppress_mask=mask.data_ptr())
+
+    def greedy(task):
+        task.set_audio(feats)
+        tokens = torch.zeros(B, T0 + N + 1, dtype=torch.int64, device=gpu_device)
+        tokens[:, :T0] = torch.tensor(init, device=gpu_device)
+        n, lp, nsp = task.greedy(tokens, params, 0, tok.no_speech)
+        return n, tokens.cpu(), lp.cpu()
+
+    ref = hip.HipTask(model, B, 1, 8, two_launch_self=True, two_launch_cross=True)
+    try:
+        want = greedy(ref)
+    finally:
+        ref.close()
+
+    monkeypatch.setenv("WH_HANDOFF_TEST_TIMEOUT", "1")
+    task = hip.HipTask(model, B, 1, 8)
+    try:
+        assert task.fused_cross_attention and task.fused_self_attention and task.handoff_fallbacks == 0
+        got = greedy(task)                                   # time-outs -> fallback -> re-run inside the call
+        assert task.handoff_fallbacks == 1 and task.handoff_timeouts() > 0
+        assert not task.fused_cross_attention and not task.fused_self_attention
+        assert got[0] == want[0] and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+        monkeypatch.delenv("WH_HANDOFF_TEST_TIMEOUT")
+        task.reset()
+        again = greedy(task)                                 # the task keeps working, on the two-launch kernels
+        assert task.handoff_fallbacks == 1
+        assert again[0] == want[0] and torch.equal(again[1], want[1])
+    finally:
+        task.close()
+
+
 @pytest.mark.parametrize("B,T0", [(2, 150), (3, 61), (1, 448)])
 def test_prefill_flash_cross_attention(wide, gpu_device, B, T0):
     """Tasks that keep the cross-attention queries (word timestamps: ~200 teacher-forced tokens per clip) hold a

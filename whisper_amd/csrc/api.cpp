@@ -271,6 +271,7 @@ struct wh_task {
   // the decode step exists in two captured forms: [0] starts with the token embedding of `step_tokens` (host-driven
   // steps, beam search), [1] starts at layer 0 because the greedy sampler of the previous step already wrote x
   int steps_eager[2];      // decode steps launched without a graph (first one warms up attributes)
+  int handoff_fallbacks;   // times a fused loop was re-run on the two-launch kernels after a hand-off time-out
   hipGraph_t graph[2]; hipGraphExec_t graph_exec[2];
   // device buffers (carved from the caller's workspace)
   void* cross_kv;          // [L][B*Ta][2D]
@@ -452,6 +453,7 @@ extern "C" int wh_task_info(wh_task* t, int what, void* stream) {
   if (what == 0) return t->fused_xattn ? 1 : 0;
   if (what == 2) return t->fused_sattn ? 1 : 0;
   if (what == 3) return t->fused_out ? 1 : 0;
+  if (what == 4) return t->handoff_fallbacks;
   if (what == 1) {                       // hand-off timeouts of the fused cross attention since the task was created
     if (t->needs_reset) return 0;
     int v = 0;
@@ -963,10 +965,42 @@ extern "C" int wh_task_rearrange(wh_task* t, const int32_t* source_indices, void
 }
 
 // ---- fused greedy loop -----------------------------------------------------------------------------
+// A bounded hand-off spin of the fused step launches ran out during a device-side loop (never observed on an unshared
+// device; a GPU time-sliced between processes could stretch a spin past its bound): what the loop produced is not valid.
+// The task leaves the fused kernels for good — its step graphs are dropped and rebuilt from the two-launch kernels, which
+// wait for nothing — and the caller re-runs the loop from the prompt, which is still in place: the prefill starts at
+// position 0 again, the cross K/V and the rows' lags are untouched.
+static int handoff_fallback(wh_task* t, hipStream_t s) {
+  t->fused_xattn = t->fused_sattn = t->fused_out = false;
+  for (int i = 0; i < 2; ++i) {
+    if (t->graph_exec[i]) { (void)hipGraphExecDestroy(t->graph_exec[i]); t->graph_exec[i] = nullptr; }
+    if (t->graph[i]) { (void)hipGraphDestroy(t->graph[i]); t->graph[i] = nullptr; }
+    t->steps_eager[i] = 0;
+  }
+  HIPCHK(hipMemsetAsync(t->d_pos, 0, 4, s));
+  t->pos = 0;
+  t->handoff_fallbacks++;
+  return WH_OK;
+}
+
+static int greedy_impl(wh_task* t, const wh_greedy_params* p, int64_t* tokens, int64_t token_stride,
+                       int sot_index, int no_speech_token, float* sum_logprobs, float* no_speech_probs,
+                       int32_t* n_tokens_out, void* stream_);
 extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* tokens, int64_t token_stride,
                               int sot_index, int no_speech_token, float* sum_logprobs, float* no_speech_probs,
                               int32_t* n_tokens_out, void* stream_) {
   TASK_ENTER(t);
+  int rc = greedy_impl(t, p, tokens, token_stride, sot_index, no_speech_token, sum_logprobs, no_speech_probs, n_tokens_out, stream_);
+  if (rc == WH_ERR_HANDOFF) {
+    rc = handoff_fallback(t, (hipStream_t)stream_);
+    if (rc == WH_OK)
+      rc = greedy_impl(t, p, tokens, token_stride, sot_index, no_speech_token, sum_logprobs, no_speech_probs, n_tokens_out, stream_);
+  }
+  return rc;
+}
+static int greedy_impl(wh_task* t, const wh_greedy_params* p, int64_t* tokens, int64_t token_stride,
+                       int sot_index, int no_speech_token, float* sum_logprobs, float* no_speech_probs,
+                       int32_t* n_tokens_out, void* stream_) {
   if (!t || !p || !tokens || !sum_logprobs || !n_tokens_out) return WH_ERR_ARG;
   hipStream_t s = (hipStream_t)stream_;
   const wh_dims& d = t->m->d;
@@ -1070,11 +1104,27 @@ static int replicate_leader_rows(wh_task* t, int T0, float* logits, int n_sel, h
 }
 
 // ---- fused beam search loop --------------------------------------------------------------------------
+static int beam_impl(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int64_t token_stride, int sot_index,
+                     int no_speech_token, float* sum_logprobs, float* no_speech_probs, int64_t* fin_tokens,
+                     int32_t* fin_len, float* fin_scores, int32_t* fin_count, int32_t* n_tokens_out, void* stream_);
 extern "C" int wh_task_beam(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int64_t token_stride, int sot_index,
                             int no_speech_token, float* sum_logprobs, float* no_speech_probs, int64_t* fin_tokens,
                             int32_t* fin_len, float* fin_scores, int32_t* fin_count, int32_t* n_tokens_out,
                             void* stream_) {
   TASK_ENTER(t);
+  int rc = beam_impl(t, bp, tokens, token_stride, sot_index, no_speech_token, sum_logprobs, no_speech_probs, fin_tokens,
+                     fin_len, fin_scores, fin_count, n_tokens_out, stream_);
+  if (rc == WH_ERR_HANDOFF) {          // (fused step kernels run with <= 8 rows only: a beam task of 2 x 4 rows, say)
+    rc = handoff_fallback(t, (hipStream_t)stream_);
+    if (rc == WH_OK)
+      rc = beam_impl(t, bp, tokens, token_stride, sot_index, no_speech_token, sum_logprobs, no_speech_probs, fin_tokens,
+                     fin_len, fin_scores, fin_count, n_tokens_out, stream_);
+  }
+  return rc;
+}
+static int beam_impl(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int64_t token_stride, int sot_index,
+                     int no_speech_token, float* sum_logprobs, float* no_speech_probs, int64_t* fin_tokens,
+                     int32_t* fin_len, float* fin_scores, int32_t* fin_count, int32_t* n_tokens_out, void* stream_) {
   if (!t || !bp || !tokens || !sum_logprobs || !fin_tokens || !fin_len || !fin_scores || !fin_count || !n_tokens_out)
     return WH_ERR_ARG;
   hipStream_t s = (hipStream_t)stream_;

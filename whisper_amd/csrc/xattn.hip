@@ -153,7 +153,7 @@ __device__ __forceinline__ void proj_stage2(int aw, int lane, const half8v (&wa)
 }
 
 // one wave fetches 32 granules (64 fp16) into LDS: relaxed agent-scope 8-byte loads until every tag matches; bounded
-__device__ __forceinline__ void fetch_granules(const u64* gp, uint32_t tag, int lane, uint32_t* dst, int* err) {
+__device__ __forceinline__ void fetch_granules(const u64* gp, uint32_t tag, int lane, uint32_t* dst, int* err, int max_spins) {
   uint32_t data = 0;
   int spins = 0;
   for (;;) {
@@ -161,7 +161,7 @@ __device__ __forceinline__ void fetch_granules(const u64* gp, uint32_t tag, int 
     data = (uint32_t)g;
     const bool ok = (uint32_t)(g >> 32) == tag;
     if (__all(ok)) break;
-    if (++spins >= X_MAX_SPINS) { if (lane == 0 && err) atomicAdd(err, 1); break; }
+    if (++spins >= max_spins) { if (lane == 0 && err) atomicAdd(err, 1); break; }
     __builtin_amdgcn_s_sleep(4);
   }
   if (lane < 32) dst[lane] = data;
@@ -173,7 +173,7 @@ __device__ __forceinline__ void fetch_granules(const u64* gp, uint32_t tag, int 
 // scalar cache's own port to L2; `glc` makes every poll miss the scalar cache.  32 granules = 256 contiguous bytes =
 // four s_load_dwordx16 into 64 SGPRs; the tags are compared on the scalar ALU and lane j picks data dword 2 j.
 typedef int int16s __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ void fetch_granules_scalar(const u64* gp, uint32_t tag, int lane, uint32_t* dst, int* err) {
+__device__ __forceinline__ void fetch_granules_scalar(const u64* gp, uint32_t tag, int lane, uint32_t* dst, int* err, int max_spins) {
   const u64* p = gp;                     // wave-uniform by construction (block index, wave index)
   int16s r0, r1, r2, r3;
   int spins = 0;
@@ -190,7 +190,7 @@ __device__ __forceinline__ void fetch_granules_scalar(const u64* gp, uint32_t ta
       ok = ok && (uint32_t)r0[2 * e + 1] == tag && (uint32_t)r1[2 * e + 1] == tag && (uint32_t)r2[2 * e + 1] == tag &&
            (uint32_t)r3[2 * e + 1] == tag;
     if (ok) break;
-    if (++spins >= X_MAX_SPINS) { if (lane == 0 && err) atomicAdd(err, 1); break; }
+    if (++spins >= max_spins) { if (lane == 0 && err) atomicAdd(err, 1); break; }
     __builtin_amdgcn_s_sleep(2);
   }
   uint32_t val = 0;
@@ -298,8 +298,8 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
     // every workgroup: auxiliary wave 0 fetches the q granules of (row r, head h)
     if (aw == 0) {
       const u64* gp = a.qg + (size_t)r * (D >> 1) + h * 32;
-      if (a.mode & 1) fetch_granules_scalar(gp, tag, lane, qsh, a.err);
-      else fetch_granules(gp, tag, lane, qsh, a.err);
+      if (a.mode & 1) fetch_granules_scalar(gp, tag, lane, qsh, a.err, (a.mode & 4) ? 1 : X_MAX_SPINS);
+      else fetch_granules(gp, tag, lane, qsh, a.err, (a.mode & 4) ? 1 : X_MAX_SPINS);
       XPROBE(a, wgid, 2);                            // q fetched
     }
     __syncthreads();                                 // B3: q is in LDS
@@ -486,8 +486,8 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
     // consumers: three auxiliary waves fetch the granules of q, new k, new v of (row r, head h)
     if (aw < 3) {
       const u64* gp = a.qg + (size_t)r * (3 * D >> 1) + aw * (D >> 1) + h * 32;
-      if (a.mode & 1) fetch_granules_scalar(gp, tag, lane, qkv_sh[aw], a.err);
-      else fetch_granules(gp, tag, lane, qkv_sh[aw], a.err);
+      if (a.mode & 1) fetch_granules_scalar(gp, tag, lane, qkv_sh[aw], a.err, (a.mode & 4) ? 1 : X_MAX_SPINS);
+      else fetch_granules(gp, tag, lane, qkv_sh[aw], a.err, (a.mode & 4) ? 1 : X_MAX_SPINS);
       if (aw == 0) XPROBE(a, wgid, 2);               // q fetched
     }
     __syncthreads();                                 // B3
@@ -706,7 +706,10 @@ int fused_mode(int kind) {      // kind 0: cross attention, 1: self attention
     const bool flip = e && e[0] == '1';
     v[kind] = kind == 0 ? (flip ? 0 : 1) : (flip ? 1 : 0);
   }
-  return v[kind];
+  // bit 2: test hook — every consumer gives up after its first poll (WH_HANDOFF_TEST_TIMEOUT=1, read per capture): exercises
+  // the time-out accounting and the fallback of wh_task_greedy / wh_task_beam to the two-launch kernels
+  const char* te = getenv("WH_HANDOFF_TEST_TIMEOUT");
+  return v[kind] | ((te && te[0] == '1') ? 4 : 0);
 }
 
 // the shapes the fused form takes: fp16 (checked by the caller), <= 8 rows, one row per audio, K = D <= 1280 in blocks

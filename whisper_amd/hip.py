@@ -615,6 +615,12 @@ class HipTask:
         """... and attn.out + the residual add run inside that launch as well"""
         return lib().wh_task_info(self.handle, 3, None) == 1
 
+    @property
+    def handoff_fallbacks(self) -> int:
+        """times wh_task_greedy / wh_task_beam re-ran a loop on the two-launch kernels after a hand-off time-out (the task
+        stays on them afterwards: fused_cross_attention / fused_self_attention turn False)"""
+        return lib().wh_task_info(self.handle, 4, None)
+
     def handoff_timeouts(self) -> int:
         """bounded hand-off spins of the fused cross attention that ran out (0 on a healthy device); synchronises"""
         with self._call():
