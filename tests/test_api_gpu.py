@@ -549,6 +549,40 @@ def test_beam_search_survives_a_handoff_timeout(setup, gpu_device, monkeypatch):
         assert g.tokens == w.tokens and g.avg_logprob == w.avg_logprob and g.no_speech_prob == w.no_speech_prob
 
 
+def test_host_driven_loop_survives_a_handoff_timeout(setup, gpu_device, monkeypatch):
+    """The loop that steps the decoder from the host (a user logit filter keeps it off the device-side loops) on the fp16
+    engine's fused step kernels: with every hand-off forced to time out, DecodingTask notices after the window (the counter
+    of wh_task_info(t, 1) moved) and decodes it again on a task that uses the two-launch kernels — the result equals a run
+    that was on those kernels from the start."""
+    from whisper_amd.decoding import DecodingTask, LogitFilter
+
+    class Noop(LogitFilter):
+        def apply(self, logits, tokens):
+            return None
+
+    key, dims, sd, model, mel = setup
+    mels = _prompted_mels(dims, gpu_device, 2)
+    opts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=10)
+    eng = model.engine(torch.float16)
+
+    def run(two_launch):
+        eng.drop_cached_tasks()
+        task = DecodingTask(model, opts)
+        task.logit_filters.append(Noop())
+        assert not task._fused_greedy_ok(torch.zeros(2, 3, dtype=torch.int64))
+        task.inference.two_launch = two_launch
+        return task, task.run(mels)
+
+    _, want = run(True)
+    monkeypatch.setenv("WH_HANDOFF_TEST_TIMEOUT", "1")
+    task, got = run(False)
+    monkeypatch.delenv("WH_HANDOFF_TEST_TIMEOUT")
+    eng.drop_cached_tasks()
+    assert task.inference.two_launch is True                 # the window was decoded a second time
+    for g, w in zip(got, want):
+        assert g.tokens == w.tokens and g.avg_logprob == w.avg_logprob and g.no_speech_prob == w.no_speech_prob
+
+
 def test_device_sampling(setup, gpu_device):
     """Temperature sampling inside the fused loop (GreedyDecoder.update at T > 0, decoding.py:281-293; SURVEY.md §8f
     rank 2).  The reference draws from torch's generator, so parity is distributional:

@@ -133,6 +133,8 @@ class HipInference(Inference):
         self.capture_q = capture_q
         self.task: Optional[hip.HipTask] = None
         self.positions: Optional[List[int]] = None      # restrict first-call logits to these positions
+        self.two_launch = False                         # keep the task off the fused step kernels (csrc/xattn.hip)
+        self._timeouts_at_start = 0
 
     def _ensure_task(self, tokens: Tensor, audio_features: Tensor) -> hip.HipTask:
         if self.task is None:
@@ -142,9 +144,23 @@ class HipInference(Inference):
             group = n_rows // n_audio if n_rows % n_audio == 0 and n_rows >= n_audio else None
             if group is None:
                 raise ValueError(f"rows ({n_rows}) must be a multiple of audio segments ({n_audio})")
-            self.task = engine.acquire_task(n_audio, group, max(tokens.shape[1], 8), capture_q=self.capture_q)
+            if self.two_launch:      # a task of its own, outside the engine's cache (whose tasks are keyed by shape only)
+                self.task = hip.HipTask(engine, n_audio, group, max(tokens.shape[1], 8), capture_q=self.capture_q,
+                                        two_launch_self=True, two_launch_cross=True)
+            else:
+                self.task = engine.acquire_task(n_audio, group, max(tokens.shape[1], 8), capture_q=self.capture_q)
             self.task.set_audio(audio_features.contiguous())
+            fused = self.task.fused_cross_attention or self.task.fused_self_attention
+            self._timeouts_at_start = self.task.handoff_timeouts() if fused else 0
         return self.task
+
+    def handoff_timed_out(self) -> bool:
+        """host-driven steps (wh_task_step) on the fused step kernels: did a bounded hand-off spin run out since this
+        task was taken?  (The device-side loops check and recover inside wh_task_greedy / wh_task_beam.)  Synchronises."""
+        t = self.task
+        if t is None or not (t.fused_cross_attention or t.fused_self_attention):
+            return False
+        return t.handoff_timeouts() != self._timeouts_at_start
 
     def logits(self, tokens: Tensor, audio_features: Tensor) -> Tensor:
         task = self._ensure_task(tokens, audio_features)
@@ -654,9 +670,25 @@ class DecodingTask:
             return self._main_loop_fused(audio_features, tokens)
         if self._fused_beam_ok():
             return self._main_loop_beam_fused(audio_features, tokens)
+        if type(self.inference) is not HipInference:
+            return self._host_loop(audio_features, tokens)[:3]
+        first = tokens.clone()
+        out = self._host_loop(audio_features, tokens)
+        if out[3]:
+            # a hand-off spin of the fused step kernels ran out under host-driven steps (never seen on an unshared device):
+            # the logits of some step were not valid.  Once more, on a task that uses the two-launch kernels.
+            self.decoder.reset()
+            self.inference.two_launch = True
+            out = self._host_loop(audio_features, first)
+        return out[:3]
+
+    def _host_loop(self, audio_features: Tensor, tokens: Tensor):
+        """the reference's loop (decoding.py:683-712), one wh_task_step per token; -> (tokens, sum_logprobs,
+        no_speech_probs, hand-off timed out)"""
         n_batch = tokens.shape[0]
         sum_logprobs: Tensor = torch.zeros(n_batch, device=audio_features.device)
         no_speech_probs = [np.nan] * n_batch
+        timed_out = False
         if type(self.inference) is HipInference:   # only two positions of the first pass are ever read
             self.inference.positions = sorted({self.sot_index, tokens.shape[1] - 1})
         try:
@@ -672,9 +704,11 @@ class DecodingTask:
                 tokens, completed = self.decoder.update(tokens, logits, sum_logprobs)
                 if completed or tokens.shape[-1] > self.n_ctx:
                     break
+            if type(self.inference) is HipInference:
+                timed_out = self.inference.handoff_timed_out()
         finally:
             self.inference.cleanup_caching()
-        return tokens, sum_logprobs, no_speech_probs
+        return tokens, sum_logprobs, no_speech_probs, timed_out
 
     @torch.no_grad()
     def run(self, mel: Tensor) -> List[DecodingResult]:
