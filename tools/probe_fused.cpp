@@ -110,9 +110,18 @@ int main(int argc, char** argv) {
     return whk::launch_attn_decode(a, 1, st) == hipSuccess;
   };
 
+  auto out_proj = [&](int i) {       // attn.out + residual (gemv8 PRO_PLAIN, EPI_RESID) on the attention rows
+    const int l = i % L;
+    whk::GemvArgs g; memset(&g, 0, sizeof(g));
+    g.pro = whk::PRO_PLAIN; g.x = att; g.x_ld = D; g.W = Wo + (size_t)l * D * D; g.bias = bias; g.N = D; g.K = D; g.R = R;
+    g.epi = whk::EPI_RESID; g.resid = x2; g.resid_ld = D;
+    return whk::launch_gemv(g, 1, st) == hipSuccess;
+  };
   struct Case { const char* name; int kind; };
   Case cases[] = {{"cross: two launches (LN->q + attention)", 0}, {"cross: fused xattn8", 1},
-                  {"self:  two launches (LN->qkv + attention)", 2}, {"self:  fused sattn8", 3}};
+                  {"self:  two launches (LN->qkv + attention)", 2}, {"self:  fused sattn8", 3},
+                  {"attn.out + residual alone", 4}, {"pair: fused sattn8, then attn.out", 5},
+                  {"pair: attn.out, then fused xattn8", 6}};
   for (const Case& c : cases) {
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipMemset(d_probe, 0, 4096 * 8 * 8));
@@ -123,6 +132,9 @@ int main(int argc, char** argv) {
       if (c.kind == 1) ok = ok && whk::launch_xattn8(xargs(i), st) == hipSuccess;
       if (c.kind == 2) ok = ok && two_self(i);
       if (c.kind == 3) ok = ok && whk::launch_sattn8(sargs(i), st) == hipSuccess;
+      if (c.kind == 4) ok = ok && out_proj(i);
+      if (c.kind == 5) { whk::SAttnArgs sa = sargs(i); sa.probe = nullptr; ok = ok && whk::launch_sattn8(sa, st) == hipSuccess && out_proj(i); }
+      if (c.kind == 6) { whk::XAttnArgs xa = xargs(i); xa.probe = nullptr; ok = ok && out_proj(i) && whk::launch_xattn8(xa, st) == hipSuccess; }
     }
     hipLaunchKernelGGL(add_int_k, dim3(1), dim3(1), 0, st, d_tick, N);
     CK(hipStreamEndCapture(st, &g));
@@ -135,7 +147,7 @@ int main(int argc, char** argv) {
       if (rep > 1 && ms < best) best = ms;
     }
     int err = 0; CK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
-    printf("%-44s %6.2f us per link (pos %d, hand-off timeouts %d)\n", c.name, best * 1e3f / N, pos, err);
+    printf("%-44s %6.2f us per link%s (pos %d, hand-off timeouts %d)\n", c.name, best * 1e3f / N, c.kind >= 5 ? " (= per PAIR)" : "", pos, err);
     if (c.kind == 1 || c.kind == 3) {
       const int nwg = c.kind == 1 ? S * H * R : 3 * D / 8;
       std::vector<long long> p((size_t)nwg * 8);
