@@ -153,9 +153,11 @@ enum {
    * (A/B and tests: the results must agree) — for the self attention / for the cross attention */
   WH_TASK_TWO_LAUNCH_SELF = 2,
   WH_TASK_TWO_LAUNCH_CROSS = 4,
-  WH_TASK_FUSE_OUT = 8           /* EXPERIMENT (off by default): attn.out + residual inside the fused self-attention launch as
-                                  * well.  Bit-identical, but measured slower than its own launch (16.3 vs 10.5 + 4.8 us:
-                                  * profiles/r03_probe_fused_out_stage.txt) */
+  /* 8: reserved (development builds of the library only; ignored here) */
+  /* Fault injection for the hand-off protocol of the fused step kernels: every consumer gives up after its FIRST poll, as
+   * if its bounded spin had run out.  The step's result is then invalid by construction; wh_task_greedy / wh_task_beam
+   * must notice (WH_ERR_HANDOFF internally), move the task to the two-launch kernels and re-run — what the tests check. */
+  WH_TASK_EXPIRE_HANDOFFS = 16
 };
 /* The workspace holds the cross-attention K/V of n_audio segments, the self-attention cache of n_audio * n_group rows
  * and the step buffers.  WH_F16 tasks with n_group > 1 (beam search) additionally hold a transposed copy of the

@@ -1,0 +1,170 @@
+"""Margin-conditioned synthetic checkpoints.  TEST INFRASTRUCTURE (like the rest of oracle/).
+
+Why.  No released Whisper checkpoint exists offline, and on seeded random-init weights the greedy decision of a step
+is the larger of two nearly equal numbers: the top two of ~50 000 i.i.d.-looking logits lie a few hundredths apart
+somewhere in every couple of hundred steps, so "token ids equal to the fp32 reference" cannot hold for ANY reduced
+precision engine over a 224-step decode, and a parity test has to fall back on a near-tie rule — which cannot tell
+rounding from a defect.  A trained model does not look like that: its next-token distribution is peaked.  Scaling
+the tied embedding or the final LayerNorm does not make random weights peaked — it multiplies margins and rounding
+errors alike.  What does: the rows of the tied embedding `decoder.token_embedding.weight` (model.py:245-247) of the
+tokens that the decode actually emits are moved along the hidden state that emits them — by exactly as much as it
+takes for the oracle's arg-max (decoding.py:277-283) to win by a drawn margin, and for the "timestamp mass" rule
+(decoding.py:498-505) to be decided by the same margin.
+
+How.  One greedy pass of the oracle (fp32, reference operation order).  At step i, row k, with h = ln(x)[k] the hidden
+state model.py:244 produces and E the embedding so far:
+  1. hard filters (decoding.py:423-495) on  E h;
+  2. the token class follows a speech-like script (a timestamp, runs of text tokens, timestamp pairs between them;
+     the hard filters force most of it), the target y is the best-scoring admissible token of that class that no row
+     has emitted yet (for timestamps: among the next few values, so that a row does not run to <|30.00|> at once);
+  3. m ~ U[margin_lo, margin_hi];  E[y] += delta * d / (d . h), d = h minus its projection on the span of the rows'
+     running mean hidden states (a row's hidden states share a large audio-dependent component, cos ~ 0.96 between
+     steps: an edit along h itself would raise y's logit at every other step of the row almost as much, and the
+     boosts would have to outgrow each other; the remainders d are nearly orthogonal, cos 0 +- 0.1), with the smallest
+     delta >= 0 such that, after rounding E[y] to fp16 (both engines and the oracle see the same weights),
+         logit[y] >= (best other token of its class) + m     and
+         logit[y] >= (logsumexp of the timestamps, if y is text | best text token, if y is a timestamp) + m;
+  4. y is emitted; its embedding row is never touched again (it is an INPUT of the following steps).
+A row of E changes by ~delta / |d| ~ 0.1-0.2 against a norm of 1.8; nothing else in the checkpoint changes.
+Edits for later steps move earlier logits a little (hidden states are not orthogonal), so the caller always re-runs
+the plain `greedy_decode` on the finished weights and asserts the margins there (`margins_of`).
+
+The result is conditioned on (weights, audio features, prompt, rules): a synthetic checkpoint on which THESE clips
+decode with real-model-like margins.  The same kernels run as on any other weights.
+"""
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .decoding import SamplingRules, apply_filters
+from .model import OracleModel
+
+EMB = "decoder.token_embedding.weight"
+
+
+def _class_script(rng: np.random.Generator, n_steps: int, text_run: Tuple[int, int]) -> List[bool]:
+    """want_timestamp[i] for the steps where the hard filters leave the choice: True where a timestamp pair starts"""
+    want = [False] * n_steps
+    i = 1 + int(rng.integers(text_run[0], text_run[1] + 1))
+    while i < n_steps:
+        want[i] = True
+        i += 2 + int(rng.integers(text_run[0], text_run[1] + 1))
+    return want
+
+
+def condition_greedy(om: OracleModel, feats: torch.Tensor, initial_tokens: List[int], n_steps: int, r: SamplingRules,
+                     seed: int = 0, margin: Tuple[float, float] = (0.3, 3.0), text_run: Tuple[int, int] = (4, 14),
+                     ts_window: int = 12, log=None) -> Dict:
+    """Edits om.sd["decoder.token_embedding.weight"] IN PLACE (see the module docstring) along one greedy pass over
+    `feats` (R, 1500, D).  Returns {"tokens" (R, T0 + n_steps), "rows": edited token ids, "margins": per (step, row) the
+    margin built, "deltas": logit boosts applied}.  The caller re-packs its engines from the same state dict."""
+    rng = np.random.default_rng(seed)
+    E = om.sd[EMB]
+    assert E.dtype == torch.float32 and E.is_contiguous()
+    R = feats.shape[0]
+    TB = r.timestamp_begin
+    tokens = torch.tensor([list(initial_tokens)] * R, dtype=torch.int64)
+    used = torch.zeros(E.shape[0], dtype=torch.bool)
+    used[list(initial_tokens)] = True
+    scripts = [_class_script(rng, n_steps, text_run) for _ in range(R)]
+    cache = om.new_cache()
+    margins, deltas, rows = [], [], []
+    ninf = -np.inf
+    mean_sum, mean_n = None, 0
+    with torch.no_grad():
+        for i in range(n_steps):
+            h_seq = om.decoder_hidden(tokens if i == 0 else tokens[:, -1:], feats, cache).float()             # (R, T, D)
+            h_all = h_seq[:, -1]                                                                               # (R, D)
+            mean_sum = h_seq.sum(1) if mean_sum is None else mean_sum + h_all
+            mean_n += h_seq.shape[1]
+            Q, _ = torch.linalg.qr((mean_sum / mean_n).T)           # (D, R): orthonormal basis of the rows' running means
+            logits_all = h_all @ E.T                                                                           # (R, V)
+            nxt = torch.empty(R, dtype=torch.int64)
+            step_edits: List[int] = []
+            for k in range(R):
+                h = h_all[k]
+                lg = logits_all[k].clone()
+                if step_edits:                                  # rows edited for earlier rows of this step
+                    lg[step_edits] = E[step_edits] @ h
+                sampled = tokens[k, r.sample_begin:].tolist()
+                apply_filters(lg, sampled, r, mass_rule=False)
+                free = lg.clone()
+                free[used] = ninf
+                if TB is None:
+                    text_ok, ts_ok = True, False
+                    text_free = free
+                else:
+                    text_ok, ts_ok = bool(torch.isfinite(lg[:TB]).any()), bool(torch.isfinite(lg[TB:]).any())
+                    text_free = free[:TB]
+                y = None
+                pair_open = TB is not None and len(sampled) >= 2 and sampled[-1] >= TB and sampled[-2] < TB
+                if ts_ok and (not text_ok or scripts[k][i] or pair_open):      # pair_open: timestamps come in pairs
+                    cand = torch.nonzero(torch.isfinite(free[TB:]))[:ts_window, 0]
+                    if len(cand):
+                        y = TB + int(cand[free[TB:][cand].argmax()])
+                    elif not text_ok:
+                        raise RuntimeError(f"row {k} step {i}: no unused admissible timestamp left; shorten the decode, "
+                                           f"lengthen text_run or shrink ts_window")
+                if y is None:
+                    assert text_ok and bool(torch.isfinite(text_free).any()), (k, i)
+                    y = int(text_free.argmax())
+                m = float(rng.uniform(*margin))
+                others = lg.clone()
+                others[y] = ninf
+                if TB is None:
+                    need = float(others.max()) + m
+                elif y < TB:
+                    need = float(others[:TB].max()) + m
+                    if ts_ok:
+                        need = max(need, float(torch.logsumexp(others[TB:], 0)) + m)
+                else:
+                    need = float(others[TB:].max()) + m if bool(torch.isfinite(others[TB:]).any()) else ninf
+                    if text_ok:
+                        need = max(need, float(others[:TB].max()) + m)
+                have = float(lg[y])
+                boost = 0.0
+                if need > have:
+                    d = h - Q @ (Q.T @ h)
+                    u = d / float(d @ h)
+                    base = E[y].clone()
+                    boost = need - have
+                    for _ in range(8):
+                        E[y] = (base + boost * u).half().float()
+                        got = float(E[y] @ h)
+                        if got >= need:
+                            break
+                        boost += (need - got) + 1e-3
+                    else:
+                        raise RuntimeError("fp16 rounding of an edited embedding row did not converge")
+                    step_edits.append(y)
+                    rows.append(y)
+                    have = float(E[y] @ h)
+                used[y] = True
+                nxt[k] = y
+                margins.append(have - (need - m))
+                deltas.append(boost)
+            tokens = torch.cat([tokens, nxt[:, None]], dim=-1)
+            if log is not None and (i % 32 == 31 or i == n_steps - 1):
+                mm = np.asarray(margins[-32 * R:])
+                log(f"condition: step {i + 1}/{n_steps}, margins of the last steps min {mm.min():.2f} median "
+                    f"{np.median(mm):.2f}, boost median {np.median(deltas[-32 * R:]):.2f} max {max(deltas[-32 * R:]):.2f}")
+    return {"tokens": tokens, "rows": sorted(set(rows)), "margins": margins, "deltas": deltas}
+
+
+def margins_of(dec: Dict) -> Dict:
+    """Decision margins of a finished `greedy_decode(..., keep_logits=True)`: per (step, row) the winner's filtered
+    logit minus the runner-up's in the vector the arg-max was taken from (decoding.py:277-283), and the distance by
+    which the timestamp-mass rule (decoding.py:498-505) was decided wherever it had a choice to make."""
+    top = []
+    for lg in dec["step_logits"]:
+        v, _ = lg.float().topk(2, dim=-1)
+        top += (v[:, 0] - v[:, 1]).tolist()
+    top = np.asarray(top)
+    out = {"min": float(top.min()), "median": float(np.median(top)), "p05": float(np.quantile(top, 0.05)),
+           "n": int(top.size)}
+    rule = [abs(x) for x in dec.get("rule_margins", []) if x is not None]
+    if rule:
+        out["rule_min"] = float(min(rule))
+        out["rule_n"] = len(rule)
+    return out

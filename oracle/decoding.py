@@ -26,8 +26,9 @@ class SamplingRules:
     no_speech: Optional[int] = None
 
 
-def apply_filters(logits: torch.Tensor, sampled: List[int], r: SamplingRules) -> None:
-    """In-place on one row of fp32 logits.  decoding.py:423-505 in filter order :554-570."""
+def apply_filters(logits: torch.Tensor, sampled: List[int], r: SamplingRules, mass_rule: bool = True) -> None:
+    """In-place on one row of fp32 logits.  decoding.py:423-505 in filter order :554-570.
+    mass_rule=False stops before the "timestamp mass" rule (:498-505) — oracle/condition.py needs the two halves."""
     L = len(sampled)
     ninf = -np.inf
     if r.suppress_blank and L == 0:                      # SuppressBlank :428-430
@@ -54,6 +55,8 @@ def apply_filters(logits: torch.Tensor, sampled: List[int], r: SamplingRules) ->
         logits[:TB] = ninf
         if r.max_initial_timestamp_index is not None:
             logits[TB + r.max_initial_timestamp_index + 1:] = ninf
+    if not mass_rule:
+        return
     lp = F.log_softmax(logits.float(), dim=-1)           # :498-505
     if lp[TB:].logsumexp(dim=-1) > lp[:TB].max():
         logits[:TB] = ninf
@@ -71,8 +74,10 @@ def greedy_decode(model: OracleModel, feats: torch.Tensor, initial_tokens: List[
                   r: SamplingRules, keep_logits: bool = False) -> Dict:
     """GreedyDecoder at temperature 0 (decoding.py:277-293) inside _main_loop (:680-710).
     Returns {"tokens": (R, n) int64 incl. the initial tokens, "sum_logprobs": [R], "no_speech_probs": [R]} and, with
-    keep_logits, "step_logits": the filtered fp32 logits (R, V) every arg-max was taken from (test helper: margins)."""
-    kept = []
+    keep_logits, "step_logits": the filtered fp32 logits (R, V) every arg-max was taken from (test helper: margins) and
+    "rule_margins": per step and row, timestamp mass minus best text log-probability where decoding.py:498-505 had a
+    choice to make (None elsewhere) — the distance by which that rule was decided."""
+    kept, kept_rule = [], []
     R = feats.shape[0]
     tokens = torch.tensor([list(initial_tokens)] * R, dtype=torch.int64)
     sum_lp = torch.zeros(R)
@@ -88,6 +93,11 @@ def greedy_decode(model: OracleModel, feats: torch.Tensor, initial_tokens: List[
         logits = logits.clone()
         nxt = torch.empty(R, dtype=torch.int64)
         for k in range(R):
+            if keep_logits and r.timestamp_begin is not None:
+                apply_filters(logits[k], tokens[k, r.sample_begin:].tolist(), r, mass_rule=False)
+                txt, ts = logits[k, : r.timestamp_begin], logits[k, r.timestamp_begin:]
+                both = bool(torch.isfinite(txt).any()) and bool(torch.isfinite(ts).any())
+                kept_rule.append(float(ts.float().logsumexp(0) - txt.max()) if both else None)
             apply_filters(logits[k], tokens[k, r.sample_begin:].tolist(), r)
             nxt[k] = int(logits[k].argmax())
             lp = F.log_softmax(logits[k].float(), dim=-1)[nxt[k]]
@@ -103,6 +113,7 @@ def greedy_decode(model: OracleModel, feats: torch.Tensor, initial_tokens: List[
     out = {"tokens": tokens, "sum_logprobs": sum_lp.tolist(), "no_speech_probs": nsp}
     if keep_logits:
         out["step_logits"] = kept
+        out["rule_margins"] = kept_rule
     return out
 
 

@@ -83,6 +83,13 @@ class OracleModel:
                 keep_qk: bool = False) -> torch.Tensor:
         """tokens (R, T) int64; xa (B, 1500, D) with R % B == 0 (rows r use audio r // (R//B)).
         With a cache, `tokens` are the new positions only.  Returns fp32 logits (R, T, V)."""
+        x = self.decoder_hidden(tokens, xa, cache, keep_qk)
+        return (x @ self.sd["decoder.token_embedding.weight"].to(x.dtype).T).float()      # model.py:245-247
+
+    def decoder_hidden(self, tokens: torch.Tensor, xa: torch.Tensor, cache: Optional[dict] = None,
+                       keep_qk: bool = False) -> torch.Tensor:
+        """model.py:227-244: everything up to and including `self.ln(x)`; (R, T, D).  Split from `decoder` for
+        oracle/condition.py, which edits rows of the tied embedding between the two halves."""
         d, sd = self.dims, self.sd
         R, T = tokens.shape
         offset = 0 if cache is None or cache["self_k"][0] is None else cache["self_k"][0].shape[1]
@@ -131,7 +138,7 @@ class OracleModel:
             cache["qk"] = qks
         elif keep_qk:
             self.last_qk = qks
-        return (x @ sd["decoder.token_embedding.weight"].to(x.dtype).T).float()      # model.py:245-247
+        return x
 
     def rearrange(self, cache: dict, source_indices: List[int]) -> None:
         """decoding.py:172-176: only the self-attention caches are gathered"""

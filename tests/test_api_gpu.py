@@ -9,6 +9,7 @@ import torch
 
 import oracle
 import whisper_amd
+from whisper_amd import hip
 from whisper_amd.synthetic import dims_for, save_checkpoint, synthetic_state_dict
 from whisper_amd.tokenizer import get_tokenizer
 
@@ -527,9 +528,9 @@ def test_device_beam_search_equals_host_loop(setup, gpu_device, kw):
         assert np.allclose([v for d in ff for v in d.values()], [v for d in hf for v in d.values()], atol=1e-4)
 
 
-def test_beam_search_survives_a_handoff_timeout(setup, gpu_device, monkeypatch):
+def test_beam_search_survives_a_handoff_timeout(setup, gpu_device):
     """2 clips x beam 4 = 8 rows in the fp16 engine: the step runs the fused self-attention launch.  With every hand-off
-    forced to time out (WH_HANDOFF_TEST_TIMEOUT=1, fresh task) wh_task_beam re-runs the search on the two-launch kernels
+    forced to time out (WH_TASK_EXPIRE_HANDOFFS, fresh task) wh_task_beam re-runs the search on the two-launch kernels
     inside the call; decode() returns what it returns without the time-outs (the fused self attention is bit-identical
     to the two-launch form, so ids and scores agree exactly)."""
     key, dims, sd, model, mel = setup
@@ -538,10 +539,12 @@ def test_beam_search_survives_a_handoff_timeout(setup, gpu_device, monkeypatch):
     eng = model.engine(torch.float16)
     eng.drop_cached_tasks()
     want = whisper_amd.decode(model, mels, opts)
-    eng.drop_cached_tasks()                                  # the next task captures its step graph with the test bit
-    monkeypatch.setenv("WH_HANDOFF_TEST_TIMEOUT", "1")
-    got = whisper_amd.decode(model, mels, opts)
-    monkeypatch.delenv("WH_HANDOFF_TEST_TIMEOUT")
+    eng.drop_cached_tasks()                                  # the next task is created with the fault-injection flag
+    eng.debug_task_flags = hip.WH_TASK_EXPIRE_HANDOFFS
+    try:
+        got = whisper_amd.decode(model, mels, opts)
+    finally:
+        eng.debug_task_flags = 0
     cached = [t for t in eng._task_cache if t.n_rows == 8]
     assert cached and cached[-1].handoff_fallbacks == 1 and not cached[-1].fused_self_attention
     eng.drop_cached_tasks()
@@ -549,7 +552,7 @@ def test_beam_search_survives_a_handoff_timeout(setup, gpu_device, monkeypatch):
         assert g.tokens == w.tokens and g.avg_logprob == w.avg_logprob and g.no_speech_prob == w.no_speech_prob
 
 
-def test_host_driven_loop_survives_a_handoff_timeout(setup, gpu_device, monkeypatch):
+def test_host_driven_loop_survives_a_handoff_timeout(setup, gpu_device):
     """The loop that steps the decoder from the host (a user logit filter keeps it off the device-side loops) on the fp16
     engine's fused step kernels: with every hand-off forced to time out, DecodingTask notices after the window (the counter
     of wh_task_info(t, 1) moved) and decodes it again on a task that uses the two-launch kernels — the result equals a run
@@ -574,9 +577,11 @@ def test_host_driven_loop_survives_a_handoff_timeout(setup, gpu_device, monkeypa
         return task, task.run(mels)
 
     _, want = run(True)
-    monkeypatch.setenv("WH_HANDOFF_TEST_TIMEOUT", "1")
-    task, got = run(False)
-    monkeypatch.delenv("WH_HANDOFF_TEST_TIMEOUT")
+    eng.debug_task_flags = hip.WH_TASK_EXPIRE_HANDOFFS
+    try:
+        task, got = run(False)
+    finally:
+        eng.debug_task_flags = 0
     eng.drop_cached_tasks()
     assert task.inference.two_launch is True                 # the window was decoded a second time
     for g, w in zip(got, want):

@@ -72,9 +72,7 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B, T0):
     stream; q / new k / new v handed between workgroups as tagged 8-byte granules).  Against the same step with
     projection and attention as separate launches (WH_TASK_TWO_LAUNCH_*), prefill + 12 steps on the same tokens, ragged
     rows (per-row lag) included:
-      * the fused SELF attention is bit-identical (same products, same order of sums) — also with the experimental third
-        stage (attn.out + residual add by the otherwise idle waves of the first D / 8 workgroups, attention outputs handed
-        over as granules, result into the second residual buffer: correct, but slower than its own launch, off by default);
+      * the fused SELF attention is bit-identical (same products, same order of sums);
       * the fused CROSS attention reproduces q bit for bit and sums each key range with 8 instead of 4 waves' partial
         sums: fp32 sums in another order flip the fp16 rounding of an attention output now and then (1 ulp), which the
         later layers and steps carry on — the logits agree at the level of the fp16 engine's own rounding noise
@@ -91,11 +89,10 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B, T0):
     toks = torch.randint(0, dims.n_vocab, (B, T0 + 12), generator=g).to(gpu_device)
     lag = [(3 * i) % 5 for i in range(B)] if B > 1 else None           # ragged prompts: rows sit at their own positions
 
-    def run(two_self, two_cross, fuse_out=False):
-        task = hip.HipTask(model, B, 1, max(8, T0), two_launch_self=two_self, two_launch_cross=two_cross, fuse_out=fuse_out)
+    def run(two_self, two_cross):
+        task = hip.HipTask(model, B, 1, max(8, T0), two_launch_self=two_self, two_launch_cross=two_cross)
         try:
             assert task.fused_self_attention == (not two_self) and task.fused_cross_attention == (not two_cross)
-            assert task.fused_out_projection == (not two_self and fuse_out)
             task.set_audio(feats)
             if lag is not None:
                 task.set_lag(lag)
@@ -109,18 +106,17 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B, T0):
 
     plain = run(True, True)
     assert torch.isfinite(plain).all()
-    for fuse_out in (False, True):       # self attention fused without / with attn.out + residual in the same launch
-        fused_self = run(False, True, fuse_out)
-        assert torch.equal(fused_self, plain), (fuse_out, (fused_self - plain).abs().max().item())
+    fused_self = run(False, True)
+    assert torch.equal(fused_self, plain), (fused_self - plain).abs().max().item()
     for out in (run(True, False), run(False, False)):                 # fused cross attention alone, and both
         d = (out - plain).abs()
         assert d.max().item() < 2e-2 and (d.double() ** 2).mean().sqrt().item() < 2e-3, (d.max().item(), (d.double() ** 2).mean().sqrt().item())
         assert (out.argmax(-1) == plain.argmax(-1)).float().mean().item() > 0.98
 
 
-def test_handoff_timeout_falls_back_to_two_launch_kernels(gpu_device, monkeypatch):
-    """A hand-off spin that runs out (forced here: WH_HANDOFF_TEST_TIMEOUT=1 lets every consumer give up after its first
-    poll) must not cost the result: wh_task_greedy counts the time-outs, moves the task to the two-launch kernels, re-runs
+def test_handoff_timeout_falls_back_to_two_launch_kernels(gpu_device):
+    """A hand-off spin that runs out (forced here: the fault-injection flag WH_TASK_EXPIRE_HANDOFFS lets every consumer give
+    up after its first poll) must not cost the result: wh_task_greedy counts the time-outs, moves the task to the two-launch kernels, re-runs
     the loop from the prompt and returns exactly what a two-launch task returns; the task stays off the fused kernels and
     works normally afterwards.  Same for a beam task with <= 8 rows."""
     from whisper_amd.tokenizer import get_tokenizer
@@ -150,15 +146,13 @@ def test_handoff_timeout_falls_back_to_two_launch_kernels(gpu_device, monkeypatc
     finally:
         ref.close()
 
-    monkeypatch.setenv("WH_HANDOFF_TEST_TIMEOUT", "1")
-    task = hip.HipTask(model, B, 1, 8)
+    task = hip.HipTask(model, B, 1, 8, expire_handoffs=True)
     try:
         assert task.fused_cross_attention and task.fused_self_attention and task.handoff_fallbacks == 0
         got = greedy(task)                                   # time-outs -> fallback -> re-run inside the call
         assert task.handoff_fallbacks == 1 and task.handoff_timeouts() > 0
         assert not task.fused_cross_attention and not task.fused_self_attention
         assert got[0] == want[0] and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
-        monkeypatch.delenv("WH_HANDOFF_TEST_TIMEOUT")
         task.reset()
         again = greedy(task)                                 # the task keeps working, on the two-launch kernels
         assert task.handoff_fallbacks == 1
@@ -195,7 +189,7 @@ def test_prefill_flash_cross_attention(wide, gpu_device, B, T0):
                     # median / head mean) against the single-clip entry points (vector-ALU QK) on the same task
                     layers, heads = [1] * 20, list(range(20))
                     frames = [1500 - 100 * i for i in range(B)]
-                    cost, _ = task.align_batch(layers, heads, [T0] * B, frames, 7, 2)
+                    cost, _, _ = task.align_batch(layers, heads, [T0] * B, frames, 7, 2)
                     for r in range(B):
                         one = hip.align_matrix(task.cross_qk(r, layers, heads, 0, T0), frames[r], 7, 2, T0 - 1)
                         assert (cost[r, :, : frames[r]] - one).abs().max().item() < 2e-3, r

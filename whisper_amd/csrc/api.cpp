@@ -420,9 +420,12 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
   {
     // attn.out inside the self-attention launch: built, bit-identical, and slower than its own launch (the gather of 160
     // (row, head) outputs by the projection workgroups costs ~4 us after the attention, and its polling slows the
-    // projection phase of the same launch): off unless asked for (WH_FUSED_OUT=1 / WH_TASK_FUSE_OUT)
-    static const bool env_out = [] { const char* e = getenv("WH_FUSED_OUT"); return e && e[0] == '1'; }();
-    t->fused_out = t->fused_sattn && (env_out || (flags & WH_TASK_FUSE_OUT));
+    // projection phase of the same launch): a development-build experiment (-DWH_DEV: WH_FUSED_OUT=1 / flag bit 8)
+#ifdef WH_DEV
+    t->fused_out = t->fused_sattn && (WH_DEV_FLAG("WH_FUSED_OUT") || (flags & 8 /* development builds: WH_TASK_FUSE_OUT */));
+#else
+    t->fused_out = false;                            // the stage is not compiled into the shipped kernels
+#endif
   }
   t->h_lag = (int*)calloc((size_t)t->R, sizeof(int));
   if (!t->h_lag) { delete t; return WH_ERR_ARG; }
@@ -610,7 +613,7 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
 
   const bool skinny = M <= SKINNY_ROWS && D <= 2048;
   // one row per audio (alignment tasks; beam search through its leader rows) and a transposed V: flash cross attention
-  static const bool no_flash = [] { const char* e = getenv("WH_NO_PREFILL_FLASH"); return e && e[0] == '1'; }();   // A/B switch
+  const bool no_flash = WH_DEV_FLAG("WH_NO_PREFILL_FLASH");   // developer A/B switch
   const bool flash_cross = !skinny && !no_flash && m->dtype == WH_F16 && t->cross_vt && Gp == 1 && R == t->B &&
                            t->vt_ld >= (Ta + 63) / 64 * 64;
   HIPCHK(launch_embed(tokens, token_stride, R, T0, m->w.tok_emb, m->w.dec_pos, t->d_pos, nullptr, D, V, t->x, m->dtype, s));
@@ -746,7 +749,7 @@ static XAttnArgs xattn_args(const wh_task* t, int l, int epoch, const float* x_i
   a.v = (char*)cross_layer(t, l) + (size_t)D * m->esize; a.v_ld = 2 * D; a.v_bs = a.k_bs;
   a.Tk = Ta; a.splits = t->cross_splits;
   a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
-  a.qg = t->xq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err; a.mode = fused_mode(0);
+  a.qg = t->xq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err; a.mode = fused_mode(0) | ((t->flags & WH_TASK_EXPIRE_HANDOFFS) ? 4 : 0);
   return a;
 }
 
@@ -766,7 +769,7 @@ static SAttnArgs sattn_args(const wh_task* t, int l, int epoch, const float* x_i
   a.kcache = self_k_layer(t, l); a.vcache = self_v_layer(t, l); a.cache_bs = (int64_t)d.n_text_ctx * D;
   a.d_pos = t->d_pos; a.lag = t->d_lag; a.q_out = t->qbuf;
   a.out = t->att; a.o_ld = D;
-  a.qg = t->sq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err; a.mode = fused_mode(1);
+  a.qg = t->sq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err; a.mode = fused_mode(1) | ((t->flags & WH_TASK_EXPIRE_HANDOFFS) ? 4 : 0);
   return a;
 }
 
@@ -849,7 +852,7 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
     memset(&g, 0, sizeof(g));
     // 17+ rows (beam search): the projection runs as 16-row workgroups that would each merge their rows' partials
     // again, so the merge is a launch of its own there (A/B: WH_NO_MERGE_KERNEL=1)
-    static const bool merge_kernel = [] { const char* e = getenv("WH_NO_MERGE_KERNEL"); return !(e && e[0] == '1'); }();
+    const bool merge_kernel = !WH_DEV_FLAG("WH_NO_MERGE_KERNEL");   // developer A/B switch
     if (t->cross_splits > 1 && R > 16 && m->dtype == WH_F16 && merge_kernel) {   // the fp32 engine keeps one code path
       HIPCHK(launch_merge_partials(t->part_o, t->part_ml, t->cross_splits, R, H, t->att, D, m->dtype, s));
       g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D;
@@ -1010,6 +1013,12 @@ static int greedy_impl(wh_task* t, const wh_greedy_params* p, int64_t* tokens, i
   // ragged rows share one step counter: no row may reach the context limit before the step budget runs out
   if (t->lag_on && (T0 + p->max_steps > p->n_ctx || T0 + p->max_steps > d.n_text_ctx)) return WH_ERR_ARG;
 
+  // hand-off time-outs are judged per call: the counter as it stands when this call's work starts (stream-ordered copy)
+  // is the baseline, so time-outs of earlier host-driven wh_task_step calls on a cached task do not trigger a fallback here
+  if (!t->h_poll) HIPCHK(hipHostMalloc((void**)&t->h_poll, ((size_t)t->B + 16) * 4, hipHostMallocDefault));
+  int* h_err0 = t->h_poll + t->B + 9;
+  HIPCHK(hipMemcpyAsync(h_err0, t->d_err, 4, hipMemcpyDeviceToHost, s));
+
   int32_t sel[2]; int n_sel;
   const bool want_ns = no_speech_token >= 0 && no_speech_probs != nullptr;
   if (want_ns && sot_index != T0 - 1) { sel[0] = sot_index; sel[1] = T0 - 1; n_sel = 2; }
@@ -1031,7 +1040,7 @@ static int greedy_impl(wh_task* t, const wh_greedy_params* p, int64_t* tokens, i
   sa.row_state = t->samp_state;
   HIPCHK(hipMemsetAsync(t->samp_state, 0, (size_t)R * 16, s));
   // the sampler also writes the next step's input row (token embedding + position): the step graph starts at layer 0
-  static const bool fused_embed = [] { const char* e = getenv("WH_NO_FUSED_EMBED"); return !(e && e[0] == '1'); }();   // A/B switch
+  const bool fused_embed = !WH_DEV_FLAG("WH_NO_FUSED_EMBED");   // developer A/B switch
   if (fused_embed) {
     sa.x_next = t->x; sa.tok_emb = t->m->w.tok_emb; sa.pos_emb = t->m->w.dec_pos; sa.D = d.n_text_state;
     sa.emb_f16 = t->m->dtype == WH_F16 ? 1 : 0; sa.n_pos = d.n_text_ctx;
@@ -1049,7 +1058,6 @@ static int greedy_impl(wh_task* t, const wh_greedy_params* p, int64_t* tokens, i
   // Completion is polled every 8 tokens WITHOUT draining the queue: the counter is copied to pinned memory behind step
   // k, an event is recorded, two more steps are queued, and only then does the host wait for the event — the GPU is
   // two steps behind the host at that point and never idles for a launch.  At most two steps run past completion.
-  if (!t->h_poll) HIPCHK(hipHostMalloc((void**)&t->h_poll, ((size_t)t->B + 16) * 4, hipHostMallocDefault));
   if (!t->poll_event) HIPCHK(hipEventCreateWithFlags(&t->poll_event, hipEventDisableTiming));
   bool pending = false;
   int ntok_at_copy = 0;
@@ -1073,7 +1081,8 @@ static int greedy_impl(wh_task* t, const wh_greedy_params* p, int64_t* tokens, i
   int* h_err = t->h_poll + t->B + 8;                                               // pinned: past the per-segment flags
   HIPCHK(hipMemcpyAsync(h_err, t->d_err, 4, hipMemcpyDeviceToHost, s));            // fused launches: hand-off timeouts
   HIPCHK(hipStreamSynchronize(s));
-  if ((t->fused_xattn || t->fused_sattn) && *h_err != t->err_seen) { t->err_seen = *h_err; return WH_ERR_HANDOFF; }
+  t->err_seen = *h_err;
+  if ((t->fused_xattn || t->fused_sattn) && *h_err != *h_err0) return WH_ERR_HANDOFF;
   alive = *t->h_poll;
   (void)done;
   // the sampler that appended token index c ran with ntok == c; "completed" first holds at c = alive + 1
@@ -1141,13 +1150,17 @@ static int beam_impl(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int6
     for (int r = 0; r < R; ++r) if (t->h_lag[r] != t->h_lag[r / G * G]) return WH_ERR_ARG;
   }
 
+  if (!t->h_poll) HIPCHK(hipHostMalloc((void**)&t->h_poll, ((size_t)t->B + 16) * 4, hipHostMallocDefault));
+  int* h_err0 = t->h_poll + t->B + 9;                    // time-out counter at call entry (see greedy_impl)
+  HIPCHK(hipMemcpyAsync(h_err0, t->d_err, 4, hipMemcpyDeviceToHost, s));
+
   int32_t sel[2]; int n_sel;
   const bool want_ns = no_speech_token >= 0 && no_speech_probs != nullptr;
   if (want_ns && sot_index != T0 - 1) { sel[0] = sot_index; sel[1] = T0 - 1; n_sel = 2; }
   else { sel[0] = T0 - 1; n_sel = 1; }
   // the G beams of a segment hold the same prompt: one row per segment through the decoder, then replicate (A/B:
   // WH_BEAM_FULL_PREFILL=1 feeds all R rows as the reference does)
-  static const bool leaders = [] { const char* e = getenv("WH_BEAM_FULL_PREFILL"); return !(e && e[0] == '1'); }();
+  const bool leaders = !WH_DEV_FLAG("WH_BEAM_FULL_PREFILL");
   int rc = prefill_impl(t, tokens, token_stride, T0, sel, n_sel, t->logits, V, s, leaders);
   if (rc != WH_OK) return rc;
   if (leaders) { rc = replicate_leader_rows(t, T0, t->logits, n_sel, s); if (rc != WH_OK) return rc; }
@@ -1171,7 +1184,7 @@ static int beam_impl(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int6
   // shared-history bookkeeping for the cache permutation (beams that descend from one ancestor hold the same K/V up to
   // the point where they split: those positions are never copied).  "Everything so far" to start with: all beams of a
   // segment hold the same prompt.  Not used with ragged prompts (positions are row-local there).
-  static const bool lcp_on = [] { const char* e = getenv("WH_BEAM_FULL_PERMUTE"); return !(e && e[0] == '1'); }();   // A/B switch
+  const bool lcp_on = !WH_DEV_FLAG("WH_BEAM_FULL_PERMUTE");   // developer A/B switch
   if (lcp_on && !t->lag_on) {
     a.lcp = t->beam_lcp; a.copy_from = t->beam_lcp + (size_t)B * 64;
     HIPCHK(hipMemsetAsync(t->beam_lcp, 0x7f, (size_t)B * 64 * 4, s));
@@ -1199,7 +1212,6 @@ static int beam_impl(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int6
   // completion flags are polled every 8 steps without draining the queue (see wh_task_greedy): snapshot behind step k,
   // wait for it two steps later.  Once every segment is done an update leaves the state untouched, so the extra steps
   // change nothing.
-  if (!t->h_poll) HIPCHK(hipHostMalloc((void**)&t->h_poll, ((size_t)t->B + 16) * 4, hipHostMallocDefault));
   if (!t->poll_event) HIPCHK(hipEventCreateWithFlags(&t->poll_event, hipEventDisableTiming));
   bool pending = false;
   while (steps < p->max_steps && ntok <= p->n_ctx && ntok <= d.n_text_ctx) {
@@ -1226,7 +1238,8 @@ static int beam_impl(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int6
   HIPCHK(hipMemcpyAsync(&err_now, t->d_err, 4, hipMemcpyDeviceToHost, s));
   if (cur == 1) HIPCHK(hipMemcpyAsync(buf[0], buf[1], (size_t)R * token_stride * 8, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipStreamSynchronize(s));
-  if ((t->fused_xattn || t->fused_sattn) && err_now != t->err_seen) { t->err_seen = err_now; return WH_ERR_HANDOFF; }
+  t->err_seen = err_now;
+  if ((t->fused_xattn || t->fused_sattn) && err_now != *h_err0) return WH_ERR_HANDOFF;
   *n_tokens_out = T0 + applied;
   return WH_OK;
 }

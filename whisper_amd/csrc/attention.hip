@@ -435,7 +435,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArg
   // may then hold anything (stale positions of an earlier clip) — their score is replaced by -inf below, and only keys are
   // fetched this way (a masked VALUE would still enter the sum as 0 x NaN).
   constexpr int EAG = SKIP ? 2 : 0;
-  const bool eager = SKIP && S == 1 && a.d_len != nullptr;
+  // (only when the cache row really holds EAG * KPR positions: k_bs / k_ld = n_text_ctx of the model — tiny test dims may not)
+  const bool eager = SKIP && S == 1 && a.d_len != nullptr && (int64_t)(EAG * KPR) * a.k_ld <= a.k_bs;
   int Tk = a.Tk;
   int vn = 0, vl = 0;
   if (a.d_len) {                          // cached length and this row's lag: two independent agent-scope loads
@@ -925,7 +926,7 @@ hipError_t launch_cross_qk_batch(const void* qcap, int64_t q_layer_stride, int64
                                  const int* d_heads, int n_pairs, const int* d_ntok, int R, int Tmax, int Tk, float* out,
                                  int dtype, hipStream_t stream) {
   if ((int64_t)R * n_pairs > 65535) return hipErrorInvalidValue;
-  static const bool valu_qk = [] { const char* e = getenv("WH_QK_VALU"); return e && e[0] == '1'; }();   // A/B switch
+  const bool valu_qk = WH_DEV_FLAG("WH_QK_VALU");   // developer A/B switch
   if (dtype == 1 && !valu_qk && D % 8 == 0) {
     dim3 mgrid((Tk + 127) / 128, (Tmax + 63) / 64, R * n_pairs);
     hipLaunchKernelGGL(cross_qk_batch_mfma_kernel, mgrid, dim3(256), 0, stream, (const half_t*)qcap, q_layer_stride, q_row_stride, D,
@@ -984,7 +985,7 @@ static hipError_t launch_attn_decode_t(const DecAttnArgs& a, hipStream_t stream)
   }
   const int chunk = (a.Tk + a.splits - 1) / a.splits;
   if constexpr (sizeof(T) == 2) {
-    static const bool no_mfma = [] { const char* e = getenv("WH_GROUP_ATTN_VALU"); return e && e[0] == '1'; }();   // A/B switch
+    const bool no_mfma = WH_DEV_FLAG("WH_GROUP_ATTN_VALU");   // developer A/B switch
     if (a.vt && !no_mfma && a.kv_group > 1 && a.kv_group <= 8 && a.R % a.kv_group == 0 && chunk <= 512 &&
         (int64_t)a.splits * ((chunk + 127) / 128 * 128) <= a.vt_ld) {
       dim3 ggrid(a.splits, a.H, a.R / a.kv_group);

@@ -503,15 +503,10 @@ hipError_t launch_rows(const whk::GemmArgs& a, int batch, hipStream_t stream) {
   whk::GemmArgs p = a;
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16_rows_kernel<ACT, BIAS>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static whk::LdsAttr attr;
+  { hipError_t e = whk::raise_dynamic_lds(attr, (const void*)gemm_f16_rows_kernel<ACT, BIAS>, ROWS_LDS); if (e != hipSuccess) return e; }
   // more tiles than CUs: 256 persistent workgroups (one per CU: the LDS ring allows no second one) walk the tiles
-  static const int dev = [] { const char* e = getenv("WH_GEMM_DEV"); return e ? atoi(e) : 0; }();   // 4: never persistent
+  const int dev = WH_DEV_INT("WH_GEMM_DEV");   // developer switch; 4: never persistent
   const int ntiles = p.tiles_m * p.tiles_n;
   p.persistent = (batch == 1 && ntiles > 256 && !(dev & 4)) ? 1 : 0;
   dim3 grid(p.persistent ? 256 : ntiles, 1, batch);
@@ -521,7 +516,7 @@ hipError_t launch_rows(const whk::GemmArgs& a, int batch, hipStream_t stream) {
 
 // fp16 in / fp16 out, no residual, rows of C 16-byte aligned, N a multiple of 4, operands below 4 GB
 bool rows_kernel_applies(const whk::GemmArgs& a) {
-  static const int dev = [] { const char* e = getenv("WH_GEMM_DEV"); return e ? atoi(e) : 0; }();   // 1: never
+  const int dev = WH_DEV_INT("WH_GEMM_DEV");   // developer switch; 1: never
   if (dev & 1) return false;
   if (a.res || (a.ldc & 7) || (a.N & 3) || (a.c_bs & 7) || (((uintptr_t)a.C) & 15)) return false;
   if (((int64_t)a.M * a.lda + a.K) * 2 >= (1LL << 32) || ((int64_t)a.N * a.ldw + a.K) * 2 >= (1LL << 32)) return false;
@@ -546,14 +541,9 @@ hipError_t launch_shape(const whk::GemmArgs& a, int batch, hipStream_t stream) {
   whk::GemmArgs p = a;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, WGM, WGN>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  { const char* e = getenv("WH_GEMM_SERIAL_EPILOGUE"); p.serial_epilogue = (e && e[0] == '1') ? 1 : 0; }   // A/B switch
+  static whk::LdsAttr attr;
+  { hipError_t e = whk::raise_dynamic_lds(attr, (const void*)gemm_nt_kernel<T, OutT, WGM, WGN>, LDS); if (e != hipSuccess) return e; }
+  p.serial_epilogue = WH_DEV_FLAG("WH_GEMM_SERIAL_EPILOGUE") ? 1 : 0;   // developer A/B switch
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
   hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, WGM, WGN>), grid, dim3(WGM * WGN * 64), LDS, stream, p);
   return hipGetLastError();
@@ -561,7 +551,7 @@ hipError_t launch_shape(const whk::GemmArgs& a, int batch, hipStream_t stream) {
 
 template <typename T, typename OutT>
 hipError_t launch_t(const whk::GemmArgs& a, int batch, hipStream_t stream) {
-  static const int force = [] { const char* e = getenv("WH_GEMM_TILE"); return e ? atoi(e) : 0; }();   // 128 / 256: developer override
+  const int force = WH_DEV_INT("WH_GEMM_TILE");   // 128 / 256: developer override
   // tools/probe_gemm on MI355X (M = 12000): 256x256 is 12-17 % faster than 128x128 on every encoder shape (e.g.
   // N=2560 K=1280: 648 vs 548 TFLOP/s; N=1280 K=5120: 949 vs 809), and among 256x256 layouts 16 waves of 64x64 beat
   // 8 waves of 128x64 (760 vs 650 on the QKV shape); deeper LDS rings at lower occupancy were slower.

@@ -453,13 +453,8 @@ hipError_t launch_cfg(const whk::GemvArgs& a, int gp, hipStream_t stream) {
   else if (lds < red_bytes) lds = red_bytes;
   if (PRO == whk::PRO_COMBINE) lds += (size_t)RT * a.H * CS * sizeof(float);   // merge weights behind `red`
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemv_kernel<T, RT, LPR, PRO, J, MULTI, WAVES, GS, MF>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static whk::LdsAttr attr;
+  { hipError_t e = whk::raise_dynamic_lds(attr, (const void*)gemv_kernel<T, RT, LPR, PRO, J, MULTI, WAVES, GS, MF>, 160 * 1024); if (e != hipSuccess) return e; }
   constexpr int KS_ = WAVES / GS, NU_ = (WAVES == 4 || MF) ? 10 : 5, BLK_ = LPR * ET<T>::UNIT;
   if (!MULTI && (a.K / BLK_ + KS_ - 1) / KS_ > NU_) return hipErrorInvalidValue;   // one batch per wave only
   const int per_wg = MULTI ? gp : GS;
@@ -735,12 +730,12 @@ hipError_t launch_stream(const whk::GemvArgs& a, hipStream_t stream) {
   if (gpw < 1) gpw = 1;
   dim3 grid((ngroups + 8 * gpw - 1) / (8 * gpw), (a.R + RT - 1) / RT), block(512);
   if (a.K <= 256 * 5) {
-    static bool set5 = false;
-    if (!set5) { (void)hipFuncSetAttribute((const void*)gemv_stream_kernel<T, RT, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set5 = true; }
+    static whk::LdsAttr attr5;
+    { hipError_t e = whk::raise_dynamic_lds(attr5, (const void*)gemv_stream_kernel<T, RT, 5>, 160 * 1024); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL((gemv_stream_kernel<T, RT, 5>), grid, block, lds, stream, a, gpw);
   } else {
-    static bool set8 = false;
-    if (!set8) { (void)hipFuncSetAttribute((const void*)gemv_stream_kernel<T, RT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set8 = true; }
+    static whk::LdsAttr attr8;
+    { hipError_t e = whk::raise_dynamic_lds(attr8, (const void*)gemv_stream_kernel<T, RT, 8>, 160 * 1024); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL((gemv_stream_kernel<T, RT, 8>), grid, block, lds, stream, a, gpw);
   }
   return hipGetLastError();
@@ -1119,9 +1114,7 @@ hipError_t launch_gemv8_pro(const whk::GemvArgs& a, hipStream_t stream) {
 }
 
 bool gemv8_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("WH_GEMV_DOT2"); v = (e && e[0] == '1') ? 0 : 1; }
-  return v == 1;
+  return !WH_DEV_FLAG("WH_GEMV_DOT2");      // developer switch: the round-1 v_dot2 kernels instead
 }
 
 // returns hipErrorNotSupported when the shape / mode is not covered (the caller falls back to the v_dot2 kernels)
@@ -1297,7 +1290,7 @@ __global__ __launch_bounds__(1024) void gemv_rows48_kernel(whk::GemvArgs a) {
 // applies to: fp16, LayerNorm prologue with folded affine part, 17..48 rows, K a multiple of 256 up to 1280,
 // store / GELU / QKV epilogues
 bool rows48_applies(const whk::GemvArgs& a) {
-  static const bool off = [] { const char* e = getenv("WH_NO_ROWS48"); return e && e[0] == '1'; }();   // A/B switch (tools)
+  const bool off = WH_DEV_FLAG("WH_NO_ROWS48");   // developer A/B switch
   // measured at 40 rows, large-v3 (rocprof, real beam step): FC1 14.9 -> 11.4 us, QKV 11.7 -> 11.4 us; the D x D
   // cross-attention query got slower (7.9 -> 8.6 us: 80 workgroups each normalising all 48 rows), so N >= 2048 only
   return !off && a.R > 16 && a.R <= 48 && a.pro == whk::PRO_LN && a.ln_folded && a.K % 256 == 0 && a.K <= 1280 &&
@@ -1306,12 +1299,8 @@ bool rows48_applies(const whk::GemvArgs& a) {
 
 hipError_t launch_rows48(const whk::GemvArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)48 * a.K * 2 > 49152 ? (size_t)48 * a.K * 2 : 49152;     // x tile, later the partial sums
-  static bool attr2 = false;
-  if (!attr2) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemv_rows48_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr2 = true;
-  }
+  static whk::LdsAttr attr2;
+  { hipError_t e = whk::raise_dynamic_lds(attr2, (const void*)gemv_rows48_kernel<2>, 160 * 1024); if (e != hipSuccess) return e; }
   hipLaunchKernelGGL((gemv_rows48_kernel<2>), dim3((a.N + 31) / 32), dim3(1024), lds, stream, a);   // 32 features per workgroup
   return hipGetLastError();
 }
@@ -1435,19 +1424,15 @@ __global__ __launch_bounds__(1024) void gemv_rows48_stream_kernel(whk::GemvArgs 
 
 // fp16, LayerNorm prologue, fp32 output without bias, 17..48 rows, K a multiple of 256 up to 1280, a long N
 bool rows48_stream_applies(const whk::GemvArgs& a) {
-  static const bool off = [] { const char* e = getenv("WH_NO_ROWS48"); return e && e[0] == '1'; }();   // A/B switch (tools)
+  const bool off = WH_DEV_FLAG("WH_NO_ROWS48");   // developer A/B switch
   return !off && a.R > 16 && a.R <= 48 && a.pro == whk::PRO_LN && a.epi == whk::EPI_F32 && !a.bias && a.K % 256 == 0 &&
          a.K <= 1280 && a.N >= 16384 && a.variant <= 0;
 }
 
 hipError_t launch_rows48_stream(const whk::GemvArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)48 * a.K * 2 + (size_t)2 * a.K * 4;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemv_rows48_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  static whk::LdsAttr attr;
+  { hipError_t e = whk::raise_dynamic_lds(attr, (const void*)gemv_rows48_stream_kernel, 160 * 1024); if (e != hipSuccess) return e; }
   const int ntiles = (a.N + 15) / 16;
   int wgs = (ntiles + 15) / 16;                        // one 16-feature tile per wave ...
   if (wgs > 256) wgs = 256;                            // ... or several when there are more tiles than 256 x 16 waves

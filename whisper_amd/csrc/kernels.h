@@ -14,7 +14,36 @@
 #define WH_PROBE_AT(args, wg, i) do {} while (0)
 #endif
 
+// Developer A/B switches (tools/README.md): environment variables are read ONLY by the -DWH_DEV build
+// (`make dev` -> libwhisper_hip_dev.so, loaded by the tools through WHISPER_AMD_LIB); in the shipped library every
+// switch is the constant of the measured-faster form and its name does not exist in the binary.  The one variable the
+// shipped library reads is WH_NO_GRAPH (api.cpp: decode steps launched eagerly — a support switch, not an experiment).
+#ifdef WH_DEV
+#include <stdlib.h>
+#define WH_DEV_FLAG(name) ([] { static const bool v = [] { const char* e = getenv(name); return e && e[0] == '1'; }(); return v; }())
+#define WH_DEV_INT(name) ([] { static const int v = [] { const char* e = getenv(name); return e ? atoi(e) : 0; }(); return v; }())
+#else
+#define WH_DEV_FLAG(name) false
+#define WH_DEV_INT(name) 0
+#endif
+
+#include <atomic>
 namespace whk {
+
+// Dynamic LDS above 64 KB is a per-DEVICE function attribute (hipFuncSetAttribute): raise it once on every device this
+// process launches `fn` on.  `c` is the call site's own cache (function-local static).
+struct LdsAttr { std::atomic<int> done[64]; };
+inline hipError_t raise_dynamic_lds(LdsAttr& c, const void* fn, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (c.done[dev].load(std::memory_order_acquire) == 1) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) c.done[dev].store(1, std::memory_order_release);
+  else (void)hipGetLastError();
+  return e;
+}
 
 // dtype: 0 = fp32, 1 = fp16 (matches WH_F32 / WH_F16)
 

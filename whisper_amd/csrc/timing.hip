@@ -376,12 +376,10 @@ hipError_t launch_dtw_backtrace_batch(const int8_t* trace, int64_t trace_bs, con
   if (clips <= 0) return hipSuccess;
   const int64_t need = (int64_t)(max_rows + 1) * ((max_cols + 4) >> 2);
   const int LDS_MAX = 156 * 1024;
-  const int lds = need <= LDS_MAX ? (int)((need + 15) & ~15ll) : 0;          // 0: walk the global trace
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dtw_backtrace_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-    attr_set = true;
-  }
+  int lds = need <= LDS_MAX ? (int)((need + 15) & ~15ll) : 0;                // 0: walk the global trace
+  // where the dynamic-LDS limit cannot be raised on this device the walk runs on the global trace (lds = 0)
+  static whk::LdsAttr attr;
+  if (lds > 64 * 1024 && whk::raise_dynamic_lds(attr, (const void*)dtw_backtrace_batch_kernel, LDS_MAX) != hipSuccess) lds = 0;
   hipLaunchKernelGGL(dtw_backtrace_batch_kernel, dim3(clips), dim3(lds ? 1024 : 64), (size_t)lds, stream, trace, trace_bs,
                      d_rows, d_cols, lds, jumps, jump_stride, path, path_stride, path_len);
   return hipGetLastError();

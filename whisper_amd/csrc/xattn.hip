@@ -37,7 +37,6 @@
 // A/B: WH_NO_FUSED_XATTN=1 / WH_NO_FUSED_SATTN=1 (process) or WH_TASK_TWO_LAUNCH_CROSS / _SELF (per task).
 #include "common.h"
 #include "kernels.h"
-#include <stdlib.h>
 
 // developer probe (tools/probe_fused.cpp, -DWH_PROBE): lane 0 of the calling wave stamps slot `i` of its workgroup's record —
 // slots 0-3 by auxiliary wave 0, slots 4-7 by the first K/V wave
@@ -217,12 +216,16 @@ __device__ __forceinline__ void publish_pair(u64* slot, half_t mine_h, int lane,
 // barrier among `n_waves_total / per-phase` auxiliary waves through an LDS arrival counter: lane 0 of each wave adds 1 after
 // the wave's own LDS writes (in-order in the LDS pipe; release fence for the compiler), everyone spins until the counter
 // reaches `target` (cumulative over the phases), acquire fence before the reads that follow
-__device__ __forceinline__ void aux_barrier(int* cnt, int target, int lane) {
+// — a spin that runs out (the waves of a resident workgroup always make progress, so: never) counts in *err like the
+// hand-off spins do, and the step's result is then discarded by the caller (WH_ERR_HANDOFF)
+__device__ __forceinline__ void aux_barrier(int* cnt, int target, int lane, int* err) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   int spins = 0;
-  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && ++spins < (1 << 20))
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+    if (++spins >= (1 << 20)) { if (lane == 0 && err) atomicAdd(err, 1); break; }
     __builtin_amdgcn_s_sleep(1);
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
@@ -278,9 +281,9 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
       const float bias = a.bias[wgid * 8 + (lane & 7)];          // requested with the rest, used after the MFMAs
       tag = ((uint32_t)(uniform(vtick) + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
       proj_ln(aw, lane, D, xv, xfrag);
-      aux_barrier(&aux_cnt, AUX, lane);              // the 4 auxiliary waves only: the K/V waves are still issuing
+      aux_barrier(&aux_cnt, AUX, lane, a.err);              // the 4 auxiliary waves only: the K/V waves are still issuing
       proj_stage2(aw, lane, wa, xfrag, pred);
-      aux_barrier(&aux_cnt, 2 * AUX, lane);
+      aux_barrier(&aux_cnt, 2 * AUX, lane, a.err);
       if (aw == 0) {                                 // 64 outputs: lane = 8 row + feature
         const int er = lane >> 3, ej = lane & 7;
         const int n = wgid * 8 + ej;
@@ -422,9 +425,11 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t qkv_sh[3][32];           // q (scaled), new k, new v of (row, head)
   __shared__ float red[WAVES][64];
   __shared__ float redm[WAVES], reds[WAVES];
+#ifdef WH_DEV
   __shared__ __attribute__((aligned(16))) half8v xfrag2[P_KS * P_NU * 64];  // output projection: attention rows, fragment order
   __shared__ float pred2[P_KS][8][8];
   __shared__ int cnt_aux, cnt_out;                 // arrival counters (output-projection workgroups)
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -433,18 +438,22 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
   const int cidx = wgid - (nwg - H * R);           // consumer index, >= 0 in the last H * R workgroups
   const bool consumer = cidx >= 0;                 // workgroup-uniform
   const int r = consumer ? cidx / H : 0, h = consumer ? cidx - (cidx / H) * H : 0;
-  // Third stage (x_out != null): `attn.out` + the residual add (model.py:153) in the same launch.  The FIRST D / 8
+  // Third stage — DEVELOPMENT BUILDS ONLY (-DWH_DEV; a rejected experiment kept reproducible: bit-identical, 16.3 us per
+  // launch against 10.5 + 4.8 for the two launches, profiles/r03_probe_fused_out_stage.txt; the shipped kernel does not
+  // contain it) — (x_out != null): `attn.out` + the residual add (model.py:153) in the same launch.  The FIRST D / 8
   // workgroups — never consumers — use their 8 otherwise idle K/V waves for it: waves 0-3 request the 8 x D weight rows
   // of feature group `wgid` at entry, each of the 8 waves gathers the attention output of ONE row (all heads) from the
   // granules the consumers publish (a.og) into LDS in MFMA fragment order; 5 MFMAs per weight wave, bias + residual, fp32 store into the
   // OTHER residual buffer (x_out; the launch's own LayerNorm input a.xf is still being read by late workgroups).
   // Inside these workgroups nothing uses the workgroup barrier after B0: the two groups of waves synchronise through LDS
   // arrival counters (aux_barrier), so neither waits for the other.
+#ifdef WH_DEV
   const bool out_wg = a.x_out != nullptr && wgid < (D >> 3);
   if (out_wg) {
     if (tid == 0) { cnt_aux = 0; cnt_out = 0; }
     __syncthreads();                               // B0
   }
+#endif
 
   if (wave >= WAVES) {
     // ================= auxiliary waves: the projection of feature group `wgid` (every workgroup) =================
@@ -459,9 +468,15 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
     half8v wa[P_NU];
     proj_stage1(aw, lane, wgid, a.W, D, a.xf, a.xf_ld, R, wa, xfrag);
     const uint32_t tag = ((uint32_t)(uniform(vtick) + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
-    if (out_wg) aux_barrier(&cnt_aux, 4, lane); else __syncthreads();          // B1
+#ifdef WH_DEV
+    if (out_wg) aux_barrier(&cnt_aux, 4, lane, a.err); else
+#endif
+    __syncthreads();                                 // B1
     proj_stage2(aw, lane, wa, xfrag, pred);
-    if (out_wg) aux_barrier(&cnt_aux, 8, lane); else __syncthreads();          // B2
+#ifdef WH_DEV
+    if (out_wg) aux_barrier(&cnt_aux, 8, lane, a.err); else
+#endif
+    __syncthreads();                                 // B2
     if (aw == 0) {                                   // 64 outputs: lane = 8 row + feature
       const int er = lane >> 3, ej = lane & 7;
       const int n = wgid * 8 + ej;                   // output feature in [0, 3D)
@@ -496,6 +511,7 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
     return;
   }
 
+#ifdef WH_DEV
   // ================= waves 0-7 of the first D / 8 workgroups: output projection + residual =================
   if (out_wg) {
     const int ow = wave;                             // also the attention row this wave gathers
@@ -569,10 +585,10 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
         }
       }
     }
-    aux_barrier(&cnt_out, 8, lane);                  // fragments of all 8 rows are in LDS
+    aux_barrier(&cnt_out, 8, lane, a.err);                  // fragments of all 8 rows are in LDS
     if (ow >= 4) return;
     proj_stage2(ow, lane, wa, xfrag2, pred2);
-    aux_barrier(&cnt_out, 12, lane);                 // the 4 weight waves
+    aux_barrier(&cnt_out, 12, lane, a.err);                 // the 4 weight waves
     if (ow == 0) {
       const int er = lane >> 3, ej = lane & 7;
       float v = e_bias;
@@ -583,6 +599,7 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
     }
     return;
   }
+#endif
 
   // ================= KV waves: only in consumer workgroups =================
   if (!consumer) return;                             // (ended waves are not waited for by the barriers of the others)
@@ -676,10 +693,13 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) { o += red[w][tid]; l += reds[w]; }
     const half_t ov = (half_t)(o / l);
+#ifdef WH_DEV
     if (a.x_out) {                                   // to the output-projection workgroups of this launch
       const uint32_t tag2 = ((uint32_t)(vtk + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
       publish_pair(a.og + (size_t)r * (D >> 1) + h * 32 + (tid >> 1), ov, lane, (tid & 1) == 0, true, tag2);
-    } else {
+    } else
+#endif
+    {
       ((half_t*)a.out)[(int64_t)r * a.o_ld + h * 64 + tid] = ov;
     }
     XPROBE(a, wgid, 7);
@@ -690,26 +710,14 @@ __global__ __launch_bounds__(768, 6) void sattn8_kernel(whk::SAttnArgs a) {
 
 namespace whk {
 
-bool xattn_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("WH_NO_FUSED_XATTN"); v = (e && e[0] == '1') ? 0 : 1; }
-  return v == 1;
-}
+bool xattn_enabled() { return !WH_DEV_FLAG("WH_NO_FUSED_XATTN"); }      // developer switch; per task: WH_TASK_TWO_LAUNCH_CROSS
 
 // how the granules are fetched: through the scalar memory path (default for the cross attention, whose consumer CUs are
 // saturated with vector-memory requests: 13.4 vs 14.1 us per launch) or with vector loads (default for the self attention:
 // 10.5 vs 10.9 us).  Developer switches: WH_XATTN_VECTOR_POLL=1, WH_SATTN_SCALAR_POLL=1.
-int fused_mode(int kind) {      // kind 0: cross attention, 1: self attention
-  static int v[2] = {-1, -1};
-  if (v[kind] < 0) {
-    const char* e = getenv(kind == 0 ? "WH_XATTN_VECTOR_POLL" : "WH_SATTN_SCALAR_POLL");
-    const bool flip = e && e[0] == '1';
-    v[kind] = kind == 0 ? (flip ? 0 : 1) : (flip ? 1 : 0);
-  }
-  // bit 2: test hook — every consumer gives up after its first poll (WH_HANDOFF_TEST_TIMEOUT=1, read per capture): exercises
-  // the time-out accounting and the fallback of wh_task_greedy / wh_task_beam to the two-launch kernels
-  const char* te = getenv("WH_HANDOFF_TEST_TIMEOUT");
-  return v[kind] | ((te && te[0] == '1') ? 4 : 0);
+int fused_mode(int kind) {      // kind 0: cross attention, 1: self attention; bit 0 = scalar-path polls
+  const bool flip = kind == 0 ? WH_DEV_FLAG("WH_XATTN_VECTOR_POLL") : WH_DEV_FLAG("WH_SATTN_SCALAR_POLL");
+  return kind == 0 ? (flip ? 0 : 1) : (flip ? 1 : 0);
 }
 
 // the shapes the fused form takes: fp16 (checked by the caller), <= 8 rows, one row per audio, K = D <= 1280 in blocks
@@ -724,9 +732,7 @@ bool xattn_supported(int D, int H, int R, int kv_group, int Tk, int splits) {
 
 // self attention + QKV projection: <= 8 rows, the cache fits the 512-key register tile, enough workgroups for the consumers
 bool sattn_supported(int D, int H, int R, int n_ctx) {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("WH_NO_FUSED_SATTN"); v = (e && e[0] == '1') ? 0 : 1; }
-  if (v != 1) return false;
+  if (WH_DEV_FLAG("WH_NO_FUSED_SATTN")) return false;      // developer switch; per task: WH_TASK_TWO_LAUNCH_SELF
   if (R < 1 || R > 8 || D % 64 != 0 || D > 1280 || H * 64 != D || n_ctx > 448) return false;
   return H * R <= 3 * D / 8;
 }

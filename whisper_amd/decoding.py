@@ -701,10 +701,24 @@ class DecodingTask:
                 logits = logits[:, -1]
                 for logit_filter in self.logit_filters:
                     logit_filter.apply(logits, tokens)
-                tokens, completed = self.decoder.update(tokens, logits, sum_logprobs)
+                hip_steps = type(self.inference) is HipInference
+                try:
+                    tokens, completed = self.decoder.update(tokens, logits, sum_logprobs)
+                except ValueError:
+                    # Categorical(logits=NaN) at temperature > 0: garbage logits after a hand-off time-out must reach the
+                    # retry below instead of raising here; anything else is the caller's error
+                    if hip_steps and self.inference.handoff_timed_out():
+                        timed_out = True
+                        break
+                    raise
                 if completed or tokens.shape[-1] > self.n_ctx:
                     break
-            if type(self.inference) is HipInference:
+                # a time-out invalidates every later step of the window: look every 16 tokens (the loop synchronises with
+                # the device at every token anyway) instead of ranking candidates on garbage until the window ends
+                if hip_steps and i % 16 == 15 and self.inference.handoff_timed_out():
+                    timed_out = True
+                    break
+            if type(self.inference) is HipInference and not timed_out:
                 timed_out = self.inference.handoff_timed_out()
         finally:
             self.inference.cleanup_caching()

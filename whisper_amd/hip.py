@@ -14,13 +14,16 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 _LIB = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwhisper_hip.so")
+# WHISPER_AMD_LIB: another build of the same C ABI — the developer build `make -C whisper_amd/csrc dev`
+# (libwhisper_hip_dev.so, -DWH_DEV: the only build that reads the A/B environment switches of tools/README.md).  Still a
+# HIP library: there is no non-HIP path to select.
+_LIB_PATH = os.environ.get("WHISPER_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwhisper_hip.so")
 
 WH_F32, WH_F16 = 0, 1
 WH_TASK_CAPTURE_Q = 1
 WH_TASK_TWO_LAUNCH_SELF = 2
 WH_TASK_TWO_LAUNCH_CROSS = 4
-WH_TASK_FUSE_OUT = 8
+WH_TASK_EXPIRE_HANDOFFS = 16        # fault injection (include/whisper_hip.h): every hand-off poll gives up at once
 WH_WEIGHTS_DEC_LN_FOLDED = 1
 WH_WEIGHTS_ENC_QK_SCALED = 2
 # sqrt(0.125 * log2 e): with it in both the query and the key projection, K.Q^T is the exp2 argument of the softmax
@@ -386,6 +389,7 @@ class HipModel:
         self.stream = torch.cuda.Stream(device=self.device)
         self._enc_ws: Optional[torch.Tensor] = None
         self._task_cache: List["HipTask"] = []          # idle tasks, most recently used last
+        self.debug_task_flags = 0                       # OR-ed into the flags of every task created (tests: WH_TASK_EXPIRE_HANDOFFS)
         # workspaces kept alive between windows: WH_TASK_CACHE_GB, else 10 % of the device memory (28 GB of the 288 GB of
         # an MI355X; a smaller GPU gets a smaller cache).  Allocation failures anywhere on this engine's path drop the
         # cache and retry once (`_alloc`), because torch's own out-of-memory retry cannot reclaim tensors we hold.
@@ -489,13 +493,14 @@ class HipTask:
 
     def __init__(self, model: HipModel, n_audio: int, n_group: int, max_prefill: int, capture_q: bool = False,
                  stream: Optional[torch.cuda.Stream] = None, two_launch_self: bool = False, two_launch_cross: bool = False,
-                 fuse_out: bool = False):
+                 expire_handoffs: bool = False, extra_flags: int = 0):
         self.model = model
         self.n_audio, self.n_group, self.n_rows = n_audio, n_group, n_audio * n_group
         self.max_prefill = max_prefill
         self.capture_q = capture_q
         flags = ((WH_TASK_CAPTURE_Q if capture_q else 0) | (WH_TASK_TWO_LAUNCH_SELF if two_launch_self else 0)
-                 | (WH_TASK_TWO_LAUNCH_CROSS if two_launch_cross else 0) | (WH_TASK_FUSE_OUT if fuse_out else 0))
+                 | (WH_TASK_TWO_LAUNCH_CROSS if two_launch_cross else 0)
+                 | (WH_TASK_EXPIRE_HANDOFFS if expire_handoffs else 0) | int(extra_flags) | int(model.debug_task_flags))
         self.stream = stream if stream is not None else model.stream   # independent tasks may run on own streams
         with torch.cuda.device(model.device):
             need = lib().wh_task_workspace_bytes(model.handle, n_audio, n_group, max_prefill, flags)
@@ -611,11 +616,6 @@ class HipTask:
         return lib().wh_task_info(self.handle, 2, None) == 1
 
     @property
-    def fused_out_projection(self) -> bool:
-        """... and attn.out + the residual add run inside that launch as well"""
-        return lib().wh_task_info(self.handle, 3, None) == 1
-
-    @property
     def handoff_fallbacks(self) -> int:
         """times wh_task_greedy / wh_task_beam re-ran a loop on the two-launch kernels after a hand-off time-out (the task
         stays on them afterwards: fused_cross_attention / fused_self_attention turn False)"""
@@ -685,9 +685,11 @@ class HipTask:
     def align_batch(self, layers: Sequence[int], heads: Sequence[int], n_tok: Sequence[int], n_frames: Sequence[int],
                     width: int, row_begin: int, qk_scale: float = 1.0):
         """find_alignment core for every row of the task (wh_task_align_batch + wh_dtw_backtrace_batch).  Returns
-        (cost [R][Nmax][Fmax] fp32, jumps int32 [R][Nmax], both on the device): jumps[r][i] = the frame at which the DTW
-        path of clip r first reaches text row i (`time_indices[jumps]` of timing.py:226-228).  Nothing is copied to the
-        host here and nothing synchronises beyond the C call's own upload of the size arrays."""
+        (cost [R][Nmax][Fmax] fp32, jumps int32 [R][Nmax], path_len int32 [R], all on the device): jumps[r][i] = the
+        frame at which the DTW path of clip r first reaches text row i (`time_indices[jumps]` of timing.py:226-228);
+        path_len[r] = number of path entries, or -1 when the walk met a trace code outside {0, 1, 2} (the reference
+        raises ValueError there, timing.py:77 — the caller must).  Nothing is copied to the host here and nothing
+        synchronises beyond the C call's own upload of the size arrays."""
         R, P = self.n_rows, len(layers)
         assert len(n_tok) == R and len(n_frames) == R
         Tmax, Fmax = max(n_tok), max(n_frames)
@@ -699,6 +701,7 @@ class HipTask:
         stride = (Nmax + 1) * (Fmax + 1)
         trace = torch.empty(R, stride, dtype=torch.int8, device=dev)
         jumps = torch.zeros(R, Nmax, dtype=torch.int32, device=dev)
+        plen = torch.zeros(R, dtype=torch.int32, device=dev)
         sizes = torch.tensor([[n_tok[r] - 1 - row_begin for r in range(R)], [int(f) for f in n_frames]],
                              dtype=torch.int32).to(dev)                      # before _enter(): ordered on the caller's stream
         arr = lambda v: (C.c_int32 * len(v))(*[int(x) for x in v])
@@ -707,11 +710,11 @@ class HipTask:
                                             float(qk_scale), cost.data_ptr(), trace.data_ptr(), stride, scratch.data_ptr(),
                                             scratch.numel(), stream_ptr(self.stream)), "wh_task_align_batch")
             check(lib().wh_dtw_backtrace_batch(trace.data_ptr(), stride, sizes[0].data_ptr(), sizes[1].data_ptr(), R, Nmax, Fmax,
-                                               jumps.data_ptr(), Nmax, None, 0, None, stream_ptr(self.stream)),
+                                               jumps.data_ptr(), Nmax, None, 0, plen.data_ptr(), stream_ptr(self.stream)),
                   "wh_dtw_backtrace_batch")
-        for t_ in (scratch, cost, trace, jumps, sizes):
+        for t_ in (scratch, cost, trace, jumps, plen, sizes):
             t_.record_stream(self.stream)
-        return cost, jumps
+        return cost, jumps, plen
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -764,16 +767,16 @@ def dtw_backtrace(trace: torch.Tensor, want_path: bool = True):
     sizes = torch.tensor([N, M], dtype=torch.int32).to(dev)
     jumps = torch.zeros(N, dtype=torch.int32, device=dev)
     path = torch.zeros(2, N + M, dtype=torch.int32, device=dev) if want_path else None
-    plen = torch.zeros(1, dtype=torch.int32, device=dev) if want_path else None
+    plen = torch.zeros(1, dtype=torch.int32, device=dev)      # always: -1 reports a corrupt trace (timing.py:77)
     s = torch.cuda.current_stream(dev)
     check(lib().wh_dtw_backtrace_batch(trace.data_ptr(), trace.numel(), sizes[0:1].data_ptr(), sizes[1:2].data_ptr(), 1, N, M,
                                        jumps.data_ptr(), N, _ptr(path), N + M, _ptr(plen), stream_ptr(s)),
           "wh_dtw_backtrace_batch")
-    if not want_path:
-        return jumps, None
     n = int(plen.item())
     if n < 0:
         raise ValueError("Unexpected trace[i, j]")          # reference timing.py:77
+    if not want_path:
+        return jumps, None
     return jumps, path[:, N + M - n:]
 
 

@@ -179,7 +179,7 @@ def find_alignment_batch(model: "Whisper", tokenizer: Tokenizer, text_tokens: Li
                 task.set_audio(features.contiguous())
                 n_text_max = Tmax - n_sot - 2
                 logits = task.prefill(tokens.contiguous(), sel=list(range(n_sot, n_sot + n_text_max)))   # (rows, n_text_max, V)
-                cost, jumps = task.align_batch([h[0] for h in heads], [h[1] for h in heads], n_tok,
+                cost, jumps, plen = task.align_batch([h[0] for h in heads], [h[1] for h in heads], n_tok,
                                                [int(num_frames[i]) // 2 for i in ids], medfilt_width, n_sot, qk_scale)
             finally:
                 task.close()
@@ -189,6 +189,8 @@ def find_alignment_batch(model: "Whisper", tokenizer: Tokenizer, text_tokens: Li
                                   device=model.device)
             probs = _token_probs(logits, padded, tokenizer.eot)
             jumps_h, probs_h = jumps.cpu().numpy(), probs.cpu().numpy()
+            if bool((plen.cpu() < 0).any()):
+                raise ValueError("Unexpected trace[i, j]")          # reference timing.py:77
             if stats is not None:
                 stats["device_s"] = stats.get("device_s", 0.0) + time.perf_counter() - t_start
                 t_start = time.perf_counter()
