@@ -153,7 +153,9 @@ enum {
    * (A/B and tests: the results must agree) — for the self attention / for the cross attention */
   WH_TASK_TWO_LAUNCH_SELF = 2,
   WH_TASK_TWO_LAUNCH_CROSS = 4,
-  /* 8: reserved (development builds of the library only; ignored here) */
+  /* attn.out + the residual add as a launch of its own instead of phase 0 of the fused cross-attention launch (A/B and
+   * tests: bit-identical rows either way) */
+  WH_TASK_TWO_LAUNCH_OUT = 8,
   /* Fault injection for the hand-off protocol of the fused step kernels: every consumer gives up after its FIRST poll, as
    * if its bounded spin had run out.  The step's result is then invalid by construction; wh_task_greedy / wh_task_beam
    * must notice (WH_ERR_HANDOFF internally), move the task to the two-launch kernels and re-run — what the tests check. */
@@ -205,7 +207,8 @@ int wh_task_position(const wh_task *t);
  * also applies attn.out + the residual add.
  * what = 1: number of bounded hand-off spins that ran out in that kernel since the task was created (always 0 on a
  * healthy device; reads device memory, i.e. synchronises `stream`).  what = 4: number of times wh_task_greedy /
- * wh_task_beam re-ran a loop on the two-launch kernels after such a time-out (the answers to 0, 2, 3 are 0 from then on).
+ * wh_task_beam re-ran a loop on the two-launch kernels after such a time-out (the answers to 0, 2, 3, 5 are 0 from then on).
+ * what = 5: 1 when attn.out + the residual add of the self-attention block run as phase 0 of the fused cross-attention launch.
  * Negative on error. */
 int wh_task_info(wh_task *t, int what, void *stream);
 

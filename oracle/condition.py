@@ -17,11 +17,13 @@ state model.py:244 produces and E the embedding so far:
   2. the token class follows a speech-like script (a timestamp, runs of text tokens, timestamp pairs between them;
      the hard filters force most of it), the target y is the best-scoring admissible token of that class that no row
      has emitted yet (for timestamps: among the next few values, so that a row does not run to <|30.00|> at once);
-  3. m ~ U[margin_lo, margin_hi];  E[y] += delta * d / (d . h), d = h minus its projection on the span of the rows'
-     running mean hidden states (a row's hidden states share a large audio-dependent component, cos ~ 0.96 between
-     steps: an edit along h itself would raise y's logit at every other step of the row almost as much, and the
-     boosts would have to outgrow each other; the remainders d are nearly orthogonal, cos 0 +- 0.1), with the smallest
-     delta >= 0 such that, after rounding E[y] to fp16 (both engines and the oracle see the same weights),
+  3. m ~ U[margin_lo, margin_hi];  E[y] += delta * d / (d . h), d = h minus its projection on the span of (a) every
+     EARLIER hidden state of the same row and (b) the other rows' running mean hidden states.  (A row's hidden states
+     share a large audio-dependent component, cos ~ 0.96 between steps, so the best tokens of one step are the
+     runners-up of the row's other steps: an edit along h itself would raise y's logit at every other step of the row
+     almost as much.  With (a) an edit leaves the logits of all earlier steps of its row exactly as they were when
+     their margins were built; (b) keeps it from lifting y in the other rows.)  delta is the smallest value >= 0 such
+     that, after rounding E[y] to fp16 (both engines and the oracle see the same weights),
          logit[y] >= (best other token of its class) + m     and
          logit[y] >= (logsumexp of the timestamps, if y is text | best text token, if y is a timestamp) + m;
   4. y is emitted; its embedding row is never touched again (it is an INPUT of the following steps).
@@ -55,10 +57,34 @@ def _class_script(rng: np.random.Generator, n_steps: int, text_run: Tuple[int, i
 
 def condition_greedy(om: OracleModel, feats: torch.Tensor, initial_tokens: List[int], n_steps: int, r: SamplingRules,
                      seed: int = 0, margin: Tuple[float, float] = (0.3, 3.0), text_run: Tuple[int, int] = (4, 14),
-                     ts_window: int = 12, log=None) -> Dict:
-    """Edits om.sd["decoder.token_embedding.weight"] IN PLACE (see the module docstring) along one greedy pass over
-    `feats` (R, 1500, D).  Returns {"tokens" (R, T0 + n_steps), "rows": edited token ids, "margins": per (step, row) the
-    margin built, "deltas": logit boosts applied}.  The caller re-packs its engines from the same state dict."""
+                     ts_window: int = 12, log=None, passes: int = 3) -> Dict:
+    """Edits om.sd["decoder.token_embedding.weight"] IN PLACE (see the module docstring) for a greedy decode of `n_steps`
+    tokens over `feats` (R, 1500, D).  Pass 1 chooses the tokens and builds the margins; an edit made for a later step can
+    still lift its token in ANOTHER row's earlier steps (rows are only decorrelated through their mean hidden states), so
+    passes 2.. walk the same token sequence again on the weights as they now stand and top the margins up where they fell
+    short (second-order small: the top-ups are a fraction of a logit).  Returns the last pass's {"tokens" (R, T0 +
+    n_steps), "rows": all edited token ids, "margins": per (step, row) the margin at the time the pass left the step,
+    "deltas": logit boosts of that pass, "drawn": the margins asked for}.  The caller re-packs its engines from the state dict
+    and ALWAYS re-decodes with the plain oracle to assert the final margins (`margins_of`)."""
+    res = _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_run, ts_window, log, None)
+    rows = set(res["rows"])
+    for p in range(1, passes):
+        if log is not None:
+            log(f"condition: pass {p + 1} (top-up along the built sequence)")
+        res = _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_run, ts_window, log,
+                              (res["tokens"], res["drawn"]))
+        rows |= set(res["rows"])
+        if log is not None:
+            nz = [d for d in res["deltas"] if d > 0]
+            log(f"condition: pass {p + 1} topped up {len(nz)} of {len(res['deltas'])} decisions, largest {max(res['deltas']):.3f}")
+        if max(res["deltas"]) == 0.0:
+            break
+    res["rows"] = sorted(rows)
+    return res
+
+
+def _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_run, ts_window, log, target) -> Dict:
+    """one walk; target = None (choose tokens, draw margins) or (tokens, drawn margins) of an earlier pass"""
     rng = np.random.default_rng(seed)
     E = om.sd[EMB]
     assert E.dtype == torch.float32 and E.is_contiguous()
@@ -69,16 +95,28 @@ def condition_greedy(om: OracleModel, feats: torch.Tensor, initial_tokens: List[
     used[list(initial_tokens)] = True
     scripts = [_class_script(rng, n_steps, text_run) for _ in range(R)]
     cache = om.new_cache()
-    margins, deltas, rows = [], [], []
+    margins, deltas, rows, drawn = [], [], [], []
     ninf = -np.inf
     mean_sum, mean_n = None, 0
+    hist = [torch.zeros(E.shape[1], 0) for _ in range(R)]         # per row: orthonormal basis of its earlier hidden states
+
+    def grow(Q, v):
+        """append v's component outside span(Q) to the orthonormal basis Q (two Gram-Schmidt passes)"""
+        for _ in range(2):
+            v = v - Q @ (Q.T @ v)
+        n = float(v.norm())
+        return torch.cat([Q, (v / n)[:, None]], 1) if n > 1e-3 else Q
+
     with torch.no_grad():
         for i in range(n_steps):
             h_seq = om.decoder_hidden(tokens if i == 0 else tokens[:, -1:], feats, cache).float()             # (R, T, D)
             h_all = h_seq[:, -1]                                                                               # (R, D)
             mean_sum = h_seq.sum(1) if mean_sum is None else mean_sum + h_all
             mean_n += h_seq.shape[1]
-            Q, _ = torch.linalg.qr((mean_sum / mean_n).T)           # (D, R): orthonormal basis of the rows' running means
+            means = mean_sum / mean_n                               # (R, D) running mean hidden state of every row
+            for k in range(R):                                      # prompt positions count as earlier hidden states
+                for t in range(h_seq.shape[1] - 1):
+                    hist[k] = grow(hist[k], h_seq[k, t])
             logits_all = h_all @ E.T                                                                           # (R, V)
             nxt = torch.empty(R, dtype=torch.int64)
             step_edits: List[int] = []
@@ -97,9 +135,11 @@ def condition_greedy(om: OracleModel, feats: torch.Tensor, initial_tokens: List[
                 else:
                     text_ok, ts_ok = bool(torch.isfinite(lg[:TB]).any()), bool(torch.isfinite(lg[TB:]).any())
                     text_free = free[:TB]
-                y = None
+                y = int(target[0][k, len(initial_tokens) + i]) if target is not None else None
                 pair_open = TB is not None and len(sampled) >= 2 and sampled[-1] >= TB and sampled[-2] < TB
-                if ts_ok and (not text_ok or scripts[k][i] or pair_open):      # pair_open: timestamps come in pairs
+                if y is not None:
+                    pass
+                elif ts_ok and (not text_ok or scripts[k][i] or pair_open):    # pair_open: timestamps come in pairs
                     cand = torch.nonzero(torch.isfinite(free[TB:]))[:ts_window, 0]
                     if len(cand):
                         y = TB + int(cand[free[TB:][cand].argmax()])
@@ -109,7 +149,8 @@ def condition_greedy(om: OracleModel, feats: torch.Tensor, initial_tokens: List[
                 if y is None:
                     assert text_ok and bool(torch.isfinite(text_free).any()), (k, i)
                     y = int(text_free.argmax())
-                m = float(rng.uniform(*margin))
+                m = float(rng.uniform(*margin)) if target is None else float(target[1][i * R + k])
+                drawn.append(m)
                 others = lg.clone()
                 others[y] = ninf
                 if TB is None:
@@ -125,7 +166,13 @@ def condition_greedy(om: OracleModel, feats: torch.Tensor, initial_tokens: List[
                 have = float(lg[y])
                 boost = 0.0
                 if need > have:
-                    d = h - Q @ (Q.T @ h)
+                    Qk = hist[k]
+                    for j in range(R):
+                        if j != k:
+                            Qk = grow(Qk, means[j])
+                    d = h
+                    for _ in range(2):
+                        d = d - Qk @ (Qk.T @ d)
                     u = d / float(d @ h)
                     base = E[y].clone()
                     boost = need - have
@@ -140,6 +187,7 @@ def condition_greedy(om: OracleModel, feats: torch.Tensor, initial_tokens: List[
                     step_edits.append(y)
                     rows.append(y)
                     have = float(E[y] @ h)
+                hist[k] = grow(hist[k], h)
                 used[y] = True
                 nxt[k] = y
                 margins.append(have - (need - m))
@@ -149,7 +197,7 @@ def condition_greedy(om: OracleModel, feats: torch.Tensor, initial_tokens: List[
                 mm = np.asarray(margins[-32 * R:])
                 log(f"condition: step {i + 1}/{n_steps}, margins of the last steps min {mm.min():.2f} median "
                     f"{np.median(mm):.2f}, boost median {np.median(deltas[-32 * R:]):.2f} max {max(deltas[-32 * R:]):.2f}")
-    return {"tokens": tokens, "rows": sorted(set(rows)), "margins": margins, "deltas": deltas}
+    return {"tokens": tokens, "rows": sorted(set(rows)), "margins": margins, "deltas": deltas, "drawn": drawn}
 
 
 def margins_of(dec: Dict) -> Dict:

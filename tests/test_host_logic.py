@@ -804,8 +804,12 @@ def test_kv_cache_hooks_surface(monkeypatch):
     assert task.closed and mm._TASK_KEY not in cache
     assert calls == [("create", 2, 2, 448), ("audio", (2, 1500, 384)), ("prefill", (4, 3)), ("step", (4,)),
                      ("prefill", (4, 2)), ("close",)]
-    with pytest.raises(NotImplementedError):
-        model.decoder(toks, xa, kv_cache={"foreign": torch.zeros(1)})
+    # a plain dict nobody hooked (reference model.py:96-104, 233-249: none of its modules is in it, so every key / value
+    # is computed from the tokens passed; only the position offset is read from the first entry): an ordinary pass ...
+    assert model.decoder(toks, xa, kv_cache={}).shape == (4, 3, 7)
+    assert model.decoder(toks, xa, kv_cache={"note": torch.zeros(2, 0, 8)}).shape == (4, 3, 7)
+    with pytest.raises(NotImplementedError):                 # ... and a non-zero offset without the earlier keys is refused
+        model.decoder(toks, xa, kv_cache={"foreign": torch.zeros(2, 5, 8)})
     user = {"note": 1}
     cache2, hooks2 = model.install_kv_cache_hooks(user)
     assert cache2 is not user and cache2["note"] == 1                                   # copied, as the reference does
@@ -844,6 +848,26 @@ def test_api_surface_matches_reference(ref):
                  "detect_language", "forward"):
         assert hasattr(m, attr), attr
     assert m.is_multilingual and m.num_languages == 99 and m.device == torch.device("cpu")
+    # the nn.Module surface a caller of the reference touches on the model object (model.py:252: Whisper is an nn.Module)
+    for attr in ("parameters", "named_parameters", "state_dict", "load_state_dict", "half", "float", "to", "cuda", "cpu",
+                 "eval", "train", "requires_grad_"):
+        assert hasattr(ref.model.Whisper, attr) and callable(getattr(m, attr)), attr
+    rdims = ref.ModelDimensions(**fm.dims.__dict__)
+    theirs_sd = ref.model.Whisper(rdims).state_dict()
+    from whisper_amd.model import expected_state_shapes
+    want = expected_state_shapes(mine.ModelDimensions(**fm.dims.__dict__))
+    assert {k: tuple(v.shape) for k, v in theirs_sd.items()} == want              # names and shapes = the reference's
+    res = m.load_state_dict(theirs_sd)                                           # a reference state dict loads as is
+    assert res.missing_keys == [] and res.unexpected_keys == []
+    assert [k for k, _ in m.named_parameters()] == [k for k, _ in ref.model.Whisper(rdims).named_parameters()]
+    assert sum(p.numel() for p in m.parameters()) == sum(p.numel() for p in ref.model.Whisper(rdims).parameters())
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in theirs_sd.items() if k != "decoder.ln.weight"})           # strict: missing key
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({**theirs_sd, "decoder.ln.weight": torch.zeros(3)})                          # size mismatch
+    loose = m.load_state_dict({"decoder.ln.weight": theirs_sd["decoder.ln.weight"], "extra": torch.zeros(1)}, strict=False)
+    assert loose.unexpected_keys == ["extra"] and "decoder.ln.bias" in loose.missing_keys
+    assert m.half() is m and m._half and m.float() is m and not m._half and m.eval() is m and m.train(False) is m
     # alignment heads: default = upper half of the decoder layers (model.py:270-276); dumps decode like the reference's
     dense = m.alignment_heads.to_dense()
     assert dense.shape == (fm.dims.n_text_layer, fm.dims.n_text_head) and bool(dense[fm.dims.n_text_layer // 2:].all())

@@ -9,6 +9,8 @@ FC1 / FC2 GEMVs, 8-wave QKV, 3-way split cross attention, 256-thread merge prolo
 
 All calls go through libwhisper_hip.so.  Tolerances are written at each assert.
 """
+import time
+
 import numpy as np
 import pytest
 import torch
@@ -73,6 +75,8 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B, T0):
     projection and attention as separate launches (WH_TASK_TWO_LAUNCH_*), prefill + 12 steps on the same tokens, ragged
     rows (per-row lag) included:
       * the fused SELF attention is bit-identical (same products, same order of sums);
+      * `attn.out` + the residual add as phase 0 of the fused cross-attention launch (round 4) against the same projection as
+        its own launch (WH_TASK_TWO_LAUNCH_OUT): bit-identical;
       * the fused CROSS attention reproduces q bit for bit and sums each key range with 8 instead of 4 waves' partial
         sums: fp32 sums in another order flip the fp16 rounding of an attention output now and then (1 ulp), which the
         later layers and steps carry on — the logits agree at the level of the fp16 engine's own rounding noise
@@ -89,10 +93,11 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B, T0):
     toks = torch.randint(0, dims.n_vocab, (B, T0 + 12), generator=g).to(gpu_device)
     lag = [(3 * i) % 5 for i in range(B)] if B > 1 else None           # ragged prompts: rows sit at their own positions
 
-    def run(two_self, two_cross):
-        task = hip.HipTask(model, B, 1, max(8, T0), two_launch_self=two_self, two_launch_cross=two_cross)
+    def run(two_self, two_cross, two_out=False):
+        task = hip.HipTask(model, B, 1, max(8, T0), two_launch_self=two_self, two_launch_cross=two_cross, two_launch_out=two_out)
         try:
             assert task.fused_self_attention == (not two_self) and task.fused_cross_attention == (not two_cross)
+            assert task.fused_out_projection == (not two_cross and not two_out)
             task.set_audio(feats)
             if lag is not None:
                 task.set_lag(lag)
@@ -108,6 +113,11 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B, T0):
     assert torch.isfinite(plain).all()
     fused_self = run(False, True)
     assert torch.equal(fused_self, plain), (fused_self - plain).abs().max().item()
+    # attn.out + residual as phase 0 of the fused cross-attention launch (x' handed from the D / 8 producer workgroups to their
+    # own LayerNorm through write-through stores + flags): the same rows, bit for bit, as with the projection as its own launch
+    sep = run(False, False, two_out=True)
+    assert torch.equal(run(False, False), sep), (run(False, False) - sep).abs().max().item()
+    assert torch.equal(run(True, False), run(True, False, two_out=True))
     for out in (run(True, False), run(False, False)):                 # fused cross attention alone, and both
         d = (out - plain).abs()
         assert d.max().item() < 2e-2 and (d.double() ** 2).mean().sqrt().item() < 2e-3, (d.max().item(), (d.double() ** 2).mean().sqrt().item())
@@ -588,6 +598,143 @@ def test_large_v3_full_depth_vs_oracle(large_v3, gpu_device):
     assert full >= 7, report            # observed: all 8 rows equal over the 32 steps; one near-tie row of slack
     distinct = len({int(x) for x in want16["tokens"][:, len(init):].flatten()})
     assert distinct >= 40                                                       # the decode is not degenerate
+
+
+def test_fused_step_kernels_under_contention(large_v3, gpu_device):
+    """The hand-off inside the fused step launches (csrc/xattn.hip) relies on nothing HIP promises about dispatch order
+    (MI355X_MICROARCH.md "Workgroup dispatch": order, timing and placement are undefined): every spin is bounded, a spin
+    that runs out is counted, and wh_task_greedy then re-runs the loop on the two-launch kernels.  The forced-time-out tests
+    prove the accounting; THIS test proves the protocol on a genuinely contended device: while a second stream keeps all
+    256 CUs busy with large GEMMs (torch / rocBLAS — other workgroups competing for the same CUs' wave slots, LDS and
+    memory queues, dispatched between and beside the step's own workgroups), the fused greedy decode of the large-v3 engine
+    (8 rows, 64 steps = 12 288 fused launches with a hand-off each) must return EXACTLY the ids and log-probabilities of a
+    task that never uses the fused kernels, decoded on an idle device.  Hand-off time-outs / fallbacks under contention are
+    legal (that is what the fallback is for) and are reported, not asserted to be zero; the answer must not change."""
+    from conftest import write_report
+    fd = large_v3
+    dims = fd.dims
+    eng = fd.engine(hip.WH_F16)
+    n_steps = 64
+    tok, init, params, rules, mask = _greedy_setup(dims, n_steps, gpu_device, suppress_eot=True)
+    T0 = len(init)
+    feats = _offset_feats(dims, 8, seed=9).to(gpu_device).half().contiguous()
+
+    def greedy(task):
+        task.set_audio(feats)
+        tokens = torch.zeros(8, T0 + n_steps + 1, dtype=torch.int64, device=gpu_device)
+        tokens[:, :T0] = torch.tensor(init, device=gpu_device)
+        n, lp, _ = task.greedy(tokens, params, 0, tok.no_speech)
+        return n, tokens.cpu(), lp.cpu()
+
+    ref = hip.HipTask(eng, 8, 1, 8, two_launch_self=True, two_launch_cross=True)
+    try:
+        want = greedy(ref)
+    finally:
+        ref.close()
+
+    side = torch.cuda.Stream(device=gpu_device)
+    a = torch.randn(8192, 8192, device=gpu_device, dtype=torch.float16)
+    b = torch.randn(8192, 8192, device=gpu_device, dtype=torch.float16)
+    c = torch.empty(8192, 8192, device=gpu_device, dtype=torch.float16)
+    torch.cuda.synchronize(gpu_device)
+    report = {"model": "large-v3 fp16, 8 rows x 64 steps, fused step kernels", "rounds": []}
+    for load in (0, 400, 1600):                       # GEMMs queued on the side stream before the decode starts (~1 ms each)
+        task = hip.HipTask(eng, 8, 1, 8)
+        try:
+            assert task.fused_cross_attention and task.fused_self_attention
+            with torch.cuda.stream(side):
+                for _ in range(load):
+                    torch.matmul(a, b, out=c)
+                busy = torch.cuda.Event()
+                busy.record(side)
+            t0 = time.perf_counter()
+            got = greedy(task)
+            dt = time.perf_counter() - t0
+            still_busy = not busy.query()             # the side stream was still running when the decode finished
+            timeouts, fallbacks = task.handoff_timeouts(), task.handoff_fallbacks
+            report["rounds"].append({"side_gemms": load, "decode_ms": round(dt * 1e3, 1), "side_stream_outlasted_decode": still_busy,
+                                     "handoff_timeouts": timeouts, "handoff_fallbacks": fallbacks})
+            assert got[0] == want[0] and torch.equal(got[1], want[1]), (load, timeouts, fallbacks)
+            if fallbacks == 0:                        # the fused kernels produced it: cross attention sums in another order
+                assert float((got[2] - want[2]).abs().max()) < 0.5
+            else:                                     # re-run on the two-launch kernels: bit-identical
+                assert torch.equal(got[2], want[2])
+        finally:
+            task.close()
+            torch.cuda.synchronize(gpu_device)
+    print("contention report:", report)
+    write_report("handoff_contention.json", report)
+    assert report["rounds"][-1]["side_stream_outlasted_decode"], "the side load ended before the decode did: not a contention test"
+
+
+def _conditioned_copy(fd):
+    """fd's weights with a private copy of the tied embedding (oracle/condition.py edits it in place) + the oracle on them"""
+    from oracle import condition
+    sd2 = dict(fd.sd)
+    sd2[condition.EMB] = fd.sd[condition.EMB].clone()
+    return sd2, oracle.OracleModel(fd.dims, sd2)
+
+
+@pytest.mark.parametrize("name,R,text_run", [("large-v3", 8, (4, 14)), ("turbo", 32, (10, 24))])
+def test_conditioned_checkpoint_token_exact_224_steps(name, R, text_run, large_v3, turbo, gpu_device):
+    """The parity statement without an escape hatch.  On seeded random-init weights the top two
+    of ~50 000 logits lie hundredths apart every few hundred steps, so NO reduced-precision engine can match the fp32
+    reference's ids over 224 steps, and the tests above fall back on a near-tie rule.  Here the checkpoint is
+    margin-conditioned (oracle/condition.py: rows of the tied embedding of the tokens the decode emits are moved along the
+    hidden state that emits them until the oracle's arg-max — and the timestamp-mass rule — are decided by a drawn
+    margin, as a trained model's are); the plain oracle then re-decodes and the margins are ASSERTED on its own filtered
+    logits: min >= 0.2, median >= 1.0 over rows x 224 steps.  On that checkpoint
+      * the fp16 engine (what bench.py times: fused step kernels, hipGraph, device-side sampler) must reproduce the fp32
+        oracle's token ids for EVERY row and ALL 224 steps — no near-tie rule, no slack;
+      * so must the fp32 strict engine, and its sum_logprobs agree to 2e-2 over 224 tokens.
+    large-v3 (32 + 32 layers) at the bench's 8 rows; turbo dims (32 + 4) at the 32 rows of BASELINE configs[4].
+    The measured fp16 logit error along the path is written to the parity report next to the margins."""
+    from conftest import write_report
+    from oracle import condition
+    fd = large_v3 if name == "large-v3" else turbo
+    dims = fd.dims
+    n_steps = 224
+    tok, init, params, rules, mask = _greedy_setup(dims, n_steps, gpu_device, suppress_eot=True)
+    T0 = len(init)
+    feats = _offset_feats(dims, R, seed=12)
+    sd2, om2 = _conditioned_copy(fd)
+    notes = []
+    built = condition.condition_greedy(om2, feats, init, n_steps, rules, seed=5, margin=(0.35, 3.0), text_run=text_run,
+                                       log=notes.append)
+    with torch.no_grad():
+        want = oracle.greedy_decode(om2, feats, init, n_steps, rules, keep_logits=True)
+    mg = condition.margins_of(want)
+    print("conditioned", name, mg, notes[-3:])
+    assert torch.equal(want["tokens"], built["tokens"])                  # the plain oracle decodes what was built
+    assert mg["min"] >= 0.2 and mg["median"] >= 1.0 and mg.get("rule_min", 1.0) >= 0.2, mg
+    n_ts = int((want["tokens"][:, T0:] >= tok.timestamp_begin).sum())
+    distinct = len({int(x) for x in want["tokens"][:, T0:].flatten()})
+    assert distinct == R * n_steps and n_ts >= 2 * R                     # every decision is its own token; timestamps occur
+
+    rep = {"model": f"{name}, seeded weights + margin-conditioned tied embedding ({len(built['rows'])} rows edited)",
+           "rows": R, "steps": n_steps, "oracle_margins": mg, "timestamp_tokens": n_ts, "engines": {}}
+    for dt, label in ((hip.WH_F16, "fp16"), (hip.WH_F32, "fp32")):
+        eng = hip.HipModel(dims, dt, hip.pack_weights(sd2, dims, dt, gpu_device))
+        try:
+            n, got, sum_lp, _ = _run_greedy(eng, feats.to(gpu_device, eng.torch_dtype), init, params, n_steps, gpu_device, tok)
+            first = [oracle.first_divergence(got[k, T0:].tolist(), want["tokens"][k, T0:].tolist()) for k in range(R)]
+            equal = sum(1 for t in first if t is None)
+            lp_err = float(np.abs(sum_lp.numpy() - np.asarray(want["sum_logprobs"])).max())
+            rep["engines"][label] = {"rows_equal_all_steps": equal, "first_divergence": first, "max_sum_logprob_err": lp_err}
+            if dt == hip.WH_F16:
+                # the fp16 engine's logit error on THIS checkpoint, teacher-forced along the path (first rows, T0 + 8 positions)
+                fd2 = type("FD", (), {"om": om2, "device": gpu_device, "engine": staticmethod(lambda _dt: eng)})()
+                mx, rms, _ = _tf_error(fd2, dt, feats[:4], want["tokens"][:4, : T0 + 8].contiguous(), T0)
+                rep["engines"][label]["teacher_forced_max_abs_dlogit"] = mx
+                rep["engines"][label]["teacher_forced_rms_dlogit"] = rms
+            assert n == T0 + n_steps
+            assert equal == R, (label, first)                            # token-id exact: every row, all 224 steps
+            assert lp_err < (2e-2 if dt == hip.WH_F32 else 5.0), (label, lp_err)
+        finally:
+            eng.drop_cached_tasks()
+            del eng
+            torch.cuda.empty_cache()
+    write_report(f"conditioned_{name.replace('-', '_')}.json", rep)
 
 
 @pytest.mark.parametrize("name", ["w512", "w768", "w1024"])

@@ -121,7 +121,8 @@ int main(int argc, char** argv) {
   Case cases[] = {{"cross: two launches (LN->q + attention)", 0}, {"cross: fused xattn8", 1},
                   {"self:  two launches (LN->qkv + attention)", 2}, {"self:  fused sattn8", 3},
                   {"attn.out + residual alone", 4}, {"pair: fused sattn8, then attn.out", 5},
-                  {"pair: attn.out, then fused xattn8", 6}};
+                  {"pair: attn.out, then fused xattn8", 6},
+                  {"ONE launch: attn.out as phase 0 of xattn8", 7}};
   for (const Case& c : cases) {
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipMemset(d_probe, 0, 4096 * 8 * 8));
@@ -135,6 +136,11 @@ int main(int argc, char** argv) {
       if (c.kind == 4) ok = ok && out_proj(i);
       if (c.kind == 5) { whk::SAttnArgs sa = sargs(i); sa.probe = nullptr; ok = ok && whk::launch_sattn8(sa, st) == hipSuccess && out_proj(i); }
       if (c.kind == 6) { whk::XAttnArgs xa = xargs(i); xa.probe = nullptr; ok = ok && out_proj(i) && whk::launch_xattn8(xa, st) == hipSuccess; }
+      if (c.kind == 7) {
+        whk::XAttnArgs xa = xargs(i);
+        xa.att_in = att; xa.out_w = Wo + (size_t)(i % L) * D * D; xa.out_b = bias; xa.x_io = xf; xa.pflags = og;
+        ok = ok && whk::launch_xattn8(xa, st) == hipSuccess;
+      }
     }
     hipLaunchKernelGGL(add_int_k, dim3(1), dim3(1), 0, st, d_tick, N);
     CK(hipStreamEndCapture(st, &g));
@@ -147,13 +153,13 @@ int main(int argc, char** argv) {
       if (rep > 1 && ms < best) best = ms;
     }
     int err = 0; CK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
-    printf("%-44s %6.2f us per link%s (pos %d, hand-off timeouts %d)\n", c.name, best * 1e3f / N, c.kind >= 5 ? " (= per PAIR)" : "", pos, err);
-    if (c.kind == 1 || c.kind == 3) {
-      const int nwg = c.kind == 1 ? S * H * R : 3 * D / 8;
+    printf("%-46s %6.2f us per link%s (pos %d, hand-off timeouts %d)\n", c.name, best * 1e3f / N, c.kind >= 5 ? " (= per PAIR)" : "", pos, err);
+    if (c.kind == 1 || c.kind == 3 || c.kind == 7) {
+      const int nwg = c.kind != 3 ? S * H * R : 3 * D / 8;
       std::vector<long long> p((size_t)nwg * 8);
       CK(hipMemcpy(p.data(), d_probe, p.size() * 8, hipMemcpyDeviceToHost));
-      const int nprod = c.kind == 1 ? D / 8 : nwg;              // producers: first D/8 (cross) / all (self)
-      const int cons0 = c.kind == 1 ? 0 : nwg - H * R;           // consumers: all (cross) / last H*R (self)
+      const int nprod = c.kind != 3 ? D / 8 : nwg;              // producers: first D/8 (cross) / all (self)
+      const int cons0 = c.kind != 3 ? 0 : nwg - H * R;           // consumers: all (cross) / last H*R (self)
       // stamps are wall_clock64() (100 MHz, chip-wide): absolute times from the first workgroup's entry, in microseconds
       long long t0 = 0;
       for (int w = 0; w < nwg; ++w) { const long long e = p[(size_t)w * 8]; if (e && (!t0 || e < t0)) t0 = e; }
@@ -189,6 +195,11 @@ int main(int argc, char** argv) {
           snprintf(nm, sizeof(nm), "  entry, wg third %d", part); row(nm, e3);
           snprintf(nm, sizeof(nm), "  published, third %d", part); row(nm, p3);
         }
+      }
+      if (c.kind == 7) {
+        std::vector<long long> p0;
+        for (int w = 0; w < D / 8; ++w) { const long long* q = &p[(size_t)w * 8]; if (q[0] && q[3]) p0.push_back(q[3] - t0); }
+        row("attn.out rows published", p0);
       }
       row("entry", ent); row("q published", pub); row("q fetched", fetch); row("K/V requested", kvis);
       row("past hand-off barrier", bar); row("scores done", sco); row("stored", end);

@@ -304,7 +304,8 @@ struct wh_task {
   unsigned long long* sq_gran;   // the same for self attention + QKV projection (q, new k, new v)
   unsigned long long* so_gran;   // ... and for the attention outputs handed to attn.out inside the same launch
   float* x2;                     // second residual-stream buffer: the fused self-attention launch reads x and writes x2 (or back)
-  bool fused_xattn, fused_sattn, fused_out;   // fused_out: attn.out + residual inside the self-attention launch
+  bool fused_xattn, fused_sattn, fused_out;   // fused_out: attn.out + residual inside the self-attention launch (dev builds)
+  bool fused_xout;               // attn.out + residual as phase 0 of the fused cross-attention launch (xattn.hip, OUT0)
   int err_seen;                  // hand-off timeouts already reported to a caller
   size_t total;
 };
@@ -417,6 +418,8 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
                    xattn_supported(m->d.n_text_state, m->d.n_text_head, t->R, t->G, m->d.n_audio_ctx, t->cross_splits);
   t->fused_sattn = !(flags & WH_TASK_TWO_LAUNCH_SELF) && m->dtype == WH_F16 && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) && t->self_splits == 1 &&
                    sattn_supported(m->d.n_text_state, m->d.n_text_head, t->R, m->d.n_text_ctx);
+  // attn.out + residual as phase 0 of the cross-attention launch: its input must be plain attention rows (one key split)
+  t->fused_xout = t->fused_xattn && t->self_splits == 1 && !(flags & WH_TASK_TWO_LAUNCH_OUT);
   {
     // attn.out inside the self-attention launch: built, bit-identical, and slower than its own launch (the gather of 160
     // (row, head) outputs by the projection workgroups costs ~4 us after the attention, and its polling slows the
@@ -456,6 +459,7 @@ extern "C" int wh_task_info(wh_task* t, int what, void* stream) {
   if (what == 0) return t->fused_xattn ? 1 : 0;
   if (what == 2) return t->fused_sattn ? 1 : 0;
   if (what == 3) return t->fused_out ? 1 : 0;
+  if (what == 5) return t->fused_xout ? 1 : 0;
   if (what == 4) return t->handoff_fallbacks;
   if (what == 1) {                       // hand-off timeouts of the fused cross attention since the task was created
     if (t->needs_reset) return 0;
@@ -738,7 +742,7 @@ extern "C" int wh_task_prefill(wh_task* t, const int64_t* tokens, int64_t token_
 
 static inline void* cross_layer(const wh_task* t, int l);
 // arguments of the fused LN -> cross query -> cross attention launch of layer l (xattn.hip)
-static XAttnArgs xattn_args(const wh_task* t, int l, int epoch, const float* x_in) {
+static XAttnArgs xattn_args(const wh_task* t, int l, int epoch, float* x_in, bool with_out = false) {
   const wh_model* m = t->m;
   const wh_dims& d = m->d;
   const int D = d.n_text_state, Ta = d.n_audio_ctx;
@@ -750,6 +754,9 @@ static XAttnArgs xattn_args(const wh_task* t, int l, int epoch, const float* x_i
   a.Tk = Ta; a.splits = t->cross_splits;
   a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
   a.qg = t->xq_gran; a.d_tick = t->d_tick; a.epoch = epoch; a.layer = l; a.err = t->d_err; a.mode = fused_mode(0) | ((t->flags & WH_TASK_EXPIRE_HANDOFFS) ? 4 : 0);
+  if (with_out) {      // phase 0: x_in += attn.out(t->att) + bias, in place, before the LayerNorm of this launch
+    a.att_in = t->att; a.out_w = L.out_w; a.out_b = L.out_b; a.x_io = x_in; a.pflags = t->so_gran;
+  }
   return a;
 }
 
@@ -814,6 +821,7 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
       HIPCHK(launch_attn_decode(a, m->dtype, s));
     }
     }
+    if (t->fused_xout) out_done = true;       // attn.out + residual run as phase 0 of the cross-attention launch below
     if (!out_done) {
     memset(&g, 0, sizeof(g));
     if (t->self_splits > 1) {
@@ -828,7 +836,7 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
     if (t->fused_xattn) {
       // LN -> cross query -> cross attention as ONE launch: the K/V stream starts at kernel entry, the projection runs
       // under it and reaches the K/V waves through tagged granules (xattn.hip)
-      HIPCHK(launch_xattn8(xattn_args(t, l, 0, xc), s));
+      HIPCHK(launch_xattn8(xattn_args(t, l, 0, xc, t->fused_xout), s));
     } else {
     // LN -> cross query
     memset(&g, 0, sizeof(g));
@@ -974,7 +982,7 @@ extern "C" int wh_task_rearrange(wh_task* t, const int32_t* source_indices, void
 // wait for nothing — and the caller re-runs the loop from the prompt, which is still in place: the prefill starts at
 // position 0 again, the cross K/V and the rows' lags are untouched.
 static int handoff_fallback(wh_task* t, hipStream_t s) {
-  t->fused_xattn = t->fused_sattn = t->fused_out = false;
+  t->fused_xattn = t->fused_sattn = t->fused_out = t->fused_xout = false;
   for (int i = 0; i < 2; ++i) {
     if (t->graph_exec[i]) { (void)hipGraphExecDestroy(t->graph_exec[i]); t->graph_exec[i] = nullptr; }
     if (t->graph[i]) { (void)hipGraphDestroy(t->graph[i]); t->graph[i] = nullptr; }
@@ -1270,9 +1278,11 @@ static int bench_issue(wh_task* t, int kind, int iters, double* bytes_per_launch
       case 1: if (t->fused_xattn) {
         // the fused launch: the tag of launch i is unique within the graph (epoch = i); one add behind the chain keeps
         // replays apart
-        HIPCHK(launch_xattn8(xattn_args(t, l, i, t->x), s));
+        // (with attn.out + residual as its phase 0 the launch also streams that D x D matrix and rewrites t->x in place:
+        // the values drift over the chain, the timing does not depend on them)
+        HIPCHK(launch_xattn8(xattn_args(t, l, i, t->x, t->fused_xout), s));
         if (i == iters - 1) HIPCHK(launch_add_int(t->d_tick, iters, s));
-        bytes = (double)t->B * 2.0 * Ta * D * es + (double)D * D * es;
+        bytes = (double)t->B * 2.0 * Ta * D * es + (t->fused_xout ? 2.0 : 1.0) * D * D * es;
       } else {
         DecAttnArgs a; memset(&a, 0, sizeof(a));
         a.q = t->qbuf; a.q_ld = D;

@@ -164,6 +164,10 @@ struct XAttnArgs {
   unsigned long long* qg; const int* d_tick; int epoch, layer;
   int* err;                                       // counts bounded spins that ran out (never on a healthy device)
   int mode;                                       // bit 0: granules fetched through the scalar memory path (fused_mode())
+  // optional phase 0 (out_w != null): x_io[r][:] += out_w . att_in[r] + out_b (attn.out + residual, model.py:153) by the
+  // producer workgroups before their LayerNorm; x_io == xf (in place), pflags = D / 8 eight-byte flag words (zero-initialised
+  // once; tags never repeat), att_in = fp16 [R][D] attention rows of the self attention
+  const void* att_in; const void* out_w; const float* out_b; float* x_io; unsigned long long* pflags;
   WH_PROBE_FIELD
 };
 int fused_mode(int kind);

@@ -229,6 +229,86 @@ __device__ __forceinline__ void aux_barrier(int* cnt, int target, int lane, int*
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// ---- phase 0 of the cross-attention launch (OUT0): `attn.out` + the residual add (model.py:153) by the producers' auxiliary
+// waves, handed to the LayerNorm of the SAME launch -------------------------------------------------------------------------
+// The output projection of the self attention used to be a launch of its own between the two attention launches (3.3 MB of
+// weights: 3.85 us per link, most of it boundary and ramp).  Its weights do not depend on anything, and the cross
+// attention's 61 MB K/V stream is requested at entry and takes ~10 us to land whatever the auxiliary waves do meanwhile —
+// so the projection moves UNDER that stream: producer workgroup g (g < D / 8) computes x'[:, 8g .. 8g+8) = x + W_out att + b
+// for all rows with the MFMA diagonal tile (PRO_PLAIN form of gemv8_kernel: same fragments, same order of sums — the rows
+// are bit-identical to the separate launch), stores them IN PLACE with write-through (sc1) stores, drains, and raises its
+// flag {tag}; every producer then waits for all D / 8 flags (bounded), reads the finished rows with L1-bypassing loads
+// (MI355X_MICROARCH.md, valid forms: sc1 payload -> vmcnt(0) -> sc1 flag; sc1 loads after the poll) and goes on with the
+// LayerNorm + query projection as before.  Producers wait for producers only, and those are the first workgroups of the
+// grid: on an idle device all are resident at once; if some are not (a shared GPU), the bounded polls run out, the count
+// in *err moves and the caller re-runs the step on the two-launch kernels, as for every other hand-off here.
+__device__ __forceinline__ float4v load_f4_sc(const void* p) {
+  float4v v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// requests of phase 0: the wave's 5 wave-loads of W_out rows 8g .. 8g+7 (non-temporal) and the matching fragments of the
+// attention rows (fp16 [R][D], written by the previous launch: plain loads); K blocks beyond D / 64 are zeroed at use
+__device__ __forceinline__ void out0_issue(int aw, int lane, int g, const void* Wo, const void* att, int K, int R,
+                                           half8v (&wo)[P_NU], half8v (&xo)[P_NU]) {
+  const int nblk = K >> 6;
+  const int idx = lane & 7, koff = ((lane >> 3) & 1) * 32 + (lane >> 4) * 8;
+  const uint32_t w_off = ((uint32_t)(g * 8 + idx) * (uint32_t)K + (uint32_t)koff) * 2u;
+  const uint32_t x_off = ((uint32_t)(idx < R ? idx : R - 1) * (uint32_t)K + (uint32_t)koff) * 2u;
+#pragma unroll
+  for (int u = 0; u < P_NU; ++u) {
+    int blk = aw + P_KS * u; if (blk > nblk - 1) blk = nblk - 1;
+    wo[u] = WH_WEIGHT_LOAD((const half8v*)((const char*)Wo + (size_t)blk * 128 + w_off));
+  }
+#pragma unroll
+  for (int u = 0; u < P_NU; ++u) {
+    int blk = aw + P_KS * u; if (blk > nblk - 1) blk = nblk - 1;
+    xo[u] = *(const half8v*)((const char*)att + (size_t)blk * 128 + x_off);
+  }
+}
+
+// 5 MFMAs, the two meaningful diagonal blocks summed, the wave's 8 x 8 partial sums to pred[aw][feature][row]
+__device__ __forceinline__ void out0_mfma(int aw, int lane, int K, const half8v (&wo)[P_NU], half8v (&xo)[P_NU], float (*pred)[8][8]) {
+  const int nblk = K >> 6;
+  const bool diag = (lane >> 5) == ((lane >> 3) & 1);
+  float4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < P_NU; ++u) {
+    if (!(aw + P_KS * u < nblk)) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xo[u][e] = (half_t)0.f;
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo[u], xo[u], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float z = diag ? acc[e] : 0.f;
+    z += lane_xor8(z);
+    float p, q; lane_swap32(z, p, q);
+    acc[e] = p + q;
+  }
+  if (lane < 32 && (lane & 15) < 8) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pred[aw][4 * (lane >> 4) + e][lane & 7] = acc[e];
+  }
+}
+
+// rows aw, aw + 4 of the finished residual stream, row-contiguous, past the L1 (the producers stored write-through)
+__device__ __forceinline__ void out0_rows(int aw, int lane, int K, const float* x, int64_t x_ld, int R, float4v (&v)[2][P_NU]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = aw + 4 * i;
+    const char* src = (const char*)x + (size_t)(row < R ? row : R - 1) * (size_t)x_ld * 4;
+#pragma unroll
+    for (int j = 0; j < P_NU; ++j) {
+      int k = (j * 64 + lane) * 4; if (k > K - 4) k = K - 4;
+      v[i][j] = load_f4_sc(src + (uint32_t)k * 4u);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Both kernels below are written as TWO role bodies under one wave-uniform branch — the KV waves and the auxiliary waves
 // never share a basic block — so that the register allocator sees each role's pressure on its own (the K/V tile of the
 // KV waves is 128 VGPRs; merged control flow carried it through the projection code: 209 VGPRs, one workgroup per CU).
@@ -240,7 +320,7 @@ __device__ __forceinline__ void aux_barrier(int* cnt, int target, int lane, int*
 // cannot retire K registers into scores early), and 16 rounds (156 VGPRs) would leave room for one workgroup per CU only:
 // with 8 rounds the kernel needs 80 VGPRs, two 12-wave workgroups fit a CU and all 480 workgroups of large-v3 x 8 rows are
 // resident at once — which is what keeps 61 MB of loads in flight.
-template <int NL>
+template <int NL, bool OUT0>
 __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
   pin_kernargs(a);
   constexpr int WAVES = 8;               // KV waves (waves 4 .. 11); the auxiliary waves are waves 0 .. 3: launched first
@@ -277,6 +357,76 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
     if (producer) {
       half8v wa[P_NU];
       float4v xv[2][P_NU];
+      int bar = 0;                                   // cumulative target of the auxiliary waves' arrival counter
+      if constexpr (OUT0) {
+        // ---- phase 0: x' = x + W_out att + b for feature group `wgid`, all rows; requests first, the query weights behind
+        half8v wo[P_NU], xo[P_NU];
+        out0_issue(aw, lane, wgid, a.out_w, a.att_in, D, a.R, wo, xo);
+        float ob = 0.f, ores = 0.f;
+        if (aw == 0) {                               // lane = 8 row + feature
+          ob = a.out_b[wgid * 8 + (lane & 7)];
+          ores = a.x_io[(int64_t)((lane >> 3) < a.R ? (lane >> 3) : a.R - 1) * a.xf_ld + wgid * 8 + (lane & 7)];
+        }
+        {
+          const int nblk = D >> 6;
+          const int idx = lane & 7, koff = ((lane >> 3) & 1) * 32 + (lane >> 4) * 8;
+          const uint32_t lane_off = ((uint32_t)(wgid * 8 + idx) * (uint32_t)D + (uint32_t)koff) * 2u;
+#pragma unroll
+          for (int u = 0; u < P_NU; ++u) {
+            int blk = aw + P_KS * u; if (blk > nblk - 1) blk = nblk - 1;
+            wa[u] = WH_WEIGHT_LOAD((const half8v*)((const char*)a.W + (size_t)blk * 128 + lane_off));
+          }
+        }
+        const float bias0 = a.bias[wgid * 8 + (lane & 7)];
+        asm volatile("" ::: "memory");
+        out0_mfma(aw, lane, D, wo, xo, pred);
+        tag = ((uint32_t)(uniform(vtick) + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
+        aux_barrier(&aux_cnt, bar += AUX, lane, a.err);
+        if (aw == 0) {
+          const int er = lane >> 3, ej = lane & 7;
+          float val = ob;
+#pragma unroll
+          for (int k = 0; k < P_KS; ++k) val += pred[k][ej][er];
+          if (er < a.R)
+            __hip_atomic_store(a.x_io + (int64_t)er * a.xf_ld + wgid * 8 + ej, ores + val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the storing wave drains, THEN the flag
+          if (lane == 0) __hip_atomic_store(a.pflags + wgid, (u64)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          XPROBE(a, wgid, 3);                        // phase 0 published
+        }
+        {
+          // every auxiliary wave polls its share of the D / 8 flags (one 8-byte agent-scope load per lane and pass)
+          const int nprod = D >> 3;
+          const int fi = aw * 64 + lane;
+          const u64* fp = a.pflags + (fi < nprod ? fi : nprod - 1);
+          const int max_spins = (a.mode & 4) ? 1 : X_MAX_SPINS;
+          int spins = 0;
+          if (aw * 64 < nprod) {
+            for (;;) {
+              const u64 f = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (__all((uint32_t)f == tag)) break;
+              if (++spins >= max_spins) { if (lane == 0 && a.err) atomicAdd(a.err, 1); break; }
+              __builtin_amdgcn_s_sleep(2);
+            }
+          }
+        }
+        aux_barrier(&aux_cnt, bar += AUX, lane, a.err);       // all flags seen by all four waves (and pred is free again)
+        out0_rows(aw, lane, D, a.x_io, a.xf_ld, a.R, xv);
+        const float bias = bias0;
+        proj_ln(aw, lane, D, xv, xfrag);
+        aux_barrier(&aux_cnt, bar += AUX, lane, a.err);
+        proj_stage2(aw, lane, wa, xfrag, pred);
+        aux_barrier(&aux_cnt, bar += AUX, lane, a.err);
+        if (aw == 0) {
+          const int er = lane >> 3, ej = lane & 7;
+          const int n = wgid * 8 + ej;
+          float val = bias;
+#pragma unroll
+          for (int k = 0; k < P_KS; ++k) val += pred[k][ej][er];
+          const half_t qh = (half_t)val;
+          const half_t qsc = (half_t)((float)qh * XSCALE);
+          publish_pair(a.qg + (size_t)er * (D >> 1) + (n >> 1), qsc, lane, (ej & 1) == 0, er < a.R, tag);
+        }
+      } else {
       proj_issue(aw, lane, wgid, a.W, D, a.xf, a.xf_ld, a.R, wa, xv);
       const float bias = a.bias[wgid * 8 + (lane & 7)];          // requested with the rest, used after the MFMAs
       tag = ((uint32_t)(uniform(vtick) + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
@@ -293,6 +443,7 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
         const half_t qh = (half_t)val;                 // what the two-launch form stores ...
         const half_t qsc = (half_t)((float)qh * XSCALE);   // ... and what its attention kernel makes of it (exact)
         publish_pair(a.qg + (size_t)er * (D >> 1) + (n >> 1), qsc, lane, (ej & 1) == 0, er < a.R, tag);
+      }
       }
     } else {
       tag = ((uint32_t)(uniform(vtick) + 1 + a.epoch) << 6) | (uint32_t)(a.layer + 1);
@@ -750,9 +901,16 @@ hipError_t launch_xattn8(const XAttnArgs& a, hipStream_t stream) {
   const int chunk = (a.Tk + a.splits - 1) / a.splits;
   const int rounds = (chunk + 63) / 64;
   dim3 grid(a.splits, a.H, a.R), block(768);
-  if (rounds <= 4) hipLaunchKernelGGL((xattn8_kernel<4>), grid, block, 0, stream, a);
-  else if (rounds <= 6) hipLaunchKernelGGL((xattn8_kernel<6>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((xattn8_kernel<8>), grid, block, 0, stream, a);
+  if (a.out_w) {                                       // phase 0: attn.out + residual inside this launch
+    if (!a.att_in || !a.out_b || !a.x_io || !a.pflags || a.x_io != a.xf) return hipErrorInvalidValue;
+    if (rounds <= 4) hipLaunchKernelGGL((xattn8_kernel<4, true>), grid, block, 0, stream, a);
+    else if (rounds <= 6) hipLaunchKernelGGL((xattn8_kernel<6, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((xattn8_kernel<8, true>), grid, block, 0, stream, a);
+    return hipGetLastError();
+  }
+  if (rounds <= 4) hipLaunchKernelGGL((xattn8_kernel<4, false>), grid, block, 0, stream, a);
+  else if (rounds <= 6) hipLaunchKernelGGL((xattn8_kernel<6, false>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((xattn8_kernel<8, false>), grid, block, 0, stream, a);
   return hipGetLastError();
 }
 

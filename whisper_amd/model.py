@@ -3,7 +3,10 @@
 Same attributes and bound methods as the reference's `whisper.model.Whisper` (model.py:252-345): `.dims`,
 `.device`, `.is_multilingual`, `.num_languages`, `.encoder(mel)`, `.decoder(tokens, xa)`, `.logits`,
 `.embed_audio`, `.forward`, `.alignment_heads`, `.set_alignment_heads`, `.detect_language`, `.transcribe`,
-`.decode`.  It is not an nn.Module: the parameters live in one packed device blob consumed by the HIP kernels
+`.decode`, and the part of the nn.Module surface a caller of the reference touches on the model object:
+`.parameters()` / `.named_parameters()` / `.state_dict()` / `.load_state_dict()` (reference names and shapes,
+model.py:174-249), `.half()` / `.float()`, `.to()` / `.cuda()`, `.eval()` / `.train()` / `.requires_grad_()`.
+It is not an nn.Module: the parameters live in one packed device blob consumed by the HIP kernels
 (whisper_amd/hip.py -> libwhisper_hip.so).  The reference keeps fp32 master weights and lets the activation
 dtype follow the input (model.py:44-50, decoding.py:645-646); here each precision is its own packed engine,
 chosen by the dtype of the tensor you pass (fp16 mel -> fp16 engine, fp32 mel -> fp32 strict-parity engine) and
@@ -13,8 +16,9 @@ from __future__ import annotations
 
 import base64
 import gzip
+from collections import namedtuple
 from dataclasses import dataclass
-from typing import Dict, Optional
+from typing import Dict, Iterator, Optional, Tuple
 
 import numpy as np
 import torch
@@ -41,6 +45,50 @@ class ModelDimensions:
     n_text_layer: int
 
 
+def expected_state_shapes(dims: ModelDimensions) -> Dict[str, Tuple[int, ...]]:
+    """names and shapes of `Whisper(dims).state_dict()` in the reference (model.py:174-249: AudioEncoder, TextDecoder,
+    ResidualAttentionBlock, MultiHeadAttention; `attn.key` has no bias, model.py:88; the decoder's causal `mask` and the
+    `alignment_heads` are non-persistent buffers and absent)"""
+    out: Dict[str, Tuple[int, ...]] = {}
+
+    def linear(p, n_out, n_in, bias=True):
+        out[p + ".weight"] = (n_out, n_in)
+        if bias:
+            out[p + ".bias"] = (n_out,)
+
+    def lnorm(p, n):
+        out[p + ".weight"] = (n,)
+        out[p + ".bias"] = (n,)
+
+    def block(p, n, cross):
+        for a in (["attn", "cross_attn"] if cross else ["attn"]):
+            linear(f"{p}.{a}.query", n, n)
+            linear(f"{p}.{a}.key", n, n, bias=False)
+            linear(f"{p}.{a}.value", n, n)
+            linear(f"{p}.{a}.out", n, n)
+            lnorm(f"{p}.{a}_ln", n)
+        linear(f"{p}.mlp.0", 4 * n, n)
+        linear(f"{p}.mlp.2", n, 4 * n)
+        lnorm(f"{p}.mlp_ln", n)
+
+    D, Dt = dims.n_audio_state, dims.n_text_state
+    out["encoder.conv1.weight"], out["encoder.conv1.bias"] = (D, dims.n_mels, 3), (D,)
+    out["encoder.conv2.weight"], out["encoder.conv2.bias"] = (D, D, 3), (D,)
+    out["encoder.positional_embedding"] = (dims.n_audio_ctx, D)
+    for i in range(dims.n_audio_layer):
+        block(f"encoder.blocks.{i}", D, False)
+    lnorm("encoder.ln_post", D)
+    out["decoder.token_embedding.weight"] = (dims.n_vocab, Dt)
+    out["decoder.positional_embedding"] = (dims.n_text_ctx, Dt)
+    for i in range(dims.n_text_layer):
+        block(f"decoder.blocks.{i}", Dt, True)
+    lnorm("decoder.ln", Dt)
+    return out
+
+
+_IncompatibleKeys = namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
+
+
 class _EncoderHandle:
     """callable `model.encoder` (AudioEncoder.forward, reference model.py:188-204)"""
 
@@ -52,7 +100,9 @@ class _EncoderHandle:
         if x.dim() == 2:
             x = x[None]
         x = x.to(owner.device)
-        if x.dtype not in (torch.float16, torch.float32):
+        if owner._half:
+            x = x.half()                       # model.half(): fp16 engine whatever comes in
+        elif x.dtype not in (torch.float16, torch.float32):
             x = x.float()
         return owner.engine(x.dtype).encode(x)
 
@@ -100,12 +150,25 @@ class _DecoderHandle:
 
     def __call__(self, x: Tensor, xa: Tensor, kv_cache: Optional[dict] = None) -> Tensor:
         owner = self._owner
+        if owner._half:
+            xa = xa.half()                     # model.half(): fp16 engine whatever comes in
+        elif xa.dtype not in (torch.float16, torch.float32):
+            xa = xa.float()
         if kv_cache is not None and _TASK_KEY in kv_cache:
             x, xa = x.to(owner.device), xa.to(owner.device)
             return self._incremental(x[None] if x.dim() == 1 else x, xa[None] if xa.dim() == 2 else xa, kv_cache)
         if kv_cache:
-            raise NotImplementedError("a kv_cache dict must come from model.install_kv_cache_hooks(): the keys and "
-                                      "values are kept in a wh_task on the device, not as tensors in the dict")
+            # A dict the hooks of install_kv_cache_hooks() never filled.  The reference (model.py:233-249, 96-104) finds
+            # none of its projection modules in it, so it computes every key / value afresh from `x` and only takes the
+            # position offset from the first entry (`next(iter(kv_cache.values())).shape[1]`).  Offset 0 is then an
+            # ordinary teacher-forced pass; a non-zero offset would embed x at shifted positions WITHOUT the earlier
+            # tokens' keys — not a decoding step of anything, and not offered here.
+            first = next(iter(kv_cache.values()))
+            offset = int(first.shape[1]) if hasattr(first, "shape") and len(first.shape) > 1 else 0
+            if offset != 0:
+                raise NotImplementedError(
+                    "kv_cache holds tensors that model.install_kv_cache_hooks() did not put there; incremental decoding "
+                    "keeps its keys / values in a device-side task: cache, hooks = model.install_kv_cache_hooks()")
         x = x.to(owner.device)
         xa = xa.to(owner.device)
         if x.dim() == 1:
@@ -136,6 +199,8 @@ class Whisper:
         self._state_dict = state_dict            # reference-format tensors (any device), kept to build engines
         self._device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
         self._engines: Dict[torch.dtype, hip.HipModel] = {}
+        self._half = False                       # model.half() was called: every input runs on the fp16 engine
+        self.training = False
         self.encoder = _EncoderHandle(self)
         self.decoder = _DecoderHandle(self)
         # default: every head of the upper half of the decoder (reference model.py:270-276)
@@ -188,11 +253,78 @@ class Whisper:
             self._engines.clear()
         return self
 
+    def cuda(self, device=None) -> "Whisper":
+        return self.to(torch.device("cuda", device) if isinstance(device, int) else (device or "cuda"))
+
+    def cpu(self) -> "Whisper":
+        """the retained checkpoint tensors stay usable (state_dict, save); computing needs a GPU device (no CPU path)"""
+        return self.to("cpu")
+
     def eval(self) -> "Whisper":
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True) -> "Whisper":
+        """inference-only engine: the flag is kept for callers that toggle it, nothing else changes (the reference has no
+        dropout or batch statistics either, model.py:142-171)"""
+        self.training = bool(mode)
+        return self
+
+    def requires_grad_(self, requires_grad: bool = True) -> "Whisper":
+        if requires_grad:
+            raise NotImplementedError("whisper_amd is an inference path: there is no backward pass")
+        return self
+
+    def half(self) -> "Whisper":
+        """reference: `model.half()` turns the parameters into fp16, after which only fp16 inputs compute (what
+        `DecodingOptions(fp16=True)` relies on, decoding.py:645-646).  Here: every input is run on the fp16 engine
+        (fp32 tensors are converted on entry instead of raising a dtype error)."""
+        self._half = True
+        return self
+
+    def float(self) -> "Whisper":
+        """reference: fp32 master weights, the activation dtype follows the input (Linear casts the weight to x.dtype,
+        model.py:44-50).  Here: the engine follows the input dtype again (fp32 in -> fp32 strict engine, fp16 in -> fp16)."""
+        self._half = False
         return self
 
     def state_dict(self) -> Dict[str, Tensor]:
         return dict(self._state_dict)
+
+    def named_parameters(self) -> Iterator[Tuple[str, Tensor]]:
+        """the retained checkpoint tensors under the reference's names (the encoder's positional table is a buffer there
+        and is skipped, model.py:185)"""
+        for k, v in self._state_dict.items():
+            if k != "encoder.positional_embedding":
+                yield k, v
+
+    def parameters(self) -> Iterator[Tensor]:
+        for _, v in self.named_parameters():
+            yield v
+
+    def load_state_dict(self, state_dict: Dict[str, Tensor], strict: bool = True):
+        """nn.Module.load_state_dict for the reference's checkpoint layout (whisper/__init__.py:150-156): names and shapes
+        are checked against model.py:174-249, the packed engines are dropped and rebuilt lazily from the new tensors.
+        Returns (missing_keys, unexpected_keys) like torch; with strict=True (default) either being non-empty raises."""
+        want = expected_state_shapes(self.dims)
+        missing = [k for k in want if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in want]
+        bad = [f"{k}: {tuple(state_dict[k].shape)} != {want[k]}" for k in want
+               if k in state_dict and tuple(state_dict[k].shape) != want[k]]
+        if bad:
+            raise RuntimeError("size mismatch in load_state_dict: " + "; ".join(bad[:8]))
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing keys {missing[:8]}, unexpected keys {unexpected[:8]}")
+        merged = dict(self._state_dict)
+        merged.update({k: v.detach() for k, v in state_dict.items() if k in want})
+        still = [k for k in want if k not in merged]
+        if still and strict:
+            raise RuntimeError(f"load_state_dict: missing keys {still[:8]}")
+        self._state_dict = merged
+        for eng in self._engines.values():
+            eng.drop_cached_tasks()
+        self._engines.clear()
+        return _IncompatibleKeys(missing, unexpected)
 
     @property
     def is_multilingual(self) -> bool:
