@@ -260,8 +260,8 @@ def main():
         "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f16",
-        "data": ("synthetic" + (" (seeded random-init weights, tied-embedding rows margin-conditioned on these clips: "
-                                "oracle/condition.py)" if prep is not None and prep.get("conditioned") else ""))
+        "data": ("synthetic" + (" (seeded random-init weights; cross-attention value biases and tied-embedding rows "
+                                "margin-conditioned on these clips: oracle/condition.py)" if prep is not None and prep.get("conditioned") else ""))
                 if ckpt_path is None else f"synthetic audio, weights of {os.path.basename(ckpt_path)}",
         "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
         "config": {"workload": f"{args.model} dims ({'random-init weights' if ckpt_path is None else 'released checkpoint'}), {B} x 30 s synthetic clips per GPU, "
@@ -470,7 +470,8 @@ def oracle_side(args, dims, sd, audio_np, condition: bool) -> dict:
     """The CHECKER's half of the parity leg, run before any HIP work (it is also the batch-B leg of the CPU baseline, so
     every stage is timed): the oracle (fp32 port of the reference's CPU path, SDPA attention) computes log-mel and
     encoder output of this run's B clips as one batch, optionally margin-conditions the synthetic checkpoint on them
-    (oracle/condition.py — token-embedding rows edited IN PLACE in `sd`, before the engines are packed from it), then
+    (oracle/condition.py — the decoder's cross-attention value biases and token-embedding rows edited IN PLACE in `sd`,
+    before the engines are packed from it), then
     greedy-decodes all sample_len (or --parity-steps) steps with the plain oracle: the tokens every row of the timed HIP
     pass must equal, the filtered logits they were chosen from, and the decision margins."""
     import oracle
@@ -496,6 +497,12 @@ def oracle_side(args, dims, sd, audio_np, condition: bool) -> dict:
         built, t_cond = None, 0.0
         if condition:
             t0 = time.perf_counter()
+            # (1) the random-init encoder's output is one constant vector plus a little (cos 0.999 between clips): cancel its
+            # contribution to the cross-attention values (value biases), or the decoder cannot tell steps and rows apart;
+            # (2) margin-condition the tied embedding along the greedy decode of these clips
+            c = cond.center_cross_values(om, feats)
+            log(f"oracle side: cross-attention value biases centred on the clips' mean encoder output (|c| = {float(c.norm()):.1f} "
+                f"of |x| = {float(feats.norm(dim=-1).mean()):.1f})")
             built = cond.condition_greedy(om, feats, init, n_steps, rules, seed=0, margin=(0.35, 3.0), log=log, passes=2)
             t_cond = time.perf_counter() - t0
         t0 = time.perf_counter()
@@ -811,8 +818,9 @@ def parity_report(decB, init, hip_rows, kp, prep=None, engine="fp16") -> dict:
     rep = {"engine": engine, "rows": B, "steps": kp, "rows_equal": n_eq, "rows_near_tie": n_tie,
            "rows_wrong": B - n_eq - n_tie, "tokens_equal": n_eq == B, "per_row": rows}
     if prep is not None:
-        rep["checkpoint"] = ("seed-0 weights, tied-embedding rows margin-conditioned on these clips (oracle/condition.py: "
-                             f"{prep['edited_rows']} rows)" if conditioned else "as given (no conditioning)")
+        rep["checkpoint"] = ("seed-0 weights; cross-attention value biases centred on the clips' mean encoder output and "
+                             f"{prep['edited_rows']} tied-embedding rows margin-conditioned on these clips (oracle/condition.py)"
+                             if conditioned else "as given (no conditioning)")
         rep["oracle_margins"] = prep["margins"]
         rep["conditioning_consistent"] = prep["consistent"]
     rep["rule"] = (f"{engine} engine vs fp32 oracle, all {B} rows x {kp} steps: token ids EXACT (no near-tie rule; the oracle's "

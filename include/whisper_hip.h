@@ -153,9 +153,7 @@ enum {
    * (A/B and tests: the results must agree) — for the self attention / for the cross attention */
   WH_TASK_TWO_LAUNCH_SELF = 2,
   WH_TASK_TWO_LAUNCH_CROSS = 4,
-  /* attn.out + the residual add as a launch of its own instead of phase 0 of the fused cross-attention launch (A/B and
-   * tests: bit-identical rows either way) */
-  WH_TASK_TWO_LAUNCH_OUT = 8,
+  /* 8: reserved (development builds of the library only; ignored here) */
   /* Fault injection for the hand-off protocol of the fused step kernels: every consumer gives up after its FIRST poll, as
    * if its bounded spin had run out.  The step's result is then invalid by construction; wh_task_greedy / wh_task_beam
    * must notice (WH_ERR_HANDOFF internally), move the task to the two-launch kernels and re-run — what the tests check. */
@@ -203,12 +201,11 @@ int wh_task_set_lag(wh_task *t, const int32_t *lag, void *stream);
 int wh_task_position(const wh_task *t);
 /* Introspection for tests and the benchmark.  what = 0: 1 when this task's decode step runs the cross attention with its
  * LayerNorm + query projection inside the same launch (csrc/xattn.hip: fp16, <= 8 rows, one row per audio), else 0.
- * what = 2: the same question for self attention + QKV projection + cache append (sattn8_kernel); what = 3: that launch
- * also applies attn.out + the residual add.
+ * what = 2: the same question for self attention + QKV projection + cache append (sattn8_kernel); what = 3: attn.out + the residual
+ * add run inside one of the attention launches (development builds only: always 0 in the shipped library).
  * what = 1: number of bounded hand-off spins that ran out in that kernel since the task was created (always 0 on a
  * healthy device; reads device memory, i.e. synchronises `stream`).  what = 4: number of times wh_task_greedy /
- * wh_task_beam re-ran a loop on the two-launch kernels after such a time-out (the answers to 0, 2, 3, 5 are 0 from then on).
- * what = 5: 1 when attn.out + the residual add of the self-attention block run as phase 0 of the fused cross-attention launch.
+ * wh_task_beam re-ran a loop on the two-launch kernels after such a time-out (the answers to 0, 2, 3 are 0 from then on).
  * Negative on error. */
 int wh_task_info(wh_task *t, int what, void *stream);
 

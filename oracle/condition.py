@@ -45,6 +45,24 @@ from .model import OracleModel
 EMB = "decoder.token_embedding.weight"
 
 
+def center_cross_values(om: OracleModel, feats: torch.Tensor) -> torch.Tensor:
+    """A random-init ENCODER maps every audio to nearly the same output: its frames share one large constant vector c
+    (|c| = 34 of |x| = 35.8 on bench.py's synthetic clips, cos 0.999 between clips — the "ordered phase" of a deep random
+    network).  Cross-attention keys do not care (q . W_k c is the same for every frame and cancels in the softmax), but
+    every value carries W_v c, so each decoder layer adds the same audio- and token-independent vector to the residual
+    stream and the hidden states of different steps and rows become near-copies (cos 0.994 / 0.995): there is then no
+    direction left along which a token could be told from its neighbours (see `condition_greedy`).  A trained encoder has
+    no such DC term.  This removes it where the architecture allows: `decoder.blocks.*.cross_attn.value.bias` (model.py:
+    88-89, 106-111) -= W_v c with c = the mean encoder output over the given clips and frames, rounded to fp16-exact
+    values.  IN PLACE in om.sd; returns c.  After it the same clips give cos 0.93 between steps and 0.93 between rows."""
+    c = feats.float().mean(dim=(0, 1))
+    for i in range(om.dims.n_text_layer):
+        p = f"decoder.blocks.{i}.cross_attn.value"
+        b = om.sd[p + ".bias"]
+        b.copy_((b - om.sd[p + ".weight"].float() @ c).half().float())
+    return c
+
+
 def _class_script(rng: np.random.Generator, n_steps: int, text_run: Tuple[int, int]) -> List[bool]:
     """want_timestamp[i] for the steps where the hard filters leave the choice: True where a timestamp pair starts"""
     want = [False] * n_steps
@@ -57,7 +75,7 @@ def _class_script(rng: np.random.Generator, n_steps: int, text_run: Tuple[int, i
 
 def condition_greedy(om: OracleModel, feats: torch.Tensor, initial_tokens: List[int], n_steps: int, r: SamplingRules,
                      seed: int = 0, margin: Tuple[float, float] = (0.3, 3.0), text_run: Tuple[int, int] = (4, 14),
-                     ts_window: int = 12, log=None, passes: int = 3) -> Dict:
+                     ts_window: int = 12, log=None, passes: int = 3, share: bool = False) -> Dict:
     """Edits om.sd["decoder.token_embedding.weight"] IN PLACE (see the module docstring) for a greedy decode of `n_steps`
     tokens over `feats` (R, 1500, D).  Pass 1 chooses the tokens and builds the margins; an edit made for a later step can
     still lift its token in ANOTHER row's earlier steps (rows are only decorrelated through their mean hidden states), so
@@ -65,14 +83,20 @@ def condition_greedy(om: OracleModel, feats: torch.Tensor, initial_tokens: List[
     short (second-order small: the top-ups are a fraction of a logit).  Returns the last pass's {"tokens" (R, T0 +
     n_steps), "rows": all edited token ids, "margins": per (step, row) the margin at the time the pass left the step,
     "deltas": logit boosts of that pass, "drawn": the margins asked for}.  The caller re-packs its engines from the state dict
-    and ALWAYS re-decodes with the plain oracle to assert the final margins (`margins_of`)."""
-    res = _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_run, ts_window, log, None)
+    and ALWAYS re-decodes with the plain oracle to assert the final margins (`margins_of`).
+    share: rows may emit the SAME token at the same step and follow one class script.  For inputs the model cannot tell
+    apart — a random-init ENCODER maps every audio to nearly the same features (cos 0.999 between clips of bench.py's
+    synthetic audio; the tests use feature tensors with a per-clip offset instead), so the rows' hidden states are
+    near-copies (cos 0.995) — forcing each row onto a token of its own would mean lifting it over its neighbour's boosted
+    token along the sliver of hidden state the two rows do not share: edits of norm >> the embedding's.  With `share` such
+    rows simply decode alike, as they do on the unconditioned weights."""
+    res = _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_run, ts_window, log, None, share)
     rows = set(res["rows"])
     for p in range(1, passes):
         if log is not None:
             log(f"condition: pass {p + 1} (top-up along the built sequence)")
         res = _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_run, ts_window, log,
-                              (res["tokens"], res["drawn"]))
+                              (res["tokens"], res["drawn"]), share)
         rows |= set(res["rows"])
         if log is not None:
             nz = [d for d in res["deltas"] if d > 0]
@@ -83,7 +107,7 @@ def condition_greedy(om: OracleModel, feats: torch.Tensor, initial_tokens: List[
     return res
 
 
-def _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_run, ts_window, log, target) -> Dict:
+def _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_run, ts_window, log, target, share=False) -> Dict:
     """one walk; target = None (choose tokens, draw margins) or (tokens, drawn margins) of an earlier pass"""
     rng = np.random.default_rng(seed)
     E = om.sd[EMB]
@@ -94,6 +118,8 @@ def _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_ru
     used = torch.zeros(E.shape[0], dtype=torch.bool)
     used[list(initial_tokens)] = True
     scripts = [_class_script(rng, n_steps, text_run) for _ in range(R)]
+    if share:
+        scripts = [scripts[0]] * R
     cache = om.new_cache()
     margins, deltas, rows, drawn = [], [], [], []
     ninf = -np.inf
@@ -120,6 +146,7 @@ def _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_ru
             logits_all = h_all @ E.T                                                                           # (R, V)
             nxt = torch.empty(R, dtype=torch.int64)
             step_edits: List[int] = []
+            step_chosen: List[int] = []
             for k in range(R):
                 h = h_all[k]
                 lg = logits_all[k].clone()
@@ -129,6 +156,8 @@ def _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_ru
                 apply_filters(lg, sampled, r, mass_rule=False)
                 free = lg.clone()
                 free[used] = ninf
+                if share and step_chosen:                       # tokens other rows chose at THIS step stay admissible
+                    free[step_chosen] = lg[step_chosen]
                 if TB is None:
                     text_ok, ts_ok = True, False
                     text_free = free
@@ -176,6 +205,9 @@ def _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_ru
                     u = d / float(d @ h)
                     base = E[y].clone()
                     boost = need - have
+                    if float(d.norm()) < 0.2:
+                        raise RuntimeError(f"row {k} step {i}: the hidden state has no direction of its own left (|d| = "
+                                           f"{float(d.norm()):.3f}): the rows are near-copies — condition with share=True")
                     for _ in range(8):
                         E[y] = (base + boost * u).half().float()
                         got = float(E[y] @ h)
@@ -183,15 +215,21 @@ def _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_ru
                             break
                         boost += (need - got) + 1e-3
                     else:
-                        raise RuntimeError("fp16 rounding of an edited embedding row did not converge")
-                    step_edits.append(y)
+                        raise RuntimeError(f"row {k} step {i}: fp16 rounding of an edited embedding row did not converge "
+                                           f"(boost {boost:.2f}, |d| {float(d.norm()):.3f}, d.h {float(d @ h):.3f}, need {need:.2f}, "
+                                           f"have {have:.2f}, got {got:.2f})")
+                    if y not in step_edits:
+                        step_edits.append(y)
                     rows.append(y)
                     have = float(E[y] @ h)
                 hist[k] = grow(hist[k], h)
+                step_chosen.append(y)
                 used[y] = True
                 nxt[k] = y
                 margins.append(have - (need - m))
                 deltas.append(boost)
+                if log is not None and boost > 30:
+                    log(f"condition: large boost {boost:.1f} at step {i} row {k} token {y} (|d| {float(d.norm()):.2f})")
             tokens = torch.cat([tokens, nxt[:, None]], dim=-1)
             if log is not None and (i % 32 == 31 or i == n_steps - 1):
                 mm = np.asarray(margins[-32 * R:])

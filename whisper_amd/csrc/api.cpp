@@ -418,8 +418,13 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
                    xattn_supported(m->d.n_text_state, m->d.n_text_head, t->R, t->G, m->d.n_audio_ctx, t->cross_splits);
   t->fused_sattn = !(flags & WH_TASK_TWO_LAUNCH_SELF) && m->dtype == WH_F16 && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) && t->self_splits == 1 &&
                    sattn_supported(m->d.n_text_state, m->d.n_text_head, t->R, m->d.n_text_ctx);
-  // attn.out + residual as phase 0 of the cross-attention launch: its input must be plain attention rows (one key split)
-  t->fused_xout = t->fused_xattn && t->self_splits == 1 && !(flags & WH_TASK_TWO_LAUNCH_OUT);
+  // attn.out + residual as phase 0 of the cross-attention launch (needs plain attention rows: one key split): a rejected
+  // experiment, slower than the two launches (xattn.hip, out0_issue) — development builds only, WH_FUSED_XOUT=1
+#ifdef WH_DEV
+  t->fused_xout = t->fused_xattn && t->self_splits == 1 && WH_DEV_FLAG("WH_FUSED_XOUT");
+#else
+  t->fused_xout = false;
+#endif
   {
     // attn.out inside the self-attention launch: built, bit-identical, and slower than its own launch (the gather of 160
     // (row, head) outputs by the projection workgroups costs ~4 us after the attention, and its polling slows the
@@ -458,8 +463,7 @@ extern "C" int wh_task_info(wh_task* t, int what, void* stream) {
   if (!t) return -1;
   if (what == 0) return t->fused_xattn ? 1 : 0;
   if (what == 2) return t->fused_sattn ? 1 : 0;
-  if (what == 3) return t->fused_out ? 1 : 0;
-  if (what == 5) return t->fused_xout ? 1 : 0;
+  if (what == 3) return (t->fused_out || t->fused_xout) ? 1 : 0;
   if (what == 4) return t->handoff_fallbacks;
   if (what == 1) {                       // hand-off timeouts of the fused cross attention since the task was created
     if (t->needs_reset) return 0;

@@ -230,7 +230,14 @@ __device__ __forceinline__ void aux_barrier(int* cnt, int target, int lane, int*
 }
 
 // ---- phase 0 of the cross-attention launch (OUT0): `attn.out` + the residual add (model.py:153) by the producers' auxiliary
-// waves, handed to the LayerNorm of the SAME launch -------------------------------------------------------------------------
+// waves, handed to the LayerNorm of the SAME launch — a round-4 experiment, REJECTED, compiled into development builds
+// (-DWH_DEV) only.  Measured (tools/probe_fused, profiles/r04_probe_out0_fusion.txt): 19.7 us for the one launch against
+// 17.0 us for attn.out (3.85) followed by the fused cross attention (13.0).  The time line says why: the rows are
+// published 4.4 us into the launch, but the producers' LayerNorm input arrives 8 us later — their flag polls and row
+// loads are vector-memory requests and queue behind the 256 KB of K/V requests of their own CU (a CU serves them in
+// issue order: the lesson of round 3, which is why the q hand-off polls through the scalar path), and 40 KB of rows per
+// producer is too much for the scalar path.  The first build was also not bit-identical to the separate launch
+// (asm loads without a data dependence on their wait); the loads below now carry one.  Kept for the record: ---------------
 // The output projection of the self attention used to be a launch of its own between the two attention launches (3.3 MB of
 // weights: 3.85 us per link, most of it boundary and ramp).  Its weights do not depend on anything, and the cross
 // attention's 61 MB K/V stream is requested at entry and takes ~10 us to land whatever the auxiliary waves do meanwhile —
@@ -306,7 +313,12 @@ __device__ __forceinline__ void out0_rows(int aw, int lane, int K, const float* 
       v[i][j] = load_f4_sc(src + (uint32_t)k * 4u);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // the compiler does not know that an asm load's result is pending: every register is an in/out operand of the wait, so
+  // that no use can be scheduled above it
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < P_NU; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[i][j]) : : "memory");
 }
 
 // Both kernels below are written as TWO role bodies under one wave-uniform branch — the KV waves and the auxiliary waves
@@ -902,11 +914,15 @@ hipError_t launch_xattn8(const XAttnArgs& a, hipStream_t stream) {
   const int rounds = (chunk + 63) / 64;
   dim3 grid(a.splits, a.H, a.R), block(768);
   if (a.out_w) {                                       // phase 0: attn.out + residual inside this launch
+#ifdef WH_DEV                                          // a REJECTED experiment (see out0_issue): development builds only
     if (!a.att_in || !a.out_b || !a.x_io || !a.pflags || a.x_io != a.xf) return hipErrorInvalidValue;
     if (rounds <= 4) hipLaunchKernelGGL((xattn8_kernel<4, true>), grid, block, 0, stream, a);
     else if (rounds <= 6) hipLaunchKernelGGL((xattn8_kernel<6, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((xattn8_kernel<8, true>), grid, block, 0, stream, a);
     return hipGetLastError();
+#else
+    return hipErrorNotSupported;
+#endif
   }
   if (rounds <= 4) hipLaunchKernelGGL((xattn8_kernel<4, false>), grid, block, 0, stream, a);
   else if (rounds <= 6) hipLaunchKernelGGL((xattn8_kernel<6, false>), grid, block, 0, stream, a);

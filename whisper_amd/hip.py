@@ -23,7 +23,6 @@ WH_F32, WH_F16 = 0, 1
 WH_TASK_CAPTURE_Q = 1
 WH_TASK_TWO_LAUNCH_SELF = 2
 WH_TASK_TWO_LAUNCH_CROSS = 4
-WH_TASK_TWO_LAUNCH_OUT = 8
 WH_TASK_EXPIRE_HANDOFFS = 16        # fault injection (include/whisper_hip.h): every hand-off poll gives up at once
 WH_WEIGHTS_DEC_LN_FOLDED = 1
 WH_WEIGHTS_ENC_QK_SCALED = 2
@@ -494,13 +493,13 @@ class HipTask:
 
     def __init__(self, model: HipModel, n_audio: int, n_group: int, max_prefill: int, capture_q: bool = False,
                  stream: Optional[torch.cuda.Stream] = None, two_launch_self: bool = False, two_launch_cross: bool = False,
-                 two_launch_out: bool = False, expire_handoffs: bool = False, extra_flags: int = 0):
+                 expire_handoffs: bool = False, extra_flags: int = 0):
         self.model = model
         self.n_audio, self.n_group, self.n_rows = n_audio, n_group, n_audio * n_group
         self.max_prefill = max_prefill
         self.capture_q = capture_q
         flags = ((WH_TASK_CAPTURE_Q if capture_q else 0) | (WH_TASK_TWO_LAUNCH_SELF if two_launch_self else 0)
-                 | (WH_TASK_TWO_LAUNCH_CROSS if two_launch_cross else 0) | (WH_TASK_TWO_LAUNCH_OUT if two_launch_out else 0)
+                 | (WH_TASK_TWO_LAUNCH_CROSS if two_launch_cross else 0)
                  | (WH_TASK_EXPIRE_HANDOFFS if expire_handoffs else 0) | int(extra_flags) | int(model.debug_task_flags))
         self.stream = stream if stream is not None else model.stream   # independent tasks may run on own streams
         with torch.cuda.device(model.device):
@@ -615,11 +614,6 @@ class HipTask:
     def fused_self_attention(self) -> bool:
         """the decode step runs LN -> QKV -> cache append -> self attention as one launch (csrc/xattn.hip)"""
         return lib().wh_task_info(self.handle, 2, None) == 1
-
-    @property
-    def fused_out_projection(self) -> bool:
-        """attn.out + the residual add run as phase 0 of the fused cross-attention launch (no launch of their own)"""
-        return lib().wh_task_info(self.handle, 5, None) == 1
 
     @property
     def handoff_fallbacks(self) -> int:
