@@ -63,6 +63,71 @@ def center_cross_values(om: OracleModel, feats: torch.Tensor) -> torch.Tensor:
     return c
 
 
+def time_code(n: int, n_freq: int = 32, longest: float = 3000.0, shortest: float = 6.0) -> torch.Tensor:
+    """(n, 2 n_freq) code of the integers 0 .. n-1: cos / sin at n_freq geometrically spaced periods.  code(t) . code(s) =
+    sum_j cos(w_j (t - s)): 2 n_freq / 2 at t = s, a few units elsewhere — a ridge a few frames wide."""
+    t = torch.arange(n, dtype=torch.float64)[:, None]
+    w = 2 * np.pi / torch.tensor(np.geomspace(longest, shortest, n_freq))[None, :]
+    return torch.cat([torch.cos(t * w), torch.sin(t * w)], 1).float()
+
+
+def condition_alignment(sd: Dict[str, torch.Tensor], dims, heads: List[Tuple[int, int]], seed: int = 0,
+                        frames_per_token: float = 11.0, first_frame: float = 12.0, pos_gain: float = 40.0,
+                        qk_gain: float = 0.7) -> Dict:
+    """Alignment-conditioned synthetic checkpoint (TEST INFRASTRUCTURE).  Random-init cross attention has no ridge: the
+    DTW of timing.py:141-151 then picks one of many nearly equally cheap monotone paths, and a rounding-level change of
+    the cost matrix moves word boundaries by tenths of a second (the fp16-vs-fp32 figures of the random-init tests).
+    A trained model's alignment heads attend along the diagonal of (token, time).  This builds that property into a seeded
+    checkpoint, IN PLACE in `sd`, for the (layer, head) pairs `heads` (to be installed as the model's alignment heads):
+      * `decoder.positional_embedding[i]` += pos_gain * U_d code(tau_i), tau_i = first_frame + frames_per_token * i: the
+        residual stream of token position i carries where in the audio the token "is spoken";
+      * rows of head h of `cross_attn.query` in layer l := qk_gain * U_d^T (LayerNorm affine divided out, bias cancelling
+        its shift), rows of head h of `cross_attn.key` := qk_gain * U_a^T: q_i . k_t peaks where the frame's code
+        matches the token's;
+    U_d, U_a: seeded orthonormal (D, 64) bases.  The AUDIO side of the code cannot come from a random-init encoder; the
+    caller builds the audio features as noise + feat_gain * code(t) U_a^T (`alignment_features`) and passes them as
+    `audio_features`, which find_alignment / find_alignment_batch accept in place of the mel (transcribe() does the same
+    with the features of the window it has just decoded).  Everything is rounded to fp16-exact values.
+    frames_per_token is ODD on purpose: with an even spacing the frame midway between two tokens' target frames scores
+    exactly the same for both (the code's kernel is symmetric) and rounding would decide the boundary.  Deep decoders dilute
+    the position code (the residual stream grows with depth): 32 layers want pos_gain ~ 120, qk_gain ~ 0.5; 4 layers 40 / 0.7
+    (chosen on the CPU with a crude all-fp16 oracle as the perturbation: no boundary moved).
+    Returns {"U_a", "U_d", "tau": frame of every token position}."""
+    D = dims.n_text_state
+    g = torch.Generator().manual_seed(seed)
+    U_d, _ = torch.linalg.qr(torch.randn(D, 64, generator=g))
+    U_a, _ = torch.linalg.qr(torch.randn(D, 64, generator=g))
+    tau = first_frame + frames_per_token * torch.arange(dims.n_text_ctx, dtype=torch.float64)
+    code = time_code(int(tau.max().item()) + 2)
+    # token side: code of the (rounded) target frame of every position
+    pos_code = code[tau.round().long()]                                       # (n_ctx, 64)
+    q16 = lambda t: t.half().float()
+    sd["decoder.positional_embedding"] = q16(sd["decoder.positional_embedding"].float() + pos_gain * pos_code @ U_d.T)
+    for l, h in heads:
+        p = f"decoder.blocks.{l}"
+        rows = slice(64 * h, 64 * h + 64)
+        gamma = sd[p + ".cross_attn_ln.weight"].float()
+        beta = sd[p + ".cross_attn_ln.bias"].float()
+        wq = sd[p + ".cross_attn.query.weight"].float().clone()
+        bq = sd[p + ".cross_attn.query.bias"].float().clone()
+        wk = sd[p + ".cross_attn.key.weight"].float().clone()
+        wq[rows] = q16(qk_gain * U_d.T / gamma[None, :])
+        bq[rows] = q16(-(wq[rows] @ beta))
+        wk[rows] = q16(qk_gain * U_a.T)
+        sd[p + ".cross_attn.query.weight"], sd[p + ".cross_attn.query.bias"] = wq, bq
+        sd[p + ".cross_attn.key.weight"] = wk
+    return {"U_a": U_a, "U_d": U_d, "tau": tau}
+
+
+def alignment_features(dims, n: int, U_a: torch.Tensor, seed: int = 0, feat_gain: float = 4.0, noise: float = 1.0) -> torch.Tensor:
+    """(n, n_audio_ctx, D) fp16-exact audio features for an alignment-conditioned checkpoint: unit noise (its own per clip)
+    plus feat_gain * code(frame) along U_a."""
+    g = torch.Generator().manual_seed(seed)
+    code = time_code(dims.n_audio_ctx)
+    x = noise * torch.randn(n, dims.n_audio_ctx, dims.n_audio_state, generator=g) + feat_gain * (code @ U_a.T)[None]
+    return x.half().float()
+
+
 def _class_script(rng: np.random.Generator, n_steps: int, text_run: Tuple[int, int]) -> List[bool]:
     """want_timestamp[i] for the steps where the hard filters leave the choice: True where a timestamp pair starts"""
     want = [False] * n_steps

@@ -421,8 +421,10 @@ FP16_LOGIT_BOUND = 6e-2     # |logit(fp16 engine) - logit(fp32 oracle)| asserted
 # Measured on MI355X (round 3): large-v3 max 0.0111 / rms 0.0018 over 8 rows x 11 positions (its seed-0 logits are of
 # scale ~0.1: the residual stream of 32 blocks dominates the tied embedding); turbo (4 decoder layers, logits of unit
 # scale) max 0.136 / rms 0.0129.  Asserted with head-room for other inputs; the near-tie rule uses twice the max bound.
-FP16_FULL_DEPTH_MAX = {"large-v3": 0.03, "turbo": 0.20}      # asserted max |dlogit|  (32 + 32 / 32 + 4 layers)
-FP16_FULL_DEPTH_RMS = {"large-v3": 5e-3, "turbo": 2e-2}      # asserted rms |dlogit|
+# Round 4: asserted at what was observed plus a small slack — 0.0111 -> 0.02, 0.136 -> 0.15; the
+# near-tie rule of the random-init tests uses twice these; the margin-conditioned checkpoints below need no such rule.
+FP16_FULL_DEPTH_MAX = {"large-v3": 0.02, "turbo": 0.15}      # asserted max |dlogit|  (32 + 32 / 32 + 4 layers)
+FP16_FULL_DEPTH_RMS = {"large-v3": 3e-3, "turbo": 1.6e-2}    # asserted rms |dlogit|  (observed 0.0018 / 0.0129)
 
 
 def greedy_rows_match_or_near_tie(got: torch.Tensor, want: dict, n_init: int, bound: float):
@@ -890,7 +892,7 @@ def test_turbo_dims_vs_oracle(turbo, gpu_device):
     full = sum(1 for t, _ in report if t is None)
     # observed: 11 of 32 rows equal over all 32 steps, the other 21 leave the oracle at a margin of 1e-4 ... 0.06 in its own
     # filtered logits (unit-scale logits, fp16 error up to 0.14): every one a near-tie, enforced above
-    check(full >= 8, ("fp16 rows equal to the oracle over all steps", full))
+    check(full >= 10, ("fp16 rows equal to the oracle over all steps", full))       # observed 11 of 32
     check(len({int(x) for x in want16["tokens"][:, T0:].flatten()}) >= 100, "degenerate oracle decode")
     rep["fp16_greedy"] = {"rows": 32, "steps": n_steps, "rows_equal_all_steps": full, "near_tie_bound": bound,
                           "teacher_forced": {"rows": 8, "positions": T0 + 8, "max_abs_dlogit": mx16, "rms_dlogit": rms16,
@@ -910,11 +912,85 @@ def test_turbo_dims_vs_oracle(turbo, gpu_device):
             worst = max(worst, float(d.max()) if len(d) else 0.0)
     rep["fp16_alignment_vs_fp32_engine"] = {"clips": 4, "words": total, "words_within_1_frame": within,
                                             "words_differing_more": total - within, "worst_seconds": worst}
-    check(total > 0 and within >= 0.8 * total, ("fp16 alignment: words within +-1 frame of the fp32 engine", within, total))
+    # observed 41 of 45 (random-init attention has no ridge: the DTW path is not stable under rounding; the alignment-
+    # conditioned checkpoint of test_alignment_conditioned_fp16_equals_fp32 is the frame-exact statement)
+    check(total > 0 and within >= 40 and within >= 0.88 * total, ("fp16 alignment: words within +-1 frame of the fp32 engine", within, total))
     rep["problems"] = [str(p) for p in problems]
     write_report("turbo_dims.json", rep)
     print("turbo dims report:", rep)
     assert not problems, problems
+
+
+@pytest.mark.parametrize("name,pos_gain,qk_gain", [("turbo", 40.0, 0.7), ("large-v3", 120.0, 0.5)])
+def test_alignment_conditioned_fp16_equals_fp32(name, pos_gain, qk_gain, large_v3, turbo, gpu_device):
+    """Word timestamps frame for frame (BASELINE configs[4] = turbo + word_timestamps).
+    Random-init cross attention has no ridge, so the DTW path of timing.py:141-151 is one of many nearly equally cheap ones
+    and rounding moves word boundaries by tenths of a second (the 41-of-45 figure of test_turbo_dims_vs_oracle).  Here the
+    seeded checkpoint is alignment-conditioned (oracle/condition.py::condition_alignment: the decoder's positional embedding
+    carries a time code, six cross-attention heads — installed as the model's alignment heads — read it against the same
+    code in the audio features), i.e. it has what a trained model has: heads that attend along the (token, time) diagonal.
+    On it, for 6 clips of 3 ... 40 text tokens and their own frame counts:
+      * fp32 strict engine (find_alignment_batch) == the oracle's alignment_matrix -> dtw_path -> word_times, exactly;
+      * fp16 engine == fp32 engine: every word start and end the SAME FRAME, all words, all clips; probabilities 3e-2."""
+    import base64
+    import gzip
+    import whisper_amd
+    from conftest import write_report
+    from oracle import condition
+    from whisper_amd.model import ModelDimensions, Whisper
+    from whisper_amd.synthetic import dims_dict
+    from whisper_amd.timing import find_alignment_batch
+    from whisper_amd.tokenizer import get_tokenizer
+    fd = large_v3 if name == "large-v3" else turbo
+    dims = fd.dims
+    L = dims.n_text_layer
+    heads = sorted([(L - 1, 3), (L - 1, 11), (L - 1, 19), (L - 2, 0), (L - 2, 7), (L - 2, 15)])
+    sd2 = dict(fd.sd)                                   # condition_alignment REPLACES the tensors it changes
+    info = condition.condition_alignment(sd2, dims, heads, seed=1, pos_gain=pos_gain, qk_gain=qk_gain)
+    om2 = oracle.OracleModel(dims, sd2)
+    model = Whisper(ModelDimensions(**dims_dict(dims)), sd2, device=gpu_device)
+    mask = np.zeros((dims.n_text_layer, dims.n_text_head), dtype=bool)
+    for l, h in heads:
+        mask[l, h] = True
+    model.set_alignment_heads(base64.b85encode(gzip.compress(mask.tobytes())))
+    assert model.alignment_heads.indices().T.tolist() == [list(x) for x in heads]
+    tok = get_tokenizer(True, num_languages=model.num_languages, language="en", task="transcribe")
+    texts = [tok.encode(" hello world this is a test of word level timing"),
+             tok.encode(" one two three"),
+             tok.encode(" the quick brown fox jumps over the lazy dog and keeps running for a while longer than anyone expected it to"),
+             tok.encode(" Unbelievably, the extraordinarily long-winded antidisestablishmentarian spoke uninterruptedly."),
+             tok.encode(" yes"),
+             tok.encode(" numbers like 1234567 and 3.14159 split into several tokens, as do names such as Przybyszewski")]
+    frames = [2 * int(12 + 11 * (len(t) + 6) + 6) for t in texts]           # the text spans its window, as speech does
+    assert max(frames) <= 3000
+    feats = condition.alignment_features(dims, len(texts), info["U_a"], seed=3)
+    got32 = find_alignment_batch(model, tok, texts, None, frames, audio_features=feats.to(gpu_device))
+    got16 = find_alignment_batch(model, tok, texts, None, frames, audio_features=feats.to(gpu_device).half())
+    n_words, exact32, same16, worst16, worst_p = 0, 0, 0, 0.0, 0.0
+    for i in range(len(texts)):
+        with torch.no_grad():
+            ws, we, wp = oracle.word_times(om2, tok, texts[i], feats[i: i + 1], frames[i], heads)
+        s32, e32, p32 = _word_arrays(got32[i])
+        s16, e16, p16 = _word_arrays(got16[i])
+        assert len(s32) == len(ws) == len(s16) and [w.word for w in got16[i]] == [w.word for w in got32[i]], i
+        n_words += len(ws)
+        exact32 += int(np.sum((np.abs(s32 - ws) < 1e-6) & (np.abs(e32 - we) < 1e-6)))
+        d = np.maximum(np.abs(s16 - s32), np.abs(e16 - e32)) if len(ws) else np.zeros(0)
+        same16 += int(np.sum(d < 1e-6))
+        worst16 = max(worst16, float(d.max()) if len(d) else 0.0)
+        worst_p = max(worst_p, float(np.abs(p16 - p32).max()) if len(d) else 0.0)
+        assert len(ws) == 0 or float(np.diff(ws).min()) >= 0.0                  # a monotone diagonal, not a degenerate path
+    rep = {"model": f"{name}, seeded weights + alignment conditioning ({len(heads)} heads)", "clips": len(texts), "words": n_words,
+           "fp32_engine_words_exact_vs_oracle": exact32, "fp16_words_same_frame_as_fp32_engine": same16,
+           "fp16_worst_seconds": worst16, "fp16_worst_probability_diff": worst_p, "frames": [f // 2 for f in frames]}
+    print("alignment-conditioned", rep)
+    write_report(f"alignment_conditioned_{name.replace('-', '_')}.json", rep)
+    assert n_words >= 60 and exact32 == n_words, rep
+    assert same16 == n_words and worst_p < 3e-2, rep
+    for eng in list(model._engines.values()):
+        eng.drop_cached_tasks()
+    model._engines.clear()
+    torch.cuda.empty_cache()
 
 
 def test_large_v3_full_depth_beam5_vs_oracle(large_v3, gpu_device):
