@@ -693,8 +693,9 @@ def test_conditioned_checkpoint_token_exact_224_steps(name, R, text_run, large_v
     feats = _offset_feats(dims, R, seed=12)
     sd2, om2 = _conditioned_copy(fd)
     notes = []
+    # two passes: the second one's top-ups are <= 0.75, a third one's were <= 0.013 (measured on the CPU for both models)
     built = condition.condition_greedy(om2, feats, init, n_steps, rules, seed=5, margin=(0.35, 3.0), text_run=text_run,
-                                       log=notes.append)
+                                       log=notes.append, passes=2)
     with torch.no_grad():
         want = oracle.greedy_decode(om2, feats, init, n_steps, rules, keep_logits=True)
     mg = condition.margins_of(want)
