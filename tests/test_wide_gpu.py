@@ -594,71 +594,52 @@ def test_large_v3_full_depth_vs_oracle(large_v3, gpu_device):
     assert distinct >= 40                                                       # the decode is not degenerate
 
 
-def test_fused_step_kernels_under_contention(large_v3, gpu_device):
+def _decode_under_contention(eng, feats, init, params, n_steps, want, tok, gpu_device):
     """The hand-off inside the fused step launches (csrc/xattn.hip) relies on nothing HIP promises about dispatch order
-    (MI355X_MICROARCH.md "Workgroup dispatch": order, timing and placement are undefined): every spin is bounded, a spin
-    that runs out is counted, and wh_task_greedy then re-runs the loop on the two-launch kernels.  The forced-time-out tests
-    prove the accounting; THIS test proves the protocol on a genuinely contended device: while a second stream keeps all
-    256 CUs busy with large GEMMs (torch / rocBLAS — other workgroups competing for the same CUs' wave slots, LDS and
-    memory queues, dispatched between and beside the step's own workgroups), the fused greedy decode of the large-v3 engine
-    (8 rows, 64 steps = 12 288 fused launches with a hand-off each) must return EXACTLY the ids and log-probabilities of a
-    task that never uses the fused kernels, decoded on an idle device.  Hand-off time-outs / fallbacks under contention are
-    legal (that is what the fallback is for) and are reported, not asserted to be zero; the answer must not change."""
-    from conftest import write_report
-    fd = large_v3
-    dims = fd.dims
-    eng = fd.engine(hip.WH_F16)
-    n_steps = 64
-    tok, init, params, rules, mask = _greedy_setup(dims, n_steps, gpu_device, suppress_eot=True)
+    (MI355X_MICROARCH.md "Workgroup dispatch": order, timing and placement are undefined): every spin is bounded, a spin that
+    runs out is counted, and wh_task_greedy then re-runs the loop on the two-launch kernels.  The forced-time-out tests prove
+    the accounting; THIS proves the protocol on a genuinely contended device: while a second stream keeps all 256 CUs busy
+    with large GEMMs (torch / rocBLAS: other workgroups competing for the same CUs' wave slots, LDS and memory queues,
+    dispatched between and beside the step's own workgroups), the fused greedy decode (8 rows x 224 steps = 14 336 fused
+    launches with a hand-off each) must still return the oracle's token ids for every row.  It runs on the margin-conditioned
+    checkpoint because only there is "the right answer" independent of the kernels' summation order (the fused cross
+    attention and its two-launch form differ in fp32 association; on random-init logits that alone flips near-ties).
+    Hand-off time-outs / fallbacks under contention are legal — that is what the fallback is for — and are reported."""
     T0 = len(init)
-    feats = _offset_feats(dims, 8, seed=9).to(gpu_device).half().contiguous()
-
-    def greedy(task):
-        task.set_audio(feats)
-        tokens = torch.zeros(8, T0 + n_steps + 1, dtype=torch.int64, device=gpu_device)
-        tokens[:, :T0] = torch.tensor(init, device=gpu_device)
-        n, lp, _ = task.greedy(tokens, params, 0, tok.no_speech)
-        return n, tokens.cpu(), lp.cpu()
-
-    ref = hip.HipTask(eng, 8, 1, 8, two_launch_self=True, two_launch_cross=True)
-    try:
-        want = greedy(ref)
-    finally:
-        ref.close()
-
+    R = feats.shape[0]
     side = torch.cuda.Stream(device=gpu_device)
     a = torch.randn(8192, 8192, device=gpu_device, dtype=torch.float16)
     b = torch.randn(8192, 8192, device=gpu_device, dtype=torch.float16)
     c = torch.empty(8192, 8192, device=gpu_device, dtype=torch.float16)
     torch.cuda.synchronize(gpu_device)
-    report = {"model": "large-v3 fp16, 8 rows x 64 steps, fused step kernels", "rounds": []}
-    for load in (0, 400, 1600):                       # GEMMs queued on the side stream before the decode starts (~1 ms each)
-        task = hip.HipTask(eng, 8, 1, 8)
+    rounds = []
+    for load in (0, 800, 3200):                      # GEMMs (~1 ms each) queued on the side stream before the decode starts
+        task = hip.HipTask(eng, R, 1, 8)
         try:
             assert task.fused_cross_attention and task.fused_self_attention
+            task.set_audio(feats.to(gpu_device, eng.torch_dtype).contiguous())
+            tokens = torch.zeros(R, T0 + n_steps + 1, dtype=torch.int64, device=gpu_device)
+            tokens[:, :T0] = torch.tensor(init, device=gpu_device)
             with torch.cuda.stream(side):
                 for _ in range(load):
                     torch.matmul(a, b, out=c)
                 busy = torch.cuda.Event()
                 busy.record(side)
             t0 = time.perf_counter()
-            got = greedy(task)
+            n, _, _ = task.greedy(tokens, params, 0, tok.no_speech)
             dt = time.perf_counter() - t0
-            still_busy = not busy.query()             # the side stream was still running when the decode finished
-            timeouts, fallbacks = task.handoff_timeouts(), task.handoff_fallbacks
-            report["rounds"].append({"side_gemms": load, "decode_ms": round(dt * 1e3, 1), "side_stream_outlasted_decode": still_busy,
-                                     "handoff_timeouts": timeouts, "handoff_fallbacks": fallbacks})
-            assert got[0] == want[0] and torch.equal(got[1], want[1]), (load, timeouts, fallbacks)
-            if fallbacks == 0:                        # the fused kernels produced it: cross attention sums in another order
-                assert float((got[2] - want[2]).abs().max()) < 0.5
-            else:                                     # re-run on the two-launch kernels: bit-identical
-                assert torch.equal(got[2], want[2])
+            outlasted = not busy.query()              # the side stream was still running when the decode finished
+            got = tokens[:, :n].cpu()
+            rounds.append({"side_gemms": load, "decode_ms": round(dt * 1e3, 1), "side_stream_outlasted_decode": outlasted,
+                           "handoff_timeouts": task.handoff_timeouts(), "handoff_fallbacks": task.handoff_fallbacks,
+                           "rows_equal": int(sum(torch.equal(got[k], want["tokens"][k]) for k in range(R)))})
+            assert torch.equal(got, want["tokens"]), rounds[-1]
         finally:
             task.close()
             torch.cuda.synchronize(gpu_device)
-    print("contention report:", report)
-    write_report("handoff_contention.json", report)
-    assert report["rounds"][-1]["side_stream_outlasted_decode"], "the side load ended before the decode did: not a contention test"
+    print("contention:", rounds)
+    assert rounds[-1]["side_stream_outlasted_decode"], "the side load ended before the decode did: not a contention test"
+    return rounds
 
 
 def _conditioned_copy(fd):
@@ -725,6 +706,8 @@ def test_conditioned_checkpoint_token_exact_224_steps(name, R, text_run, large_v
             assert n == T0 + n_steps
             assert equal == R, (label, first)                            # token-id exact: every row, all 224 steps
             assert lp_err < (2e-2 if dt == hip.WH_F32 else 5.0), (label, lp_err)
+            if dt == hip.WH_F16 and R <= 8:
+                rep["contention"] = _decode_under_contention(eng, feats, init, params, n_steps, want, tok, gpu_device)
         finally:
             eng.drop_cached_tasks()
             del eng
@@ -980,7 +963,7 @@ def test_alignment_conditioned_fp16_equals_fp32(name, pos_gain, qk_gain, large_v
         same16 += int(np.sum(d < 1e-6))
         worst16 = max(worst16, float(d.max()) if len(d) else 0.0)
         worst_p = max(worst_p, float(np.abs(p16 - p32).max()) if len(d) else 0.0)
-        assert len(ws) == 0 or float(np.diff(ws).min()) >= 0.0                  # a monotone diagonal, not a degenerate path
+        assert len(ws) < 2 or float(np.diff(ws).min()) >= 0.0                   # a monotone diagonal, not a degenerate path
     rep = {"model": f"{name}, seeded weights + alignment conditioning ({len(heads)} heads)", "clips": len(texts), "words": n_words,
            "fp32_engine_words_exact_vs_oracle": exact32, "fp16_words_same_frame_as_fp32_engine": same16,
            "fp16_worst_seconds": worst16, "fp16_worst_probability_diff": worst_p, "frames": [f // 2 for f in frames]}
