@@ -299,7 +299,7 @@ def main():
         # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/, per round),
         # and only when it was taken on this very workload; otherwise null.
         traffic, tsrc = None, None
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             tf = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
             if os.path.isfile(tf) and args.model == "large-v3" and B == 8:
                 with open(tf) as f:
