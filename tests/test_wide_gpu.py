@@ -649,7 +649,9 @@ def _conditioned_copy(fd):
     from oracle import condition
     sd2 = dict(fd.sd)
     sd2[condition.EMB] = fd.sd[condition.EMB].clone()
-    return sd2, oracle.OracleModel(fd.dims, sd2)
+    # sdpa: attention as the reference computes it by default (model.py:124-128).  The explicit form (model.py:130-139)
+    # rescales the whole cached K of every layer at every step — 3 x 224 oracle steps took 10 minutes that way, 90 s this way
+    return sd2, oracle.OracleModel(fd.dims, sd2, sdpa=True)
 
 
 @pytest.mark.parametrize("name,R,text_run", [("large-v3", 8, (4, 14)), ("turbo", 32, (10, 24))])

@@ -521,9 +521,10 @@ bool rows_kernel_applies(const whk::GemmArgs& a) {
   if (a.res || (a.ldc & 7) || (a.N & 3) || (a.c_bs & 7) || (((uintptr_t)a.C) & 15)) return false;
   if (((int64_t)a.M * a.lda + a.K) * 2 >= (1LL << 32) || ((int64_t)a.N * a.ldw + a.K) * 2 >= (1LL << 32)) return false;
   if (!(a.M >= 1024 && a.N >= 1024 && a.K % 128 == 0)) return false;      // the K loop takes two 64-wide steps per trip
-  // 256 x 256 tiles only when they fill most of the chip: one 30 s window of a small model (M = 1500) is 36 - 90 of
-  // them on 256 CUs — the general kernel's smaller tiles then put 3 - 8 x as many workgroups to work (launch_t)
-  return (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 160;
+  // small models (D <= 768: N, K <= 3072) with few 256 x 256 tiles — one 30 s window is 36 - 72 of them on 256 CUs — go to
+  // the general kernel's smaller tiles instead (launch_t)
+  if (a.N <= 3072 && a.K <= 3072 && (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) < 160) return false;
+  return true;
 }
 
 hipError_t launch_rows_any(const whk::GemmArgs& a, int batch, hipStream_t stream) {
@@ -558,13 +559,18 @@ hipError_t launch_t(const whk::GemmArgs& a, int batch, hipStream_t stream) {
   // tools/probe_gemm on MI355X (M = 12000): 256x256 is 12-17 % faster than 128x128 on every encoder shape (e.g.
   // N=2560 K=1280: 648 vs 548 TFLOP/s; N=1280 K=5120: 949 vs 809), and among 256x256 layouts 16 waves of 64x64 beat
   // 8 waves of 128x64 (760 vs 650 on the QKV shape); deeper LDS rings at lower occupancy were slower.
-  // Few tiles (one window, small models: BASELINE configs[1] is base x 1 clip, M = 1500, N = 512 ... 2048): the tile shrinks
-  // until ~200 workgroups exist — 128 x 128 (4 waves, two workgroups per CU), 64 x 128 (2 waves), 64 x 64 (1 wave).  The
-  // K order of every output element is the same in all shapes (bit-identical results).
+  // Few tiles on SMALL models (D <= 768, i.e. N, K <= 3072; BASELINE configs[1] is base x 1 clip: M = 1500, N = 512 ... 2048,
+  // 12 - 48 tiles of 256 x 256 on 256 CUs): the tile shrinks until ~200 workgroups exist — 128 x 128 (4 waves), 64 x 128
+  // (2 waves), 64 x 64 (1 wave); base x 1 encoder 0.87 -> 0.78 ms.  At large-v3 widths the same rule was a LOSS (the 185-token
+  // teacher-forced pass of the word-timestamp leg: 81 -> 150 ms per batch, gpurun calls 2 / 4 of round 4: K = 1280 ... 5120 is
+  // too long a loop for one- and two-wave workgroups), so there the round-2 choice stands.  The K order of every output
+  // element is the same in all shapes (bit-identical results).
   auto tiles = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * batch; };
-  const bool big = force ? force == 256 : (a.M >= 1024 && a.N >= 1024 && tiles(256, 256) >= 160);
+  const bool small_model = a.N <= 3072 && a.K <= 3072;
+  const bool big = force ? force == 256 : (a.M >= 1024 && a.N >= 1024 && !(small_model && tiles(256, 256) < 160));
   if (big) return launch_shape<T, OutT, 4, 4>(a, batch, stream);
-  if (force == 128 || tiles(128, 128) >= 192 || (int64_t)a.M * a.N <= 128 * 128) return launch_shape<T, OutT, 2, 2>(a, batch, stream);
+  if (force == 128 || !small_model || tiles(128, 128) >= 192 || (int64_t)a.M * a.N <= 128 * 128)
+    return launch_shape<T, OutT, 2, 2>(a, batch, stream);
   if (tiles(64, 128) >= 192) return launch_shape<T, OutT, 1, 2>(a, batch, stream);
   return launch_shape<T, OutT, 1, 1>(a, batch, stream);
 }
