@@ -10,7 +10,7 @@ import sys
 # bench name -> regex on "mangled name grid=(...)" rows (large-v3, 8 clips, fp16)
 PATTERNS = {
     # round 3: LN + projection + attention in one launch (xattn.hip); the two-launch kernels otherwise
-    "attn_decode_cross": r"(xattn8_kernel<8>|xattn8_kernelILi8E|attn_decode_kernelIDF16_Li16ELi4ELb0E.*grid=\(768,20,8\))",
+    "attn_decode_cross": r"(xattn8_kernel<8>|xattn8_kernel<8, false>|xattn8_kernelILi8E|attn_decode_kernelIDF16_Li16ELi4ELb0E.*grid=\(768,20,8\))",
     "attn_decode_self": r"(sattn8_kernel|attn_decode_kernelIDF16_Li8ELi8ELb1E.*grid=\(512,20,8\))",
     # gemv8_kernel<PRO, GS, KS, NU, CSm, XW, NRT>: LN = 1, PLAIN = 0, COMBINE = 2 (qkv / cq only in the two-launch form)
     "gemv_qkv": r"gemv8_kernel<1, 2, 4, 5, 1, 8, 1>",
