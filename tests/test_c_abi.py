@@ -112,3 +112,15 @@ def test_struct_layouts_match_the_header(tmp_path):
         assert int(got[cname]) == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def test_shipped_library_reads_no_experiment_switches():
+    """developer A/B switches and rejected experiments live in the -DWH_DEV build only
+    (`make -C whisper_amd/csrc dev`).  The shipped library's data must not contain a single `WH_*` environment-variable
+    name besides WH_NO_GRAPH (decode steps launched eagerly: a support switch)."""
+    import re
+    from whisper_amd import hip
+    with open(hip.lib_path(), "rb") as f:
+        blob = f.read()
+    names = {m.decode() for m in re.findall(rb"WH_[A-Z0-9_]{3,}", blob)}
+    assert names == {"WH_NO_GRAPH"}, names
