@@ -7,7 +7,7 @@ import bench
 from whisper_amd.synthetic import dims_for
 from whisper_amd.tokenizer import get_tokenizer
 model = sys.argv[1] if len(sys.argv) > 1 else "large-v3"
-args = types.SimpleNamespace(model=model, cpu_steps=12, cpu_repeats=3, sample_len=224, cpu_threads=int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+args = types.SimpleNamespace(model=model, cpu_steps=12, cpu_repeats=3, sample_len=224, parity_steps=0, cpu_threads=int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dims = dims_for(model)
 tok = get_tokenizer(True, num_languages=dims.n_vocab - 51765 - 1, language="en", task="transcribe")
 init = list(tok.sot_sequence)
