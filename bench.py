@@ -401,13 +401,15 @@ def main():
                 text = [[t for t in r.tokens if t < tok.eot][:200] for r in res]
                 find_alignment_batch(wmodel, tok, text, mel.half(), [3000] * B)
                 torch.cuda.synchronize(device)
-                t0 = time.perf_counter()
-                stats = {}
-                for _ in range(2):
+                stats, wts = {}, []
+                for _ in range(3):          # median of three: a single call is now and then 3 x slower (allocator churn of the
+                    t0 = time.perf_counter()                                      # 6 GB score slabs), seen as 75 vs 150 ms between runs
                     al = find_alignment_batch(wmodel, tok, text, mel.half(), [3000] * B, stats=stats)
-                torch.cuda.synchronize(device)
-                wms = (time.perf_counter() - t0) / 2 * 1e3
+                    torch.cuda.synchronize(device)
+                    wts.append((time.perf_counter() - t0) * 1e3)
+                wms = sorted(wts)[1]
                 extras["word_timestamps"] = {"clips": B, "text_tokens_per_clip": len(text[0]), "ms_per_batch": round(wms, 2),
+                                             "calls_ms": [round(x, 1) for x in wts],
                                              "words": sum(len(a) for a in al),
                                              # wall clock until the device results (paths, probabilities) are on the host /
                                              # host-only work after that (word split, boundaries), last batch
