@@ -122,7 +122,8 @@ int main(int argc, char** argv) {
                   {"self:  two launches (LN->qkv + attention)", 2}, {"self:  fused sattn8", 3},
                   {"attn.out + residual alone", 4}, {"pair: fused sattn8, then attn.out", 5},
                   {"pair: attn.out, then fused xattn8", 6},
-                  {"ONE launch: attn.out as phase 0 of xattn8", 7}};
+                  {"ONE launch: attn.out as phase 0 of xattn8", 7},
+                  {"cross: fused xattn8, HEAD-MAJOR K / V layout", 8}};
   for (const Case& c : cases) {
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipMemset(d_probe, 0, 4096 * 8 * 8));
@@ -136,6 +137,13 @@ int main(int argc, char** argv) {
       if (c.kind == 4) ok = ok && out_proj(i);
       if (c.kind == 5) { whk::SAttnArgs sa = sargs(i); sa.probe = nullptr; ok = ok && whk::launch_sattn8(sa, st) == hipSuccess && out_proj(i); }
       if (c.kind == 6) { whk::XAttnArgs xa = xargs(i); xa.probe = nullptr; ok = ok && out_proj(i) && whk::launch_xattn8(xa, st) == hipSuccess; }
+      if (c.kind == 8) {          // K [row][head][key][64] and V likewise in the second half of the layer's block: contiguous 64 KB per split
+        whk::XAttnArgs xa = xargs(i);
+        half_t* base = ckv + (size_t)(i % L) * R * Ta * 2 * D;
+        xa.k = base; xa.v = base + (size_t)R * Ta * D;
+        xa.k_ld = 64; xa.v_ld = 64; xa.k_bs = (int64_t)H * Ta * 64; xa.v_bs = xa.k_bs; xa.kv_hs = (int64_t)Ta * 64;
+        ok = ok && whk::launch_xattn8(xa, st) == hipSuccess;
+      }
       if (c.kind == 7) {
         whk::XAttnArgs xa = xargs(i);
         xa.att_in = att; xa.out_w = Wo + (size_t)(i % L) * D * D; xa.out_b = bias; xa.x_io = xf; xa.pflags = og;
@@ -154,7 +162,7 @@ int main(int argc, char** argv) {
     }
     int err = 0; CK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
     printf("%-46s %6.2f us per link%s (pos %d, hand-off timeouts %d)\n", c.name, best * 1e3f / N, c.kind >= 5 ? " (= per PAIR)" : "", pos, err);
-    if (c.kind == 1 || c.kind == 3 || c.kind == 7) {
+    if (c.kind == 1 || c.kind == 3 || c.kind == 7 || c.kind == 8) {
       const int nwg = c.kind != 3 ? S * H * R : 3 * D / 8;
       std::vector<long long> p((size_t)nwg * 8);
       CK(hipMemcpy(p.data(), d_probe, p.size() * 8, hipMemcpyDeviceToHost));

@@ -7,10 +7,12 @@
 // workgroup records s_memtime at phase boundaries.  Compiled out of libwhisper_hip.so.
 #ifdef WH_PROBE
 #define WH_PROBE_FIELD long long* probe;
+#define WH_PROBE_KVHS_FIELD int64_t kv_hs;   /* probe builds only: head stride of the cross K / V (0 = 64: heads side by side in a key row) */
 #define WH_PROBE_AT(args, wg, i) \
   do { if ((args).probe && threadIdx.x == 0) (args).probe[(size_t)(wg) * 8 + (i)] = clock64(); } while (0)
 #else
 #define WH_PROBE_FIELD
+#define WH_PROBE_KVHS_FIELD
 #define WH_PROBE_AT(args, wg, i) do {} while (0)
 #endif
 
@@ -169,6 +171,7 @@ struct XAttnArgs {
   // once; tags never repeat), att_in = fp16 [R][D] attention rows of the self attention
   const void* att_in; const void* out_w; const float* out_b; float* x_io; unsigned long long* pflags;
   WH_PROBE_FIELD
+  WH_PROBE_KVHS_FIELD
 };
 int fused_mode(int kind);
 bool xattn_supported(int D, int H, int R, int kv_group, int Tk, int splits);
