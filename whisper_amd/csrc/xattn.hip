@@ -488,11 +488,12 @@ __global__ __launch_bounds__(768, 6) void xattn8_kernel(whk::XAttnArgs a) {
   {
 #ifdef WH_PROBE      // tools/probe_fused: the same kernel on a head-major K / V layout (a key row = 128 contiguous bytes per head)
     const int64_t hs = a.kv_hs ? a.kv_hs : 64;
-#else
-    constexpr int64_t hs = 64;
-#endif
     const half_t* kp = (const half_t*)a.k + (int64_t)r * a.k_bs + h * hs + cu * 8;
     const half_t* vp = (const half_t*)a.v + (int64_t)r * a.v_bs + h * hs + cu * 8;
+#else
+    const half_t* kp = (const half_t*)a.k + (int64_t)r * a.k_bs + h * 64 + cu * 8;
+    const half_t* vp = (const half_t*)a.v + (int64_t)r * a.v_bs + h * 64 + cu * 8;
+#endif
     const int klast = nkeys > 0 ? nkeys - 1 : 0;
     const uint32_t ldk = (uint32_t)a.k_ld, ldv = (uint32_t)a.v_ld;
     const uint32_t ok0 = (uint32_t)(k0 + kk0) * ldk, okl = (uint32_t)(k0 + klast) * ldk;
