@@ -561,9 +561,10 @@ hipError_t launch_t(const whk::GemmArgs& a, int batch, hipStream_t stream) {
   // 8 waves of 128x64 (760 vs 650 on the QKV shape); deeper LDS rings at lower occupancy were slower.
   // Few tiles on SMALL models (D <= 768, i.e. N, K <= 3072; BASELINE configs[1] is base x 1 clip: M = 1500, N = 512 ... 2048,
   // 12 - 48 tiles of 256 x 256 on 256 CUs): the tile shrinks until ~200 workgroups exist — 128 x 128 (4 waves), 64 x 128
-  // (2 waves), 64 x 64 (1 wave); base x 1 encoder 0.87 -> 0.78 ms.  At larger widths (K = 1024 ... 5120: a long loop for one- and
-  // two-wave workgroups) the rule has no clean measurement behind it — the bench leg it was judged on turned out to be
-  // bimodal for another reason — so there the round-2 choice stands.  The K order of every output element is the same in
+  // (2 waves), 64 x 64 (1 wave); base x 1 encoder 0.87 -> 0.78 ms.  At larger widths it buys nothing: the 185-token teacher-forced
+  // pass of the word-timestamp leg (M = 1480, large-v3) takes 78.7 ms per batch with 128 x 128 tiles everywhere against 79.3 ms
+  // with the product's 256 x 256 choice (development build, WH_GEMM_DEV=1 WH_GEMM_TILE=128, gpurun call 11 of round 4), and the
+  // 8-clip encoder loses 2 % — so there the round-2 choice stands.  The K order of every output element is the same in
   // all shapes (bit-identical results).
   auto tiles = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * batch; };
   const bool small_model = a.N <= 3072 && a.K <= 3072;
