@@ -662,7 +662,7 @@ def test_conditioned_checkpoint_token_exact_224_steps(name, R, text_run, large_v
     margin-conditioned (oracle/condition.py: rows of the tied embedding of the tokens the decode emits are moved along the
     hidden state that emits them until the oracle's arg-max — and the timestamp-mass rule — are decided by a drawn
     margin, as a trained model's are); the plain oracle then re-decodes and the margins are ASSERTED on its own filtered
-    logits: min >= 0.2, median >= 1.0 over rows x 224 steps.  On that checkpoint
+    logits: min >= 0.3 (built at 0.35), median >= 1.0 over rows x 224 steps.  On that checkpoint
       * the fp16 engine (what bench.py times: fused step kernels, hipGraph, device-side sampler) must reproduce the fp32
         oracle's token ids for EVERY row and ALL 224 steps — no near-tie rule, no slack;
       * so must the fp32 strict engine, and its sum_logprobs agree to 2e-2 over 224 tokens.
@@ -686,7 +686,7 @@ def test_conditioned_checkpoint_token_exact_224_steps(name, R, text_run, large_v
     mg = condition.margins_of(want)
     print("conditioned", name, mg, notes[-3:])
     assert torch.equal(want["tokens"], built["tokens"])                  # the plain oracle decodes what was built
-    assert mg["min"] >= 0.2 and mg["median"] >= 1.0 and mg.get("rule_min", 1.0) >= 0.2, mg
+    assert mg["min"] >= 0.3 and mg["median"] >= 1.0 and mg.get("rule_min", 1.0) >= 0.3, mg       # built at 0.35
     n_ts = int((want["tokens"][:, T0:] >= tok.timestamp_begin).sum())
     distinct = len({int(x) for x in want["tokens"][:, T0:].flatten()})
     assert distinct == R * n_steps and n_ts >= 2 * R                     # every decision is its own token; timestamps occur
@@ -709,7 +709,7 @@ def test_conditioned_checkpoint_token_exact_224_steps(name, R, text_run, large_v
                 rep["engines"][label]["teacher_forced_rms_dlogit"] = rms
             assert n == T0 + n_steps
             assert equal == R, (label, first)                            # token-id exact: every row, all 224 steps
-            assert lp_err < (2e-2 if dt == hip.WH_F32 else 5.0), (label, lp_err)
+            assert lp_err < (2e-2 if dt == hip.WH_F32 else 0.3), (label, lp_err)     # fp16 observed 0.18 over 224 tokens
             if dt == hip.WH_F16 and R <= 8:
                 rep["contention"] = _decode_under_contention(eng, feats, init, params, n_steps, want, tok, gpu_device)
         finally:
@@ -868,8 +868,28 @@ def test_turbo_dims_vs_oracle(turbo, gpu_device):
     tk, init, params, rules, mask = _greedy_setup(dims, n_steps, gpu_device, suppress_eot=True)
     with torch.no_grad():
         want16 = oracle.greedy_decode(om, feats32r, init, n_steps, rules, keep_logits=True)
-    mx16, rms16, pp16 = _tf_error(fd, hip.WH_F16, feats32r[:8], want16["tokens"][:8, : T0 + 8].contiguous(), T0)
+    tf_toks = want16["tokens"][:8, : T0 + 8].contiguous()
+    mx16, rms16, pp16 = _tf_error(fd, hip.WH_F16, feats32r[:8], tf_toks, T0)
     check(mx16 < FP16_FULL_DEPTH_MAX["turbo"] and rms16 < FP16_FULL_DEPTH_RMS["turbo"], ("fp16 logit error", mx16, rms16))
+    # ATTRIBUTION ("defect or rounding?").  The engine is one packed blob per dtype, so stages cannot
+    # be swapped to fp32 one at a time; instead the fp32 oracle is run with fp16 round trips at the sites where the engine
+    # stores or consumes fp16 (oracle/rounding.py), one site at a time and all together, on the SAME rows and tokens.  If
+    # rounding at those sites is all there is, the engine's measured rms error equals the all-sites figure (summation order
+    # aside); a defective kernel would put it above.  Measured on the CPU for this input: every site contributes 0.004-0.006
+    # rms (cross K/V cache the most, the logits GEMV's input the least), all together 0.012 — the engine measured 0.013.
+    # The 8 x swing against `_offset_feats` is the INPUT's conditioning, not a site: the same 1e-3 perturbation of the residual
+    # stream after block 0 moves the logits by 2.4e-3 rms on these features and by 5e-5 on offset features (the per-clip
+    # offset puts a large constant into every cross-attention value, the residual stream's rms grows 4.3 -> 11.4 and every
+    # following LayerNorm divides a perturbation by it: tools/attribute_fp16_error.py).
+    from oracle.rounding import site_table
+    sites = site_table(dims, fd.sd, tf_toks, feats32r[:8])
+    model_rms, model_max = sites["ALL"]["rms"], sites["ALL"]["max"]
+    rep["fp16_error_attribution"] = {"input": "_feats(seed=33), 8 rows x (T0 + 8) positions, the oracle's greedy path",
+                                     "rounding_model_per_site": sites, "engine_measured": {"max": mx16, "rms": rms16},
+                                     "engine_rms_over_model_rms": rms16 / model_rms}
+    check(0.6 * model_rms < rms16 < 1.5 * model_rms, ("fp16 engine rms error vs the rounding model", rms16, model_rms))
+    check(mx16 < 2.5 * model_max, ("fp16 engine max error vs the rounding model", mx16, model_max))
+    check(max(v["rms"] for k, v in sites.items() if k != "ALL") < 0.75 * model_rms, ("one rounding site carries the error", sites))
     n, got16, _, _ = _run_greedy(fd.engine(hip.WH_F16), feats32r.to(gpu_device).half(), init, params, n_steps, gpu_device, tk)
     check(n == T0 + n_steps, "fp16 greedy step count")
     bound = 2 * FP16_FULL_DEPTH_MAX["turbo"]
@@ -954,6 +974,17 @@ def test_alignment_conditioned_fp16_equals_fp32(name, pos_gain, qk_gain, large_v
     feats = condition.alignment_features(dims, len(texts), info["U_a"], seed=3)
     got32 = find_alignment_batch(model, tok, texts, None, frames, audio_features=feats.to(gpu_device))
     got16 = find_alignment_batch(model, tok, texts, None, frames, audio_features=feats.to(gpu_device).half())
+    # The features above are handed to both engines, so the fp16 ENCODER's own error never reaches the DTW (VERDICT round 4,
+    # weak 3).  It does here: the features of the fp16 engine are perturbed by what test_large_v3_full_depth_vs_oracle measures
+    # for the fp16 encoder at 32 layers (max 2e-3 ... 4e-2 asserted, rms 3.5e-4 measured): seeded noise of rms 3.5e-4, clipped
+    # at +-2e-3 with the extremes present, then rounded to fp16 as the encoder's output is.  Same frames required.
+    gp = torch.Generator().manual_seed(11)
+    delta = (3.5e-4 * torch.randn(feats.shape, generator=gp)).clamp_(-2e-3, 2e-3)
+    delta.view(-1)[torch.randperm(delta.numel(), generator=gp)[:64]] = 2e-3
+    delta.view(-1)[torch.randperm(delta.numel(), generator=gp)[:64]] = -2e-3
+    feats_p = (feats + delta).half()
+    got16p = find_alignment_batch(model, tok, texts, None, frames, audio_features=feats_p.to(gpu_device))
+    same16p, worst16p = 0, 0.0
     n_words, exact32, same16, worst16, worst_p = 0, 0, 0, 0.0, 0.0
     for i in range(len(texts)):
         with torch.no_grad():
@@ -967,14 +998,23 @@ def test_alignment_conditioned_fp16_equals_fp32(name, pos_gain, qk_gain, large_v
         same16 += int(np.sum(d < 1e-6))
         worst16 = max(worst16, float(d.max()) if len(d) else 0.0)
         worst_p = max(worst_p, float(np.abs(p16 - p32).max()) if len(d) else 0.0)
+        sp, ep, _ = _word_arrays(got16p[i])
+        assert len(sp) == len(s32) and [w.word for w in got16p[i]] == [w.word for w in got32[i]], i
+        dp = np.maximum(np.abs(sp - s32), np.abs(ep - e32)) if len(ws) else np.zeros(0)
+        same16p += int(np.sum(dp < 1e-6))
+        worst16p = max(worst16p, float(dp.max()) if len(dp) else 0.0)
         assert len(ws) < 2 or float(np.diff(ws).min()) >= 0.0                   # a monotone diagonal, not a degenerate path
     rep = {"model": f"{name}, seeded weights + alignment conditioning ({len(heads)} heads)", "clips": len(texts), "words": n_words,
            "fp32_engine_words_exact_vs_oracle": exact32, "fp16_words_same_frame_as_fp32_engine": same16,
-           "fp16_worst_seconds": worst16, "fp16_worst_probability_diff": worst_p, "frames": [f // 2 for f in frames]}
+           "fp16_worst_seconds": worst16, "fp16_worst_probability_diff": worst_p, "frames": [f // 2 for f in frames],
+           "fp16_with_encoder_error": {"perturbation": {"max_abs": float((feats_p.float() - feats).abs().max()),
+                                                         "rms": float((feats_p.float() - feats).pow(2).mean().sqrt()), "seed": 11},
+                                       "words_same_frame_as_fp32_engine": same16p, "worst_seconds": worst16p}}
     print("alignment-conditioned", rep)
     write_report(f"alignment_conditioned_{name.replace('-', '_')}.json", rep)
     assert n_words >= 60 and exact32 == n_words, rep
     assert same16 == n_words and worst_p < 3e-2, rep
+    assert same16p == n_words, rep                                              # with the fp16 encoder's error in the loop
     for eng in list(model._engines.values()):
         eng.drop_cached_tasks()
     model._engines.clear()
@@ -1047,3 +1087,62 @@ def test_large_v3_full_depth_beam5_vs_oracle(large_v3, gpu_device):
     print("fp16 beam-5 full depth:", rows)
     assert n_eq + n_tie == 8, rows
     assert n_eq >= 6, rows              # observed: all 8 winners equal
+
+
+def test_conditioned_checkpoint_beam5_winners_exact_64_steps(large_v3, gpu_device):
+    """BASELINE.json configs[3] at the length bench.py times it, WITHOUT a near-tie rule:
+    large-v3 (32 + 32 layers), 8 audio x beam 5 = 40 rows, 64 forced steps (EOT suppressed, as bench.py's beam leg), on the
+    margin-conditioned checkpoint (oracle/condition.py, conditioned along the 64-step greedy decode of these clips: peaked
+    next-token distributions, as a trained model has).  The oracle's BeamSearchDecoder + MaximumLikelihoodRanker restatement
+    (whisper/decoding.py:301-404, 190-213, 734-740) gives every audio's ranked winner; its own separation from the runner-up
+    hypothesis is ASSERTED first (>= 0.3 in sum_logprob: the test is not decided by rounding), then
+      * the fp16 engine (device-side beam loop, 48-row projection kernels, group attention, in-place cache permutation):
+        the winner's token sequence equals the oracle's for ALL 8 audio, sum_logprob within 0.3;
+      * the fp32 strict engine (the one that meets north_star's 1e-3 beam tolerance): the same, sum_logprob within 2e-2."""
+    import whisper_amd
+    from conftest import write_report
+    from oracle import condition
+    from whisper_amd.model import ModelDimensions, Whisper
+    from whisper_amd.synthetic import dims_dict
+    fd = large_v3
+    dims = fd.dims
+    n_steps, G = 64, 5
+    tok, init, params, rules, mask = _greedy_setup(dims, n_steps, gpu_device, suppress_eot=True)
+    T0 = len(init)
+    feats = _offset_feats(dims, 8, seed=12)
+    sd2, om2 = _conditioned_copy(fd)
+    built = condition.condition_greedy(om2, feats, init, n_steps, rules, seed=5, margin=(0.35, 3.0), text_run=(4, 14), passes=2)
+    with torch.no_grad():
+        want = oracle.beam_decode(om2, feats, init, n_steps, rules, G)
+    winners, gaps = [], []
+    for a in range(8):
+        body, lp = oracle.decoding.rank_candidates(want["candidates"][a], T0, tok.eot)
+        winners.append((body, lp))
+        scores = sorted((v for _, v in want["candidates"][a]), reverse=True)
+        assert len(scores) == G and len(body) == n_steps
+        gaps.append(scores[0] - scores[1])
+    assert min(gaps) >= 0.3, gaps                                        # the oracle's own decision is not a near-tie
+    follows_greedy = sum(w[0] == built["tokens"][a, T0:].tolist() for a, w in enumerate(winners))
+    model = Whisper(ModelDimensions(**dims_dict(dims)), sd2, device=gpu_device)
+    rep = {"model": f"large-v3, seeded weights + margin-conditioned tied embedding ({len(built['rows'])} rows edited)", "audio": 8,
+           "beam": G, "rows": 8 * G, "steps": n_steps, "oracle_winner_minus_runner_up": [round(x, 3) for x in gaps],
+           "oracle_winners_equal_to_greedy_path": follows_greedy, "engines": {}}
+    try:
+        for fp16, label, lp_tol in ((True, "fp16", 0.3), (False, "fp32", 2e-2)):
+            opts = whisper_amd.DecodingOptions(language="en", fp16=fp16, sample_len=n_steps, beam_size=G, suppress_tokens=[-1, tok.eot])
+            x = feats.to(gpu_device)
+            res = whisper_amd.decode(model, x.half() if fp16 else x, opts)
+            equal = [r.tokens == winners[a][0] for a, r in enumerate(res)]
+            lp_err = max(abs(r.avg_logprob * (len(r.tokens) + 1) - winners[a][1]) for a, r in enumerate(res))
+            rep["engines"][label] = {"winners_equal": sum(equal), "per_audio_equal": equal, "max_sum_logprob_err": lp_err,
+                                     "first_divergence": [None if e else oracle.first_divergence(r.tokens, winners[a][0])
+                                                          for a, (e, r) in enumerate(zip(equal, res))]}
+            print("conditioned beam-5 x 64:", label, rep["engines"][label])
+            assert all(equal), (label, rep["engines"][label])
+            assert lp_err < lp_tol, (label, lp_err)
+    finally:
+        write_report("conditioned_large_v3_beam5.json", rep)
+        for eng in list(model._engines.values()):
+            eng.drop_cached_tasks()
+        model._engines.clear()
+        torch.cuda.empty_cache()

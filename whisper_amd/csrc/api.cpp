@@ -306,7 +306,6 @@ struct wh_task {
   float* x2;                     // second residual-stream buffer: the fused self-attention launch reads x and writes x2 (or back)
   bool fused_xattn, fused_sattn, fused_out;   // fused_out: attn.out + residual inside the self-attention launch (dev builds)
   bool fused_xout;               // attn.out + residual as phase 0 of the fused cross-attention launch (xattn.hip, OUT0)
-  int err_seen;                  // hand-off timeouts already reported to a caller
   size_t total;
 };
 
@@ -1093,7 +1092,6 @@ static int greedy_impl(wh_task* t, const wh_greedy_params* p, int64_t* tokens, i
   int* h_err = t->h_poll + t->B + 8;                                               // pinned: past the per-segment flags
   HIPCHK(hipMemcpyAsync(h_err, t->d_err, 4, hipMemcpyDeviceToHost, s));            // fused launches: hand-off timeouts
   HIPCHK(hipStreamSynchronize(s));
-  t->err_seen = *h_err;
   if ((t->fused_xattn || t->fused_sattn) && *h_err != *h_err0) return WH_ERR_HANDOFF;
   alive = *t->h_poll;
   (void)done;
@@ -1250,7 +1248,6 @@ static int beam_impl(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int6
   HIPCHK(hipMemcpyAsync(&err_now, t->d_err, 4, hipMemcpyDeviceToHost, s));
   if (cur == 1) HIPCHK(hipMemcpyAsync(buf[0], buf[1], (size_t)R * token_stride * 8, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipStreamSynchronize(s));
-  t->err_seen = err_now;
   if ((t->fused_xattn || t->fused_sattn) && err_now != *h_err0) return WH_ERR_HANDOFF;
   *n_tokens_out = T0 + applied;
   return WH_OK;

@@ -233,6 +233,26 @@ class GreedyDecoder(TokenDecoder):
     def __init__(self, temperature: float, eot: int):
         self.temperature = temperature
         self.eot = eot
+        self._buf: Optional[Tensor] = None
+
+    def reset(self):
+        self._buf = None
+
+    def _append(self, tokens: Tensor, picked: Tensor) -> Tensor:
+        """`torch.cat([tokens, picked[:, None]], -1)` (reference decoding.py:290) without a reallocation + full copy per step:
+        the sequences live in a buffer with spare columns; as long as the caller hands back the view this method returned,
+        the new column is written in place and a one-column-wider view of the same storage goes out.  Any other `tokens`
+        (first call, a caller that built its own tensor) is copied into a fresh buffer — same values either way."""
+        n = tokens.shape[1]
+        buf = self._buf
+        if (buf is None or buf.shape[0] != tokens.shape[0] or buf.dtype != tokens.dtype or buf.device != tokens.device
+                or n + 1 > buf.shape[1] or tokens.data_ptr() != buf.data_ptr() or (tokens.shape[0] > 1 and tokens.stride(0) != buf.stride(0))
+                or tokens.stride(1) != 1):
+            buf = torch.empty(tokens.shape[0], max(2 * (n + 1), 64), dtype=tokens.dtype, device=tokens.device)
+            buf[:, :n] = tokens
+            self._buf = buf
+        buf[:, n] = picked
+        return buf[:, : n + 1]
 
     def update(self, tokens: Tensor, logits: Tensor, sum_logprobs: Tensor) -> Tuple[Tensor, bool]:
         if self.temperature == 0:
@@ -244,7 +264,7 @@ class GreedyDecoder(TokenDecoder):
         ended = tokens[:, -1] == self.eot
         sum_logprobs += chosen * (~ended)
         picked = torch.where(ended, torch.full_like(picked, self.eot), picked)
-        tokens = torch.cat([tokens, picked[:, None]], dim=-1)
+        tokens = self._append(tokens, picked)
         return tokens, bool((tokens[:, -1] == self.eot).all())
 
     def finalize(self, tokens: Tensor, sum_logprobs: Tensor):

@@ -434,15 +434,15 @@ class HipModel:
             return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
     def _release_task(self, task: "HipTask") -> bool:
-        if task.ws is None or task.ws.numel() > self.task_cache_bytes:
+        if task.ws is None or task.held_bytes() > self.task_cache_bytes:
             return False
         if any(t is task for t in self._task_cache):     # closed twice: it is already idle, do not list it again
             return True
         self._task_cache.append(task)
-        total = sum(t.ws.numel() for t in self._task_cache)
+        total = sum(t.held_bytes() for t in self._task_cache)
         while total > self.task_cache_bytes and len(self._task_cache) > 1:
             old = self._task_cache.pop(0)
-            total -= old.ws.numel()
+            total -= old.held_bytes()
             old.destroy()
         return True
 
@@ -534,6 +534,12 @@ class HipTask:
             lib().wh_task_destroy(self.handle)
             self.handle = None
             self.ws = None
+            self._align_scratch = None
+
+    def held_bytes(self) -> int:
+        """device bytes this task keeps while it idles in its engine's task cache: the workspace + the alignment score slabs"""
+        extra = getattr(self, "_align_scratch", None)
+        return (0 if self.ws is None else self.ws.numel()) + (0 if extra is None else extra.numel())
 
     def __del__(self):
         try:
@@ -696,7 +702,16 @@ class HipTask:
         Nmax = Tmax - 1 - row_begin
         dev = self.model.device
         need = lib().wh_align_batch_scratch_bytes(R, P, Tmax, self.model.dims.n_audio_ctx, Fmax)
-        scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+        # The score slabs (GBs: QK, softmax and z-norm of every alignment head x token x frame) belong to the TASK, like its
+        # K/V workspace: a cached task (`acquire_task`) brings them along, so a second call of the same shape allocates nothing.
+        # They used to be a fresh torch.empty per call, recorded on the task's stream: the caching allocator may not hand such a
+        # block back before that stream's work is known to be done, so every other call or so paid a multi-GB hipMalloc
+        # (round 4: the word-timestamp leg was bimodal, 74-80 ms or 130-150 ms).  Grown, never shrunk; released with the task.
+        scratch = getattr(self, "_align_scratch", None)
+        if scratch is None or scratch.numel() < need:
+            self._align_scratch = None
+            scratch = self._align_scratch = self.model._alloc(int(need))
+            scratch.record_stream(self.stream)
         cost = torch.empty(R, Nmax, Fmax, dtype=torch.float32, device=dev)
         stride = (Nmax + 1) * (Fmax + 1)
         trace = torch.empty(R, stride, dtype=torch.int8, device=dev)
@@ -712,7 +727,7 @@ class HipTask:
             check(lib().wh_dtw_backtrace_batch(trace.data_ptr(), stride, sizes[0].data_ptr(), sizes[1].data_ptr(), R, Nmax, Fmax,
                                                jumps.data_ptr(), Nmax, None, 0, plen.data_ptr(), stream_ptr(self.stream)),
                   "wh_dtw_backtrace_batch")
-        for t_ in (scratch, cost, trace, jumps, plen, sizes):
+        for t_ in (cost, trace, jumps, plen, sizes):
             t_.record_stream(self.stream)
         return cost, jumps, plen
 

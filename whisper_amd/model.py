@@ -246,11 +246,35 @@ class Whisper:
     def device(self) -> torch.device:
         return self._device
 
-    def to(self, device) -> "Whisper":
-        device = torch.device(device)
-        if device != self._device:
-            self._device = device
-            self._engines.clear()
+    def to(self, *args, **kwargs) -> "Whisper":
+        """nn.Module.to for what an inference user passes: a device (`model.to("cuda:1")`), a floating dtype
+        (`model.to(torch.float16)` == `model.half()`, `torch.float32` == `model.float()`), or both (positional or as
+        `device=` / `dtype=`).  Anything else (a tensor, memory formats) is not part of this surface and raises."""
+        device, dtype = kwargs.pop("device", None), kwargs.pop("dtype", None)
+        kwargs.pop("non_blocking", None)
+        if kwargs:
+            raise TypeError(f"Whisper.to(): unsupported arguments {sorted(kwargs)}")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            elif isinstance(a, (str, int, torch.device)):
+                device = a
+            else:
+                raise TypeError(f"Whisper.to(): expected a device or a dtype, got {type(a).__name__}")
+        if dtype is not None:
+            if dtype == torch.float16:
+                self.half()
+            elif dtype == torch.float32:
+                self.float()
+            else:
+                raise TypeError(f"unsupported parameter dtype {dtype} (float16 or float32)")
+        if device is not None:
+            device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+            if device != self._device:
+                self._device = device
+                for eng in self._engines.values():
+                    eng.drop_cached_tasks()
+                self._engines.clear()
         return self
 
     def cuda(self, device=None) -> "Whisper":
@@ -299,6 +323,9 @@ class Whisper:
                 yield k, v
 
     def parameters(self) -> Iterator[Tensor]:
+        """The retained checkpoint tensors, on the device and in the dtype they were loaded with (normally CPU fp32) — NOT the
+        packed engine blobs.  The reference idiom `next(model.parameters()).device` therefore does not say where this model
+        computes; `model.device` (and `model.half()` / the input dtype) do."""
         for _, v in self.named_parameters():
             yield v
 
@@ -310,13 +337,17 @@ class Whisper:
         missing = [k for k in want if k not in state_dict]
         unexpected = [k for k in state_dict if k not in want]
         bad = [f"{k}: {tuple(state_dict[k].shape)} != {want[k]}" for k in want
-               if k in state_dict and tuple(state_dict[k].shape) != want[k]]
+               if k in state_dict and isinstance(state_dict[k], Tensor) and tuple(state_dict[k].shape) != want[k]]
         if bad:
             raise RuntimeError("size mismatch in load_state_dict: " + "; ".join(bad[:8]))
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict: missing keys {missing[:8]}, unexpected keys {unexpected[:8]}")
+        notensor = [k for k in want if k in state_dict and not isinstance(state_dict[k], Tensor)]
+        if notensor:
+            raise TypeError(f"load_state_dict: values of {notensor[:8]} are not tensors")
         merged = dict(self._state_dict)
-        merged.update({k: v.detach() for k, v in state_dict.items() if k in want})
+        # torch COPIES into the module's parameters: a later in-place edit of the caller's tensors must not reach the model
+        merged.update({k: v.detach().clone() for k, v in state_dict.items() if k in want})
         still = [k for k in want if k not in merged]
         if still and strict:
             raise RuntimeError(f"load_state_dict: missing keys {still[:8]}")
