@@ -140,7 +140,8 @@ def _class_script(rng: np.random.Generator, n_steps: int, text_run: Tuple[int, i
 
 def condition_greedy(om: OracleModel, feats: torch.Tensor, initial_tokens: List[int], n_steps: int, r: SamplingRules,
                      seed: int = 0, margin: Tuple[float, float] = (0.3, 3.0), text_run: Tuple[int, int] = (4, 14),
-                     ts_window: int = 12, log=None, passes: int = 3, share: bool = False) -> Dict:
+                     ts_window: int = 12, log=None, passes: int = 3, share: bool = False,
+                     head: Optional[Tuple[int, float, float]] = None) -> Dict:
     """Edits om.sd["decoder.token_embedding.weight"] IN PLACE (see the module docstring) for a greedy decode of `n_steps`
     tokens over `feats` (R, 1500, D).  Pass 1 chooses the tokens and builds the margins; an edit made for a later step can
     still lift its token in ANOTHER row's earlier steps (rows are only decorrelated through their mean hidden states), so
@@ -154,14 +155,18 @@ def condition_greedy(om: OracleModel, feats: torch.Tensor, initial_tokens: List[
     synthetic audio; the tests use feature tensors with a per-clip offset instead), so the rows' hidden states are
     near-copies (cos 0.995) — forcing each row onto a token of its own would mean lifting it over its neighbour's boosted
     token along the sliver of hidden state the two rows do not share: edits of norm >> the embedding's.  With `share` such
-    rows simply decode alike, as they do on the unconditioned weights."""
-    res = _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_run, ts_window, log, None, share)
+    rows simply decode alike, as they do on the unconditioned weights.
+    head = (n, lo, hi): the first n steps draw their margins from [lo, hi] instead of `margin`.  A BEAM search over those steps
+    is then decided by the model as well: with top-1 margins of a few tenths a runner-up hypothesis can end within 0.01 of the
+    winner's sum_logprob (seen: 0.013 over 64 steps), and which of the two wins then differs between two hosts' fp32 oracles;
+    with margins >= 2 the greedy path is the beam winner by >= 2 (bench.py's beam leg and the 64-step beam test)."""
+    res = _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_run, ts_window, log, None, share, head)
     rows = set(res["rows"])
     for p in range(1, passes):
         if log is not None:
             log(f"condition: pass {p + 1} (top-up along the built sequence)")
         res = _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_run, ts_window, log,
-                              (res["tokens"], res["drawn"]), share)
+                              (res["tokens"], res["drawn"]), share, head)
         rows |= set(res["rows"])
         if log is not None:
             nz = [d for d in res["deltas"] if d > 0]
@@ -172,7 +177,7 @@ def condition_greedy(om: OracleModel, feats: torch.Tensor, initial_tokens: List[
     return res
 
 
-def _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_run, ts_window, log, target, share=False) -> Dict:
+def _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_run, ts_window, log, target, share=False, head=None) -> Dict:
     """one walk; target = None (choose tokens, draw margins) or (tokens, drawn margins) of an earlier pass"""
     rng = np.random.default_rng(seed)
     E = om.sd[EMB]
@@ -243,7 +248,7 @@ def _condition_pass(om, feats, initial_tokens, n_steps, r, seed, margin, text_ru
                 if y is None:
                     assert text_ok and bool(torch.isfinite(text_free).any()), (k, i)
                     y = int(text_free.argmax())
-                m = float(rng.uniform(*margin)) if target is None else float(target[1][i * R + k])
+                m = float(rng.uniform(*(margin if head is None or i >= head[0] else head[1:]))) if target is None else float(target[1][i * R + k])
                 drawn.append(m)
                 others = lg.clone()
                 others[y] = ninf

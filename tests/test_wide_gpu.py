@@ -1092,10 +1092,12 @@ def test_large_v3_full_depth_beam5_vs_oracle(large_v3, gpu_device):
 def test_conditioned_checkpoint_beam5_winners_exact_64_steps(large_v3, gpu_device):
     """BASELINE.json configs[3] at the length bench.py times it, WITHOUT a near-tie rule:
     large-v3 (32 + 32 layers), 8 audio x beam 5 = 40 rows, 64 forced steps (EOT suppressed, as bench.py's beam leg), on the
-    margin-conditioned checkpoint (oracle/condition.py, conditioned along the 64-step greedy decode of these clips: peaked
-    next-token distributions, as a trained model has).  The oracle's BeamSearchDecoder + MaximumLikelihoodRanker restatement
-    (whisper/decoding.py:301-404, 190-213, 734-740) gives every audio's ranked winner; its own separation from the runner-up
-    hypothesis is ASSERTED first (>= 0.3 in sum_logprob: the test is not decided by rounding), then
+    margin-conditioned checkpoint (oracle/condition.py, conditioned along the 64-step greedy decode of these clips with
+    margins drawn from [2, 4] logits: the top token holds 0.8 ... 0.98 of the mass, as a trained model's does, so that the
+    hypotheses are separated by the MODEL, not by rounding — with the [0.35, 3] margins of the greedy test a runner-up can
+    still come within 0.1 of the winner, and which one it is then differs between two hosts' fp32 oracles).  The oracle's
+    BeamSearchDecoder + MaximumLikelihoodRanker restatement (whisper/decoding.py:301-404, 190-213, 734-740) gives every
+    audio's ranked winner; its own separation from the runner-up hypothesis is ASSERTED first (>= 1.0 in sum_logprob), then
       * the fp16 engine (device-side beam loop, 48-row projection kernels, group attention, in-place cache permutation):
         the winner's token sequence equals the oracle's for ALL 8 audio, sum_logprob within 0.3;
       * the fp32 strict engine (the one that meets north_star's 1e-3 beam tolerance): the same, sum_logprob within 2e-2."""
@@ -1111,7 +1113,7 @@ def test_conditioned_checkpoint_beam5_winners_exact_64_steps(large_v3, gpu_devic
     T0 = len(init)
     feats = _offset_feats(dims, 8, seed=12)
     sd2, om2 = _conditioned_copy(fd)
-    built = condition.condition_greedy(om2, feats, init, n_steps, rules, seed=5, margin=(0.35, 3.0), text_run=(4, 14), passes=2)
+    built = condition.condition_greedy(om2, feats, init, n_steps, rules, seed=5, margin=(2.0, 4.0), text_run=(4, 14), passes=2)
     with torch.no_grad():
         want = oracle.beam_decode(om2, feats, init, n_steps, rules, G)
     winners, gaps = [], []
@@ -1121,7 +1123,7 @@ def test_conditioned_checkpoint_beam5_winners_exact_64_steps(large_v3, gpu_devic
         scores = sorted((v for _, v in want["candidates"][a]), reverse=True)
         assert len(scores) == G and len(body) == n_steps
         gaps.append(scores[0] - scores[1])
-    assert min(gaps) >= 0.3, gaps                                        # the oracle's own decision is not a near-tie
+    assert min(gaps) >= 1.0, gaps                                        # the oracle's own decision is not a near-tie
     follows_greedy = sum(w[0] == built["tokens"][a, T0:].tolist() for a, w in enumerate(winners))
     model = Whisper(ModelDimensions(**dims_dict(dims)), sd2, device=gpu_device)
     rep = {"model": f"large-v3, seeded weights + margin-conditioned tied embedding ({len(built['rows'])} rows edited)", "audio": 8,

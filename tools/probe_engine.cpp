@@ -84,22 +84,27 @@ template <int N> __device__ __forceinline__ void eng_wait_vmcnt() { asm volatile
 // ten 16-byte write-through-coherent (sc1: L1-bypassing) loads of one lane, issued back to back and waited for inside ONE
 // statement (hipcc does not count asm loads: cdna_hip_programming.md §5.7 form (i))
 struct Gather10 { uint4v v[10]; };
+// OFF2: byte distance of a lane's second 16 bytes (granules 2, 3) from its first (granules 0, 1).  The hand-off buffers are laid
+// out so that one load INSTRUCTION reads whole 128-byte lines: the first halves of 8 (h) / 64 (x') neighbouring lanes are
+// contiguous, the second halves follow 128 bytes / 1 KB further on (with the natural layout, 32 contiguous bytes per lane, every
+// instruction touched every line of its span and used half of it: twice the L2 requests per byte).
+template <int OFF2>
 __device__ __forceinline__ void gather10(Gather10& g, const char* p0, const char* p1, const char* p2, const char* p3, const char* p4) {
   asm volatile(
       "global_load_dwordx4 %0, %10, off sc1\n\t"
-      "global_load_dwordx4 %1, %10, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %1, %10, off offset:%c15 sc1\n\t"
       "global_load_dwordx4 %2, %11, off sc1\n\t"
-      "global_load_dwordx4 %3, %11, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %3, %11, off offset:%c15 sc1\n\t"
       "global_load_dwordx4 %4, %12, off sc1\n\t"
-      "global_load_dwordx4 %5, %12, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %5, %12, off offset:%c15 sc1\n\t"
       "global_load_dwordx4 %6, %13, off sc1\n\t"
-      "global_load_dwordx4 %7, %13, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %7, %13, off offset:%c15 sc1\n\t"
       "global_load_dwordx4 %8, %14, off sc1\n\t"
-      "global_load_dwordx4 %9, %14, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %9, %14, off offset:%c15 sc1\n\t"
       "s_waitcnt vmcnt(0)"
       : "=&v"(g.v[0]), "=&v"(g.v[1]), "=&v"(g.v[2]), "=&v"(g.v[3]), "=&v"(g.v[4]), "=&v"(g.v[5]), "=&v"(g.v[6]), "=&v"(g.v[7]),
         "=&v"(g.v[8]), "=&v"(g.v[9])
-      : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4)
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "i"(OFF2)
       : "memory");
 }
 __device__ __forceinline__ bool tags_ok(const Gather10& g, uint32_t tag) {
@@ -108,14 +113,15 @@ __device__ __forceinline__ bool tags_ok(const Gather10& g, uint32_t tag) {
   for (int i = 0; i < 10; ++i) ok = ok && g.v[i][1] == tag && g.v[i][3] == tag;
   return ok;
 }
-// every lane fetches its own 5 x 32 bytes of granules until all of ITS tags match; lanes that are done issue nothing more
+// every ACTIVE lane fetches its own 5 x 32 bytes of granules until all of ITS tags match; lanes that are done issue nothing more
+template <int OFF2>
 __device__ __forceinline__ void gather_until(Gather10& g, const char* p0, const char* p1, const char* p2, const char* p3, const char* p4,
-                                             uint32_t tag, int lane, int* err) {
-  bool done = false;
+                                             uint32_t tag, int lane, int* err, bool active = true) {
+  bool done = !active;
   int spins = 0;
   for (;;) {
     if (!done) {
-      gather10(g, p0, p1, p2, p3, p4);
+      gather10<OFF2>(g, p0, p1, p2, p3, p4);
       done = tags_ok(g, tag);
     }
     if (__all(done)) break;
@@ -164,7 +170,20 @@ __device__ __forceinline__ void chain5(const half8v* wa, const half8v* xb, float
 }
 
 // 256 workgroups (one per CU) x 16 waves: waves 0-14 consumers, wave 15 the loader (and the 16th FC2 wave).
-template <int DEPTH>      // groups of 8 DMA instructions (8 KB) the loader keeps in flight
+__device__ __forceinline__ void wait_flag(const int* f, int lane, int* err) {
+  int spins = 0;
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+    if (++spins >= (1 << 20)) { if (lane == 0 && err) atomicAdd(err, 1); break; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// DEPTH: groups of 8 DMA instructions (8 KB) the loader keeps in flight.  MODE bit 0: sampled polling (one row of an edge is polled,
+// the rest is gathered once it is complete) instead of every wave sweeping its whole share from the moment it is ready; bit 1: the
+// loader holds FC2's slice back until the x' gather of its workgroup is over.
+// (An intermediate version announced arrivals on 8 sharded device-scope counters instead: the 256 / 768 atomics of an edge took
+// 5 / 12 us to complete — ~16 ns each, serialised — profiles/r05_probe_engine.txt.)
+template <int DEPTH, int MODE>
 __global__ __launch_bounds__(1024) void tail3_kernel(EngArgs a) {
   using namespace eng;
   pin_kernargs(a);
@@ -206,33 +225,47 @@ __global__ __launch_bounds__(1024) void tail3_kernel(EngArgs a) {
       }
       if (on) glds16_nt(src, lds0 + (uint32_t)t * 1024u);
     };
-    // groups of GRP instructions; after issuing group g, wait until group g - DEPTH + 1 has landed and publish it
+    // [T0, T1) in groups of GRP instructions: after issuing a group, wait until all but the DEPTH - 1 youngest groups have
+    // landed and publish the count; a full drain at the end of the range
+    auto stream = [&](auto t0_tag, auto t1_tag) {
+      constexpr int T0 = decltype(t0_tag)::value, T1 = decltype(t1_tag)::value;
+      constexpr int NG = (T1 - T0 + GRP - 1) / GRP, LAST = (T1 - T0) - (NG - 1) * GRP;
 #pragma unroll
-    for (int g = 0; g < NGRP; ++g) {
+      for (int g = 0; g < NG; ++g) {
 #pragma unroll
-      for (int i = 0; i < GRP; ++i) if (g * GRP + i < T_ALL) issue(g * GRP + i);
-      if (g >= DEPTH - 1) {
-        constexpr int last = T_ALL - (NGRP - 1) * GRP;                   // instructions of the last group
-        // instructions still allowed in flight: the DEPTH - 1 youngest groups
-        if (g == NGRP - 1) eng_wait_vmcnt<(DEPTH - 2) * GRP + last>(); else eng_wait_vmcnt<(DEPTH - 1) * GRP>();
-        if (lane == 0) __hip_atomic_store(&ctl[0], (g - DEPTH + 2) * GRP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      if (g == 1) ESTAMP(8);
-    }
-#pragma unroll
-    for (int k = DEPTH - 2; k >= 0; --k) {                               // drain: k groups still in flight
-      constexpr int last = T_ALL - (NGRP - 1) * GRP;
-      if (k == 0) { eng_wait_vmcnt<0>(); if (lane == 0) __hip_atomic_store(&ctl[0], T_ALL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-      else {
-        switch (k) {                                                     // vmcnt immediates: (k - 1) full groups + the last one
-          case 1: eng_wait_vmcnt<last>(); break;
-          case 2: eng_wait_vmcnt<GRP + last>(); break;
-          case 3: eng_wait_vmcnt<2 * GRP + last>(); break;
-          case 4: eng_wait_vmcnt<3 * GRP + last>(); break;
-          default: eng_wait_vmcnt<4 * GRP + last>(); break;
+        for (int i = 0; i < GRP; ++i) if (T0 + g * GRP + i < T1) issue(T0 + g * GRP + i);
+        if (g >= DEPTH - 1 && g < NG - 1) {
+          eng_wait_vmcnt<(DEPTH - 1) * GRP>();
+          if (lane == 0) __hip_atomic_store(&ctl[0], T0 + (g - DEPTH + 2) * GRP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        if (lane == 0) __hip_atomic_store(&ctl[0], (NGRP - k) * GRP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (T0 == 0 && g == 1) ESTAMP(8);
       }
+      // drain: the youngest groups one by one (vmcnt immediates: k - 1 full groups + the last, shorter one)
+#pragma unroll
+      for (int k = (DEPTH - 1 < NG ? DEPTH - 1 : NG) - 1; k >= 0; --k) {
+        switch (k) {
+          case 0: eng_wait_vmcnt<0>(); break;
+          case 1: eng_wait_vmcnt<LAST>(); break;
+          case 2: eng_wait_vmcnt<GRP + LAST>(); break;
+          case 3: eng_wait_vmcnt<2 * GRP + LAST>(); break;
+          case 4: eng_wait_vmcnt<3 * GRP + LAST>(); break;
+          default: eng_wait_vmcnt<4 * GRP + LAST>(); break;
+        }
+        if (lane == 0) __hip_atomic_store(&ctl[0], k == 0 ? T1 : T0 + (NG - k) * GRP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    };
+    if (MODE & 2) {
+      // cout + FC1 first; FC2's slice only once this workgroup's x' gather is over: a gather issued while 48 KB of the CU's own
+      // DMA requests are in flight comes back behind them (the CU's vector-memory pipe returns in issue order)
+      stream(std::integral_constant<int, 0>(), std::integral_constant<int, T_C + T_1>());
+      int spins = 0;
+      while (__hip_atomic_load(&ctl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 8) {
+        if (++spins >= (1 << 20)) { if (lane == 0 && a.err) atomicAdd(a.err, 1); break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      stream(std::integral_constant<int, T_C + T_1>(), std::integral_constant<int, T_ALL>());
+    } else {
+      stream(std::integral_constant<int, 0>(), std::integral_constant<int, T_ALL>());
     }
     ESTAMP(9);
     // the launch's tag, left in LDS by consumer wave 0 long ago (never 0)
@@ -340,7 +373,9 @@ __global__ __launch_bounds__(1024) void tail3_kernel(EngArgs a) {
       xprime = e_res + v;
       if (ej < FWC && er < R) {
         const u64 g = ((u64)tag << 32) | (u64)__float_as_uint(xprime);
-        __hip_atomic_store(a.xg + (size_t)er * D + w * FWC + ej, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int f = w * FWC + ej;                                      // granule slot of feature f: see gather10
+        const int slot = (f >> 8) * 256 + ((f >> 1) & 1) * 128 + ((f & 255) >> 2) * 2 + (f & 1);
+        __hip_atomic_store(a.xg + (size_t)er * D + slot, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       ESTAMP(2);
     }
@@ -349,9 +384,15 @@ __global__ __launch_bounds__(1024) void tail3_kernel(EngArgs a) {
       const int r = wave;
       const char* rowp = (const char*)(a.xg + (size_t)(r < R ? r : R - 1) * D);
       Gather10 g;
-      // lane's elements of wave-load j: k = (64 j + lane) * 4 .. + 3 -> granules k .. k + 3 = 32 bytes
-      gather_until(g, rowp + (size_t)(0 * 64 + lane) * 32, rowp + (size_t)(1 * 64 + lane) * 32, rowp + (size_t)(2 * 64 + lane) * 32,
-                   rowp + (size_t)(3 * 64 + lane) * 32, rowp + (size_t)(4 * 64 + lane) * 32, tag, lane, a.err);
+      // SAMPLED POLLING (MODE bit 0): every producer stores its granules of all 8 rows with ONE instruction, so row 0 complete
+      // means (as good as) everything complete.  Wave 0 polls row 0 — 10 KB per round instead of the 80 KB all eight waves
+      // would sweep — and releases the others, which then gather once; the tags still decide (a straggling granule is re-fetched).
+      if ((MODE & 1) && wave != 0) wait_flag(&ctl[3], lane, a.err);
+      // lane's elements of wave-load j: k = (64 j + lane) * 4 .. + 3: granules 0, 1 at 2 KB j + 16 lane, granules 2, 3 1 KB further
+      gather_until<1024>(g, rowp + (size_t)0 * 2048 + lane * 16, rowp + (size_t)1 * 2048 + lane * 16, rowp + (size_t)2 * 2048 + lane * 16,
+                         rowp + (size_t)3 * 2048 + lane * 16, rowp + (size_t)4 * 2048 + lane * 16, tag, lane, a.err);
+      if ((MODE & 1) && wave == 0 && lane == 0) __hip_atomic_store(&ctl[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) __hip_atomic_fetch_add(&ctl[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // the loader may go on
       if (wave == 0) ESTAMP(3);
       float4v v[NU];
 #pragma unroll
@@ -409,7 +450,9 @@ __global__ __launch_bounds__(1024) void tail3_kernel(EngArgs a) {
       const uint32_t other = __float_as_uint(lane_xor1(__uint_as_float(mine)));
       if ((lane & 1) == 0 && on) {
         const u64 g = ((u64)tag << 32) | (u64)(mine | (other << 16));
-        __hip_atomic_store(a.hg + (size_t)er * (N1 / 2) + ((w * FW1 + wave * 8 + ej) >> 1), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int n = w * FW1 + wave * 8 + ej;                           // even feature; slot of its granule: see gather10
+        const int wi = n & 63, slot = (n >> 6) * 32 + ((wi >> 2) & 1) * 16 + (wi >> 3) * 2 + ((wi >> 1) & 1);
+        __hip_atomic_store(a.hg + (size_t)er * (N1 / 2) + slot, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (wave == 0) ESTAMP(5);
     }
@@ -420,10 +463,16 @@ __global__ __launch_bounds__(1024) void tail3_kernel(EngArgs a) {
     const int rr = idx < R ? idx : R - 1;
     const char* rowp = (const char*)(a.hg + (size_t)rr * (N1 / 2));
     Gather10 g;
-    // lane's B fragment of block blk: k = 64 blk + 32 half + 8 c .. + 7 -> granules k / 2 .. + 3 = 32 bytes
-    const size_t lo = (size_t)(hlf * 16 + cq * 4) * 8;
-    gather_until(g, rowp + (size_t)(wave + 16 * 0) * 256 + lo, rowp + (size_t)(wave + 16 * 1) * 256 + lo, rowp + (size_t)(wave + 16 * 2) * 256 + lo,
-                 rowp + (size_t)(wave + 16 * 3) * 256 + lo, rowp + (size_t)(wave + 16 * 4) * 256 + lo, tag, lane, a.err);
+    // lane's B fragment of block blk: k = 64 blk + 32 half + 8 c .. + 7: granules 0, 1 at 256 blk + 16 (4 half + c), 2, 3 128 bytes on
+    const size_t lo = (size_t)gq * 16;
+    const char *q0 = rowp + (size_t)(wave + 16 * 0) * 256 + lo, *q1 = rowp + (size_t)(wave + 16 * 1) * 256 + lo,
+               *q2 = rowp + (size_t)(wave + 16 * 2) * 256 + lo, *q3 = rowp + (size_t)(wave + 16 * 3) * 256 + lo,
+               *q4 = rowp + (size_t)(wave + 16 * 4) * 256 + lo;
+    // sampled polling: the row-0 lanes (8 of 64) poll until the producers of this wave's five K blocks have published, then
+    // everyone gathers once (a producer stores all 8 rows with one instruction)
+    if (MODE & 1) gather_until<128>(g, q0, q1, q2, q3, q4, tag, lane, a.err, idx == 0);
+    if (wave == 0) ESTAMP(10);
+    gather_until<128>(g, q0, q1, q2, q3, q4, tag, lane, a.err);
     if (wave == 0) ESTAMP(6);
     wait_landed(&ctl[0], NEED_2, lane, a.err);
     half8v wa[NU], xb[NU];
@@ -438,6 +487,7 @@ __global__ __launch_bounds__(1024) void tail3_kernel(EngArgs a) {
     chain5(wa, xb, red2 + wave * 64, lane);
   }
   cbarrier(&ctl[1], 76, lane, a.err);                                    // #5: all 16 waves
+  if (wave == 0) ESTAMP(11);
   if (wave == 0) {
     const int er = lane >> 3, ej = lane & 7;
     float s = e_b2;
@@ -461,14 +511,14 @@ static void fill_float(float* d, size_t n, float scale, float offset = 0.f) {
   CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
 }
 
-template <int DEPTH>
+template <int DEPTH, int MODE>
 static void launch_tail3(const EngArgs& a, hipStream_t st) {
   static bool raised = false;
   if (!raised) {
-    CK(hipFuncSetAttribute((const void*)tail3_kernel<DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, eng::LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)tail3_kernel<DEPTH, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, eng::LDS_BYTES));
     raised = true;
   }
-  hipLaunchKernelGGL(tail3_kernel<DEPTH>, dim3(256), dim3(1024), eng::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((tail3_kernel<DEPTH, MODE>), dim3(256), dim3(1024), eng::LDS_BYTES, st, a);
 }
 
 int main(int argc, char** argv) {
@@ -513,26 +563,31 @@ int main(int argc, char** argv) {
     g.epi = whk::EPI_RESID; g.resid = x; g.resid_ld = D;
     return whk::launch_gemv(g, 1, st) == hipSuccess;
   };
-  auto fused = [&](int depth, int i, float* x, long long* pr) {
+  auto fused = [&](int variant, int i, float* x, long long* pr) {      // variant = 10 * DEPTH + MODE
     EngArgs a; memset(&a, 0, sizeof(a));
     a.part_o = po; a.part_ml = pml; a.Wc = W + wl * (i % L); a.bc = bc; a.W1 = a.Wc + (size_t)D * D; a.b1 = b1;
     a.W2 = a.W1 + (size_t)4 * D * D; a.b2 = b2; a.x = x; a.x_ld = D; a.xg = xg; a.hg = hg; a.d_tick = tick; a.epoch = i;
     a.err = err; a.R = R; a.probe = pr;
-    switch (depth) {
-      case 3: launch_tail3<3>(a, st); break;
-      case 4: launch_tail3<4>(a, st); break;
-      default: launch_tail3<6>(a, st); break;
+    switch (variant) {
+      case 60: launch_tail3<6, 0>(a, st); break;
+      case 61: launch_tail3<6, 1>(a, st); break;
+      case 63: launch_tail3<6, 3>(a, st); break;
+      case 43: launch_tail3<4, 3>(a, st); break;
+      default: launch_tail3<6, 2>(a, st); break;
     }
   };
 
   // ---- numerics: one triple, both forms, from the same residual rows (and a second link, so that stale granules of the
   // first one are in the buffers)
-  for (int depth : {3, 4, 6}) {
+  for (int nlinks = 1; nlinks <= 2; ++nlinks)
+  for (int depth : {60, 61, 63, 43, 62}) {
+    if (nlinks == 1 && depth != 60) continue;
     CK(hipMemcpyAsync(xa, x0, (size_t)8 * D * 4, hipMemcpyDeviceToDevice, st));
     CK(hipMemcpyAsync(xb, x0, (size_t)8 * D * 4, hipMemcpyDeviceToDevice, st));
-    bool ok = three_launch(3, xa) && three_launch(4, xa);
+    bool ok = three_launch(3, xa) && (nlinks == 1 || three_launch(4, xa));
     if (!ok) { printf("three-launch form failed to launch\n"); return 1; }
-    fused(depth, 3, xb, nullptr); fused(depth, 4, xb, nullptr);
+    fused(depth, 3, xb, nullptr); if (nlinks == 2) fused(depth, 4, xb, nullptr);
+    printf("[%d link(s)] ", nlinks);
     hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(64), 0, st, tick, N);
     CK(hipStreamSynchronize(st));
     std::vector<float> ha((size_t)8 * D), hb((size_t)8 * D), h0((size_t)8 * D);
@@ -544,15 +599,28 @@ int main(int argc, char** argv) {
       if (!std::isfinite(hb[i])) { ++nbad; continue; }
       mx = std::max(mx, (double)fabsf(ha[i] - hb[i])); mv = std::max(mv, (double)fabsf(ha[i] - h0[i])); nd += ha[i] != hb[i];
     }
+    if (nd) {
+      printf("    rows that differ:");
+      for (int r = 0; r < R; ++r) {
+        size_t c = 0; double m = 0;
+        for (int n = 0; n < D; ++n) { c += ha[(size_t)r * D + n] != hb[(size_t)r * D + n]; m = std::max(m, (double)fabsf(ha[(size_t)r * D + n] - hb[(size_t)r * D + n])); }
+        if (c) printf(" row %d: %zu values, max %.3g;", r, c, m);
+      }
+      printf("\n");
+    }
     int herr = 0; CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
-    printf("numerics (R = %d, loader depth %d): one launch vs three, two links: max |d| %.3g, %zu of %d values differ, %zu not finite "
+    printf("numerics (R = %d, variant %d = 10 x loader depth + mode): one launch vs three, two links: max |d| %.3g, %zu of %d values differ, %zu not finite "
            "(the two links moved the rows by up to %.3g); spins that ran out %d\n", R, depth, mx, nd, R * D, nbad, mv, herr);
   }
 
   // ---- timing: 32-link chains
   struct Form { const char* name; int depth; };
-  Form forms[] = {{"three launches (product: merge+cout | LN+FC1+GELU | FC2)", 0}, {"one launch, loader keeps 3 x 8 KB in flight", 3},
-                  {"one launch, loader keeps 4 x 8 KB in flight", 4}, {"one launch, loader keeps 6 x 8 KB in flight", 6}};
+  Form forms[] = {{"three launches (product: merge+cout | LN+FC1+GELU | FC2)", 0},
+                  {"one launch, depth 6, sweeps from the start (round-5 v1)", 60},
+                  {"one launch, depth 6, sampled polling", 61},
+                  {"one launch, depth 6, sampled polling + loader holds FC2 back", 63},
+                  {"one launch, depth 4, sampled polling + loader holds FC2 back", 43},
+                  {"one launch, depth 6, loader holds FC2 back", 62}};
   for (const Form& f : forms) {
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipMemcpy(xa, x0, (size_t)8 * D * 4, hipMemcpyDeviceToDevice));
@@ -581,8 +649,9 @@ int main(int argc, char** argv) {
       for (int wg = 0; wg < 256; ++wg) t0 = std::min(t0, p[(size_t)wg * 16]);
       printf(" | spins that ran out %d\n    time line, us after the first workgroup's entry (min / median / max over 256 workgroups):\n", herr);
       const char* names[] = {"entry", "merged fragments complete", "x' published", "x' row gathered (wave 0)", "LayerNorm complete", "h published",
-                             "h gathered (wave 0)", "FC2 + residual stored", "loader: 16 DMA issued", "loader: all landed"};
-      for (int s = 0; s < 10; ++s) {
+                             "h gathered (wave 0)", "FC2 + residual stored", "loader: 16 DMA issued", "loader: all landed",
+                             "h: row-0 sample complete (wave 0)", "FC2 partial sums complete"};
+      for (int s = 0; s < 12; ++s) {
         std::vector<double> d;
         for (int wg = 0; wg < 256; ++wg) d.push_back((p[(size_t)wg * 16 + s] - t0) / 100.0);
         std::sort(d.begin(), d.end());
