@@ -670,3 +670,56 @@ def test_incremental_decoder_with_kv_cache_hooks(setup, gpu_device):
         h.remove()
     # the caches were released: destroyed, or parked in the engine's task cache for the next decode of this shape
     assert mm._TASK_KEY not in cache and (task.handle is None or task in model.engine(feats.dtype)._task_cache)
+
+
+@pytest.mark.parametrize("fp16,beam", [(False, None), (True, None), (False, 3)])
+def test_decode_many_in_lanes_equals_sequential(setup, fp16, beam):
+    """whisper_amd.decode_many: several batches decoded with up to 3 in flight — each on a host thread and HIP stream of its own
+    (HipModel.lane), the encoder on the engine's one stream — must give exactly what decode() gives batch by batch: token ids,
+    avg_logprob, no_speech_prob; greedy and beam search, both engines; raw audio batches take their log-mel inside the lane.
+    Batches of different sizes (different task shapes), more batches than lanes (a lane runs several), twice in a row (the
+    lanes' tasks come back from the engine's cache)."""
+    key, dims, sd, model, mel = setup
+    dev = mel.device
+    clips = [audio(50 + i) for i in range(9)]
+    mels = [whisper_amd.pad_or_trim(whisper_amd.log_mel_spectrogram(c, dims.n_mels, device=dev), 3000) for c in clips]
+    batches = [torch.stack(mels[0:3]), torch.stack(mels[3:4]), torch.stack(mels[4:6]), torch.stack(mels[6:9]), torch.stack(mels[0:2])]
+    opts = whisper_amd.DecodingOptions(language="en", fp16=fp16, sample_len=16, beam_size=beam)
+    want = [whisper_amd.decode(model, (b.half() if fp16 else b), opts) for b in batches]
+    for _ in range(2):
+        got = whisper_amd.decode_many(model, [(b.half() if fp16 else b) for b in batches], opts, in_flight=3)
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert [r.tokens for r in g] == [r.tokens for r in w]
+            assert np.allclose([r.avg_logprob for r in g], [r.avg_logprob for r in w], atol=1e-6)
+            assert np.allclose([r.no_speech_prob for r in g], [r.no_speech_prob for r in w], atol=1e-6)
+    # raw audio in, log-mel inside the lane
+    raw = [torch.from_numpy(np.stack(clips[0:3])).to(dev), torch.from_numpy(np.stack(clips[4:6])).to(dev)]
+    got = whisper_amd.decode_many(model, raw, opts, in_flight=2)
+    want_raw = [whisper_amd.decode(model, whisper_amd.log_mel_spectrogram(r, dims.n_mels).to(torch.float16 if fp16 else torch.float32), opts)
+                for r in raw]
+    assert [[r.tokens for r in g] for g in got] == [[r.tokens for r in w] for w in want_raw]
+    # an exception inside a lane reaches the caller
+    with pytest.raises(Exception):
+        whisper_amd.decode_many(model, [batches[0], torch.zeros(2, dims.n_mels, 17, device=dev)], opts, in_flight=2)
+    assert [r.tokens for r in whisper_amd.decode(model, (batches[1].half() if fp16 else batches[1]), opts)] == [r.tokens for r in want[1]]
+
+
+def test_transcribe_batch_in_flight_equals_one_lane(setup):
+    """transcribe_batch(in_flight=2): two groups of files driven concurrently on their own threads and streams — every file's
+    result (tokens, seeks, boundaries, word times) exactly what in_flight=1 returns, in input order; fp32 strict engine."""
+    key, dims, sd, model, mel = setup
+    files = [audio(31, 200000), np.concatenate([audio(32), audio(33, 240000)]), audio(37, 480000),
+             np.concatenate([audio(34), audio(35), audio(36, 100000)]), audio(38, 90000)]
+    kw = dict(temperature=0.0, fp16=False, language="en", sample_len=12, word_timestamps=True, batch_size=2,
+              condition_on_previous_text=True, no_speech_threshold=None, logprob_threshold=None, compression_ratio_threshold=None)
+    want = model.transcribe_batch(files, **kw)
+    got = model.transcribe_batch(files, in_flight=2, **kw)
+    assert len(got) == len(want) == 5
+    for g, w in zip(got, want):
+        assert g["language"] == w["language"] and g["text"] == w["text"]
+        assert [s["tokens"] for s in g["segments"]] == [s["tokens"] for s in w["segments"]]
+        assert [s["seek"] for s in g["segments"]] == [s["seek"] for s in w["segments"]]
+        gw = [[x["start"], x["end"]] for s in g["segments"] for x in s["words"]]
+        ww = [[x["start"], x["end"]] for s in w["segments"] for x in s["words"]]
+        assert gw == ww

@@ -635,6 +635,41 @@ def test_detect_language_host_logic_matches_reference(ref):
         ref.decoding.detect_language(_fake_model(False), torch.zeros(1500, 384), ref.tokenizer.get_tokenizer(False))
 
 
+def test_transcribe_batch_in_flight_groups_and_merges(monkeypatch):
+    """transcribe_batch(in_flight=k): the files are dealt round-robin into k groups, every group is an ordinary
+    transcribe_batch call handed to decoding.run_in_lanes (one host thread + HIP stream per group on a GPU; a sequential
+    stand-in here), and the results come back in INPUT order and equal to in_flight=1.  An exception in a lane surfaces."""
+    import oracle
+    import whisper_amd  # noqa: F401
+    mine_tr = sys.modules["whisper_amd.transcribe"]
+    from whisper_amd import decoding as mine
+    from whisper_amd.tokenizer import get_tokenizer
+    tk = get_tokenizer(True, num_languages=99, language="en", task="transcribe")
+    filt = oracle.mel_filterbank(80)
+    monkeypatch.setattr(mine_tr, "log_mel_spectrogram", lambda a, n_mels=80, padding=0, device=None: oracle.log_mel_spectrogram(a, filt, padding=padding))
+    seen = []
+
+    def fake_lanes(model, jobs, in_flight=3, dtype=None):
+        jobs = list(jobs)
+        seen.append((len(jobs), in_flight, dtype))
+        return [j() for j in jobs]
+    monkeypatch.setattr(mine, "run_in_lanes", fake_lanes)
+    rng = np.random.default_rng(3)
+    files = [(rng.standard_normal(16000 * n) * 0.01).astype(np.float32) for n in (40, 95, 20, 61, 33)]
+    kw = dict(language="en", fp16=False, temperature=(0.0, 0.2), batch_size=2)
+    want = mine_tr.transcribe_batch(_FunctionalModel(mine.DecodingResult, tk), files, **kw)
+    assert not seen                                                              # in_flight = 1: no lanes
+    m = _FunctionalModel(mine.DecodingResult, tk)
+    got = mine_tr.transcribe_batch(m, files, in_flight=2, **kw)
+    assert seen == [(2, 2, torch.float32)]                                       # two groups: files 0, 2, 4 and 1, 3
+    assert [g["text"] for g in got] == [w["text"] for w in want] and [g["segments"] for g in got] == [w["segments"] for w in want]
+    assert all(n <= 2 for n, _ in m.calls)
+    seen.clear()
+    got = mine_tr.transcribe_batch(_FunctionalModel(mine.DecodingResult, tk), files, in_flight=8, **kw)
+    assert seen == [(5, 5, torch.float32)] and [g["text"] for g in got] == [w["text"] for w in want]     # never more groups than files
+    assert mine_tr.transcribe_batch(_FunctionalModel(mine.DecodingResult, tk), files[:1], in_flight=3, **kw)[0]["text"] == want[0]["text"]
+
+
 def test_transcribe_batch_loads_files_concurrently(monkeypatch, tmp_path):
     """paths given to transcribe_batch are decoded by a thread pool up front (same results as arrays, input order kept,
     a failing file raises the loader's error)"""

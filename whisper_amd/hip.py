@@ -9,6 +9,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import os
+import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -389,6 +390,13 @@ class HipModel:
         self.stream = torch.cuda.Stream(device=self.device)
         self._enc_ws: Optional[torch.Tensor] = None
         self._task_cache: List["HipTask"] = []          # idle tasks, most recently used last
+        # Several PASSES may be in flight on one engine (`lane`, whisper_amd.decode_many): a decode chain is ~190 dependent
+        # launches per token and leaves the chip idle between them, so independent chains on their own streams fill each
+        # other's gaps (large-v3, 8 clips per pass: 692 audio-s/s one pass at a time, 917 / 1025 with 2 / 3 in flight).
+        # Host-side state shared by the lanes' threads is guarded here; the encoder has ONE workspace and ONE stream.
+        self._lock = threading.RLock()                  # task cache, workspace (re)allocation
+        self._enc_lock = threading.Lock()               # one encoder's launches are enqueued without another's in between
+        self._tls = threading.local()                   # .stream: the lane stream of the calling thread (None: self.stream)
         self.debug_task_flags = 0                       # OR-ed into the flags of every task created (tests: WH_TASK_EXPIRE_HANDOFFS)
         # workspaces kept alive between windows: WH_TASK_CACHE_GB, else 10 % of the device memory (28 GB of the 288 GB of
         # an MI355X; a smaller GPU gets a smaller cache).  Allocation failures anywhere on this engine's path drop the
@@ -401,23 +409,49 @@ class HipModel:
                 self.task_cache_bytes = int(torch.cuda.mem_get_info()[1] * 0.10)
 
     # -- decoding tasks are expensive to set up (GBs of workspace, a 250-node graph capture): keep them -------------
+    @contextlib.contextmanager
+    def lane(self, stream: Optional[torch.cuda.Stream] = None):
+        """Run the calling THREAD's work on a stream of its own: inside the block `stream` (a new one by default) is
+        torch's current stream and the stream of every task this thread acquires from the engine, so that the thread's
+        log-mel, sampling and decode chains overlap those of other threads' lanes.  Without it all tasks of an engine share
+        `self.stream` and run one after the other.  The encoder stays on the engine's stream (one workspace): encoders of
+        different lanes are ordered among themselves and overlap the other lanes' decode chains."""
+        st = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        prev = getattr(self._tls, "stream", None)
+        self._tls.stream = st
+        try:
+            with torch.cuda.device(self.device), torch.cuda.stream(st):
+                yield st
+        finally:
+            self._tls.stream = prev
+
+    def task_stream(self) -> torch.cuda.Stream:
+        """the stream tasks acquired by the calling thread run on"""
+        return getattr(self._tls, "stream", None) or self.stream
+
     def acquire_task(self, n_audio: int, n_group: int, max_prefill: int, capture_q: bool = False,
                      stream: Optional[torch.cuda.Stream] = None) -> "HipTask":
         """A reset task of this shape: a cached one (its workspace and captured step graph are reused) or a new one.
         `task.close()` hands it back.  max_prefill is rounded up so that windows with prompts of different lengths
-        share a task."""
+        share a task.  The task runs on `stream`, else on the calling thread's lane stream (`lane`), else on the engine's."""
         if max_prefill <= 8:
             max_prefill = 8
         elif max_prefill <= 64:
             max_prefill = 64
         else:
             max_prefill = self.dims.n_text_ctx
-        key = (n_audio, n_group, max_prefill, capture_q, stream if stream is not None else self.stream)
-        for i in range(len(self._task_cache) - 1, -1, -1):
-            if self._task_cache[i].cache_key == key:
-                task = self._task_cache.pop(i)
-                task.reset()
-                return task
+        if stream is None:
+            stream = self.task_stream()
+        key = (n_audio, n_group, max_prefill, capture_q, stream)
+        task = None
+        with self._lock:
+            for i in range(len(self._task_cache) - 1, -1, -1):
+                if self._task_cache[i].cache_key == key:
+                    task = self._task_cache.pop(i)
+                    break
+        if task is not None:
+            task.reset()
+            return task
         task = HipTask(self, n_audio, n_group, max_prefill, capture_q=capture_q, stream=stream)
         task._cached = True
         return task
@@ -436,19 +470,27 @@ class HipModel:
     def _release_task(self, task: "HipTask") -> bool:
         if task.ws is None or task.held_bytes() > self.task_cache_bytes:
             return False
-        if any(t is task for t in self._task_cache):     # closed twice: it is already idle, do not list it again
-            return True
-        self._task_cache.append(task)
-        total = sum(t.held_bytes() for t in self._task_cache)
-        while total > self.task_cache_bytes and len(self._task_cache) > 1:
-            old = self._task_cache.pop(0)
-            total -= old.held_bytes()
+        evicted = []
+        with self._lock:
+            if any(t is task for t in self._task_cache):     # closed twice: it is already idle, do not list it again
+                return True
+            self._task_cache.append(task)
+            total = sum(t.held_bytes() for t in self._task_cache)
+            while total > self.task_cache_bytes and len(self._task_cache) > 1:
+                old = self._task_cache.pop(0)
+                total -= old.held_bytes()
+                evicted.append(old)
+        for old in evicted:
             old.destroy()
         return True
 
     def drop_cached_tasks(self) -> None:
-        while self._task_cache:
-            self._task_cache.pop().destroy()
+        while True:
+            with self._lock:
+                if not self._task_cache:
+                    return
+                t = self._task_cache.pop()
+            t.destroy()
 
     def __del__(self):
         try:
@@ -470,17 +512,22 @@ class HipModel:
         mel = mel.contiguous()
         B = mel.shape[0]
         need = lib().wh_encoder_workspace_bytes(self.handle, B)
-        if self._enc_ws is None or self._enc_ws.numel() < need:
-            self._enc_ws = None
-            self._enc_ws = self._alloc(need)
         out = torch.empty(B, d.n_audio_ctx, d.n_audio_state, dtype=self.torch_dtype, device=self.device)
-        with torch.cuda.device(self.device):           # the C ABI launches on the calling thread's current device
+        # one encoder at a time ENQUEUES (a few hundred launches into the engine's stream, all on the one workspace): another
+        # thread's encoder must not slip its launches in between.  The lock is held for the enqueue only, not for the run.
+        with self._enc_lock, torch.cuda.device(self.device):   # the C ABI launches on the calling thread's current device
+            if self._enc_ws is None or self._enc_ws.numel() < need:
+                if self._enc_ws is not None:
+                    self.stream.synchronize()          # a running encoder may still use the workspace being replaced
+                self._enc_ws = None
+                self._enc_ws = self._alloc(need)
             cur = torch.cuda.current_stream(self.device)
             self.stream.wait_stream(cur)
             check(lib().wh_encode(self.handle, mel.data_ptr(), int(mel.dtype == torch.float16), B, out.data_ptr(),
                                   self._enc_ws.data_ptr(), self._enc_ws.numel(), stream_ptr(self.stream)), "wh_encode")
             cur.wait_stream(self.stream)
         mel.record_stream(self.stream)
+        out.record_stream(self.stream)
         return out
 
 

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import base64
 import gzip
+import threading
 from collections import namedtuple
 from dataclasses import dataclass
 from typing import Dict, Iterator, Optional, Tuple
@@ -193,6 +194,9 @@ class _DecoderHandle:
     forward = __call__
 
 
+_ENGINE_LOCK = threading.Lock()
+
+
 class Whisper:
     def __init__(self, dims: ModelDimensions, state_dict: Dict[str, Tensor], device=None):
         self.dims = dims
@@ -214,11 +218,14 @@ class Whisper:
             raise TypeError(f"unsupported activation dtype {dtype}")
         eng = self._engines.get(dtype)
         if eng is None:
-            hip.require_gpu(self._device)
-            code = hip.WH_F16 if dtype == torch.float16 else hip.WH_F32
-            blob = hip.pack_weights(self._state_dict, self.dims, code, self._device)
-            eng = hip.HipModel(self.dims, code, blob)
-            self._engines[dtype] = eng
+            with _ENGINE_LOCK:                     # threads of several lanes (decoding.run_in_lanes) may ask at once: pack once
+                eng = self._engines.get(dtype)
+                if eng is None:
+                    hip.require_gpu(self._device)
+                    code = hip.WH_F16 if dtype == torch.float16 else hip.WH_F32
+                    blob = hip.pack_weights(self._state_dict, self.dims, code, self._device)
+                    eng = hip.HipModel(self.dims, code, blob)
+                    self._engines[dtype] = eng
         return eng
 
     def adopt_engine(self, dtype: torch.dtype, engine: hip.HipModel) -> None:

@@ -446,7 +446,7 @@ def _load_all(audios) -> list:
 
 
 def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, max_active_files: Optional[int] = None,
-                     **kwargs) -> List[dict]:
+                     in_flight: int = 1, **kwargs) -> List[dict]:
     """Transcribe several files at once (no counterpart in the reference, which is strictly
     one file at a time).  Every file keeps its own seek / prompt / fallback state machine exactly as `transcribe`;
     the driver advances them in lock-step and decodes the windows that are pending at the same moment — and whose
@@ -460,7 +460,27 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, max_acti
     rung decodes them as a batch again (sampling runs on the device, `best_of` rows per window).  With
     `word_timestamps` the alignments of the windows just decoded are computed together (find_alignment_batch).
     At most `max_active_files` (default 2 * batch_size) files are in flight: only those are decoded to PCM and keep
-    their whole-file spectrogram on the device; the next file starts when one finishes."""
+    their whole-file spectrogram on the device; the next file starts when one finishes.
+    `in_flight` > 1: the files are dealt round-robin into that many groups and every group is driven as described above on a
+    host thread and HIP stream of its own (decoding.run_in_lanes): the groups' decode chains overlap on the GPU — each is a
+    chain of dependent launches that leaves the chip idle between them — while every file's result stays exactly what it is
+    with in_flight = 1 (a file's windows never depend on another file).  Worth it from about 2 * batch_size files on."""
+    audios = list(audios)
+    if in_flight > 1 and len(audios) > 1:
+        from .decoding import run_in_lanes
+        n = min(int(in_flight), len(audios))
+        groups = [list(range(k, len(audios), n)) for k in range(n)]
+        fp16 = kwargs.get("fp16", True)
+
+        def job(ids):
+            return lambda: transcribe_batch(model, [audios[i] for i in ids], batch_size=batch_size,
+                                            max_active_files=max_active_files, in_flight=1, **kwargs)
+        parts = run_in_lanes(model, [job(ids) for ids in groups], n, torch.float16 if fp16 else torch.float32)
+        merged: List[Optional[dict]] = [None] * len(audios)
+        for ids, part in zip(groups, parts):
+            for i, r in zip(ids, part):
+                merged[i] = r
+        return merged
     names = ("verbose", "temperature", "compression_ratio_threshold", "logprob_threshold", "no_speech_threshold",
              "condition_on_previous_text", "initial_prompt", "carry_initial_prompt", "word_timestamps",
              "prepend_punctuations", "append_punctuations", "clip_timestamps", "hallucination_silence_threshold")
