@@ -92,6 +92,7 @@ def parse():
     p.add_argument("--checkpoint", default=None, help="reference-format checkpoint to run instead of seeded weights "
                                                       "(default: ~/.cache/whisper/<model file> when it exists)")
     p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = all usable cores)")
+    p.add_argument("--lane-priority", type=int, default=0, help="HIP stream priority of the lanes' streams (-1 = high; the encoder's stream stays at 0)")
     p.add_argument("--in-flight", type=int, default=3, help="passes (batches of --batch clips) in flight at once on this GPU: each on "
                                                             "its own task, HIP stream and host thread (1 = one pass after the other)")
     return p.parse_args()
@@ -232,9 +233,15 @@ def main():
     # ended).  The encoder always runs on the engine's stream with the engine's one workspace: encoders of different lanes are
     # ordered among themselves and overlap the other lanes' decode chains.
     F = max(1, args.in_flight)
+    if world > 1:
+        # every lane has a host thread that waits for its decode loop (hipStreamSynchronize spins): keep one usable core per
+        # lane and rank, or the ranks' threads take turns on the cores and the scaling curve measures the host
+        from whisper_amd.utils import usable_cores
+        F = max(1, min(F, usable_cores() // world))
+        log(f"rank {rank}: {F} passes in flight ({usable_cores()} usable host cores for {world} ranks)")
     lanes = []
     for i in range(F):
-        st = torch.cuda.Stream(device=device) if F > 1 else torch.cuda.current_stream(device)
+        st = torch.cuda.Stream(device=device, priority=args.lane_priority) if F > 1 else torch.cuda.current_stream(device)
         lanes.append((st, hip.HipTask(model, B, 1, max(T0, 8), stream=st if F > 1 else None),
                       torch.zeros(B, T0 + N + 1, dtype=torch.int64, device=device)))
     task, tokens = lanes[0][1], lanes[0][2]
@@ -373,7 +380,7 @@ def main():
         # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/, per round),
         # and only when it was taken on this very workload; otherwise null.
         traffic, tsrc = None, None
-        for rnd in ("r04", "r03", "r02", "r01"):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             tf = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
             if os.path.isfile(tf) and args.model == "large-v3" and B == 8:
                 with open(tf) as f:
@@ -392,7 +399,13 @@ def main():
                            "bytes_per_launch": dom["bytes"], "avg_us": dom["avg_us"],
                            # the whole decode step (all ~257 dependent launches of one token) against the same peak
                            "step_frac": round(step["GBps"] / HBM_PEAK_GBS, 4), "step_avg_us": step["avg_us"],
-                           "step_bytes": step["bytes"], "all_kernels": kern}
+                           "step_bytes": step["bytes"], "all_kernels": kern,
+                           "measured_as": "every kernel and the step alone on the chip (one chain, HIP events on its launch stream, layer-rotated); "
+                                          "profiles/r05_kernel_stats.csv is the kernel trace of `bench.py --in-flight 1`",
+                           # the timed region itself: all lanes' decode steps against the HBM peak (the encoder's share of the pass is MFMA work)
+                           "pass_level": {"passes_in_flight": F, "decode_bytes_per_pass": step["bytes"] * N,
+                                          "GBps": round(step["bytes"] * N / (ms_per_step * 1e-3) / 1e9, 1),
+                                          "frac": round(step["bytes"] * N / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
     tf_err = None
     if rank == 0 and prep is not None:
         try:
@@ -462,6 +475,15 @@ def main():
                 extras["greedy_sample_len_64"] = {"clips": B, "steps": 64, "ms_per_pass": round(ms64, 2),
                                                   "audio_s_per_s": round(B * 30.0 / (ms64 / 1e3), 1),
                                                   "path": "whisper_amd.decode (public API), log-mel + encoder + 64 forced steps"}
+                if F > 1:
+                    whisper_amd.decode_many(wmodel, [audio] * F, o64, in_flight=F)
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    whisper_amd.decode_many(wmodel, [audio] * (3 * F), o64, in_flight=F)
+                    torch.cuda.synchronize(device)
+                    l64 = (time.perf_counter() - t0) / (3 * F) * 1e3
+                    extras["greedy_sample_len_64"]["in_flight"] = {"passes_in_flight": F, "ms_per_pass": round(l64, 2),
+                                                                   "audio_s_per_s": round(B * 30.0 / (l64 / 1e3), 1), "passes": 3 * F}
                 log(f"greedy, 64 steps: {ms64:.1f} ms per pass = {B * 30.0 / (ms64 / 1e3):.0f} audio-s/s")
             # BASELINE configs[3] shape: beam search (beam 5) on this GPU's clips, device-side beam loop
             if args.beam >= 2:
@@ -478,6 +500,18 @@ def main():
                 bms = (time.perf_counter() - t0) / 2 * 1e3
                 extras["beam_search"] = {"beam_size": args.beam, "clips": B, "rows": B * args.beam, "steps": args.beam_steps,
                                          "ms_per_pass": round(bms, 2), "audio_s_per_s": round(30.0 * B / (bms * 1e-3), 1)}
+                if F > 1:
+                    mel_b = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
+                    whisper_amd.decode_many(wmodel, [mel_b] * F, bopts, in_flight=F)
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    many = whisper_amd.decode_many(wmodel, [audio] * (2 * F), bopts, in_flight=F)
+                    torch.cuda.synchronize(device)
+                    lms = (time.perf_counter() - t0) / (2 * F) * 1e3
+                    extras["beam_search"]["in_flight"] = {
+                        "passes_in_flight": F, "ms_per_pass": round(lms, 2), "audio_s_per_s": round(30.0 * B / (lms * 1e-3), 1),
+                        "passes": 2 * F, "winners_equal_to_one_at_a_time": all([r.tokens for r in rs] == [r.tokens for r in bres] for rs in many)}
+                    log(f"beam {args.beam}, {F} passes in flight: {lms:.1f} ms per pass")
                 bp = beam_parity(bres, prep, "fp16")
                 if bp is not None:
                     extras["beam_search"]["parity"] = bp
@@ -522,7 +556,7 @@ def main():
             if args.other_configs and args.model == "large-v3":
                 task_bytes = model.task_cache_bytes
                 model.drop_cached_tasks()
-                extras["other_configs"] = other_configs(device, N)
+                extras["other_configs"] = other_configs(device, N, F)
                 model.task_cache_bytes = task_bytes
         except Exception as e:      # the optional legs never cost the headline line: report and go on
             import traceback
@@ -846,7 +880,7 @@ def event_ms(fn, device, reps: int = 5) -> float:
     return sorted(ts)[len(ts) // 2]
 
 
-def other_configs(device, N):
+def other_configs(device, N, in_flight=3):
     """BASELINE.json configs[1] / configs[4] shapes on this GPU (never the headline): audio-s/s through
     log_mel_spectrogram + decode() [+ find_alignment_batch], fixed N steps per clip, synthetic weights of those dims."""
     import whisper_amd
@@ -889,6 +923,19 @@ def other_configs(device, N):
         res[key] = {"ms_per_pass": round(ms, 2), "audio_s_per_s": round(30.0 * batch / (ms * 1e-3), 1), "steps": N,
                     "passes_ms": [round(x, 1) for x in times]}
         log(f"other config {key}: {ms:.1f} ms per pass = {30.0 * batch / (ms * 1e-3):.0f} audio-s/s")
+        if in_flight > 1:
+            # the same passes, `in_flight` at once (run_in_lanes: a host thread + HIP stream per pass)
+            from whisper_amd.decoding import run_in_lanes
+            reps = 2 * in_flight
+            run_in_lanes(m, [one] * in_flight, in_flight, torch.float16)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            run_in_lanes(m, [one] * reps, in_flight, torch.float16)
+            torch.cuda.synchronize(device)
+            lms = (time.perf_counter() - t0) / reps * 1e3
+            res[key]["in_flight"] = {"passes_in_flight": in_flight, "ms_per_pass": round(lms, 2),
+                                     "audio_s_per_s": round(30.0 * batch / (lms * 1e-3), 1), "passes": reps}
+            log(f"other config {key}, {in_flight} passes in flight: {lms:.1f} ms per pass = {30.0 * batch / (lms * 1e-3):.0f} audio-s/s")
         # where this leg stands against the hardware: log-mel, encoder (MFMA peak), one decode step (HBM peak)
         mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
         mel_ms = event_ms(lambda: whisper_amd.log_mel_spectrogram(audio, dims.n_mels), device)

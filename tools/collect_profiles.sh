@@ -9,6 +9,7 @@ P=profiles/r${R}
 cat $F/bench.err $F/bench.out > ${P}_bench.log
 cp $F/kernel_stats.csv ${P}_kernel_stats.csv
 cp $F/kernel_stats_extras.csv ${P}_kernel_stats_extras.csv
+[ -f $F/kernel_stats_lanes.csv ] && cp $F/kernel_stats_lanes.csv ${P}_kernel_stats_lanes.csv
 cp $F/pmc_fetch_size.csv ${P}_pmc_fetch_size.csv
 cp $F/pmc_write_size.csv ${P}_pmc_write_size.csv
 cp $F/pmc_traffic.json ${P}_pmc_traffic.json
@@ -21,7 +22,7 @@ python - "$R" <<'PY'
 import json, os, sys
 out = {"source": "tests/test_wide_gpu.py (pytest -m gpu) via tests/conftest.py::write_report, MI355X"}
 for name in ("fp16_large_v3_greedy", "fp16_large_v3_beam5", "turbo_dims", "conditioned_large_v3", "conditioned_turbo",
-             "alignment_conditioned_turbo", "alignment_conditioned_large_v3"):
+             "conditioned_large_v3_beam5", "alignment_conditioned_turbo", "alignment_conditioned_large_v3"):
     p = os.path.join("gpurun_out", "parity", name + ".json")
     if os.path.exists(p):
         out[name] = json.load(open(p))
