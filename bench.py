@@ -416,8 +416,10 @@ def main():
             traceback.print_exc(file=sys.stderr)
             tf_err = {"error": f"{type(e).__name__}: {e}"[:200]}
     if rank == 0:
-        out["handoff_timeouts"] = task.handoff_timeouts()      # fused step kernels: bounded spins that ran out (must be 0)
-        out["handoff_fallbacks"] = task.handoff_fallbacks      # loops re-run on the two-launch kernels because of them (must be 0)
+        # fused step kernels: bounded spins that ran out / loops re-run on the two-launch kernels because of them, over ALL lanes
+        # (must be 0: with several chains on the chip a producer workgroup may be dispatched late, the bounds have to hold there too)
+        out["handoff_timeouts"] = sum(ln[1].handoff_timeouts() for ln in lanes)
+        out["handoff_fallbacks"] = sum(ln[1].handoff_fallbacks for ln in lanes)
     for ln in lanes:
         ln[1].close()
 

@@ -1148,3 +1148,64 @@ def test_conditioned_checkpoint_beam5_winners_exact_64_steps(large_v3, gpu_devic
             eng.drop_cached_tasks()
         model._engines.clear()
         torch.cuda.empty_cache()
+
+
+def test_large_v3_three_lanes_equal_one_chain_no_timeouts(large_v3, gpu_device):
+    """Lanes at full depth (round 5): three tasks of 8 rows decode AT ONCE on the fp16 engine — each on its own host thread and
+    HIP stream (`HipModel.lane`), as bench.py's headline and `decode_many` run — and every lane's 8 x 96 token ids equal the
+    ids the same task produces alone.  The fused step kernels hand q / k / v over through bounded spins that assume their
+    producer workgroups get dispatched in time; with two other chains' kernels on the same CUs that assumption is exercised
+    for real: the spins that ran out and the loops that fell back to the two-launch kernels are asserted to be 0."""
+    import threading
+    fd = large_v3
+    dims = fd.dims
+    eng = fd.engine(hip.WH_F16)
+    n_steps = 96
+    tok, init, params, rules, mask = _greedy_setup(dims, n_steps, gpu_device, suppress_eot=True)
+    T0 = len(init)
+    feats = [_offset_feats(dims, 8, seed=40 + i).to(gpu_device).half() for i in range(3)]
+    init_t = torch.tensor(init, device=gpu_device)
+    sot_index = tok.sot_sequence.index(tok.sot)
+
+    def decode(task, f, out):
+        task.reset(); task.set_audio(f); out.zero_(); out[:, :T0] = init_t
+        n, _, _ = task.greedy(out, params, sot_index, tok.no_speech)
+        assert n == T0 + n_steps
+
+    alone = []
+    for f in feats:                                               # one chain at a time
+        t = hip.HipTask(eng, 8, 1, max(T0, 8))
+        o = torch.zeros(8, T0 + n_steps + 1, dtype=torch.int64, device=gpu_device)
+        decode(t, f, o)
+        torch.cuda.synchronize()
+        alone.append(o[:, : T0 + n_steps].clone())
+        assert t.handoff_timeouts() == 0
+        t.close()
+    got, stats, errors = [None] * 3, [None] * 3, []
+
+    def worker(i):
+        try:
+            with eng.lane() as st:
+                t = eng.acquire_task(8, 1, max(T0, 8))
+                assert t.stream is st
+                o = torch.zeros(8, T0 + n_steps + 1, dtype=torch.int64, device=gpu_device)
+                for _ in range(3):                                # three passes per lane: the chains drift against each other
+                    decode(t, feats[i], o)
+                st.synchronize()
+                got[i] = o[:, : T0 + n_steps].clone()
+                stats[i] = (t.handoff_timeouts(), t.handoff_fallbacks)
+                t.close()
+        except BaseException as e:      # noqa: BLE001
+            errors.append(e)
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    print("three lanes: (time-outs, fallbacks) per lane:", stats)
+    for i in range(3):
+        assert torch.equal(got[i].cpu(), alone[i].cpu()), i
+        assert stats[i] == (0, 0), stats
+    eng.drop_cached_tasks()

@@ -9,7 +9,6 @@ P=profiles/r${R}
 cat $F/bench.err $F/bench.out > ${P}_bench.log
 cp $F/kernel_stats.csv ${P}_kernel_stats.csv
 cp $F/kernel_stats_extras.csv ${P}_kernel_stats_extras.csv
-[ -f $F/kernel_stats_lanes.csv ] && cp $F/kernel_stats_lanes.csv ${P}_kernel_stats_lanes.csv
 cp $F/pmc_fetch_size.csv ${P}_pmc_fetch_size.csv
 cp $F/pmc_write_size.csv ${P}_pmc_write_size.csv
 cp $F/pmc_traffic.json ${P}_pmc_traffic.json
