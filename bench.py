@@ -92,6 +92,9 @@ def parse():
     p.add_argument("--checkpoint", default=None, help="reference-format checkpoint to run instead of seeded weights "
                                                       "(default: ~/.cache/whisper/<model file> when it exists)")
     p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = all usable cores)")
+    p.add_argument("--task-form", type=int, default=-1, help="developer A/B: 0 = the fused step launches of csrc/xattn.hip, 1 = self attention "
+                                                            "as two launches, 2 = cross attention as two launches, 3 = both; default -1: 0 for one "
+                                                            "pass at a time, 1 in lanes (what HipModel.acquire_task gives a lane's task)")
     p.add_argument("--lane-priority", type=int, default=0, help="HIP stream priority of the lanes' streams (-1 = high; the encoder's stream stays at 0)")
     p.add_argument("--in-flight", type=int, default=3, help="passes (batches of --batch clips) in flight at once on this GPU: each on "
                                                             "its own task, HIP stream and host thread (1 = one pass after the other)")
@@ -239,10 +242,13 @@ def main():
         from whisper_amd.utils import usable_cores
         F = max(1, min(F, usable_cores() // world))
         log(f"rank {rank}: {F} passes in flight ({usable_cores()} usable host cores for {world} ranks)")
+    if args.task_form < 0:
+        args.task_form = 1 if F > 1 else 0
     lanes = []
     for i in range(F):
         st = torch.cuda.Stream(device=device, priority=args.lane_priority) if F > 1 else torch.cuda.current_stream(device)
-        lanes.append((st, hip.HipTask(model, B, 1, max(T0, 8), stream=st if F > 1 else None),
+        lanes.append((st, hip.HipTask(model, B, 1, max(T0, 8), stream=st if F > 1 else None,
+                                      two_launch_self=bool(args.task_form & 1), two_launch_cross=bool(args.task_form & 2)),
                       torch.zeros(B, T0 + N + 1, dtype=torch.int64, device=device)))
     task, tokens = lanes[0][1], lanes[0][2]
     torch.cuda.synchronize(device)

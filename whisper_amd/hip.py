@@ -442,6 +442,11 @@ class HipModel:
             max_prefill = self.dims.n_text_ctx
         if stream is None:
             stream = self.task_stream()
+        # a task of a LANE (several chains share the chip) keeps its self attention as two launches: the fused launch
+        # (csrc/xattn.hip, 1024-thread workgroups whose consumers spin for their q / k / v) is the better form for a chain that
+        # has the chip to itself (r03) and the worse one beside other chains — 3 lanes: 1042 vs 1008 audio-s/s, same tokens
+        # (bit-identical forms), `bench.py --task-form`, profiles/r05_lanes.txt.  The cross attention stays fused in both.
+        in_lane = getattr(self._tls, "stream", None) is not None and stream is self._tls.stream
         key = (n_audio, n_group, max_prefill, capture_q, stream)
         task = None
         with self._lock:
@@ -452,7 +457,7 @@ class HipModel:
         if task is not None:
             task.reset()
             return task
-        task = HipTask(self, n_audio, n_group, max_prefill, capture_q=capture_q, stream=stream)
+        task = HipTask(self, n_audio, n_group, max_prefill, capture_q=capture_q, stream=stream, two_launch_self=in_lane)
         task._cached = True
         return task
 
