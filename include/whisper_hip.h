@@ -117,6 +117,11 @@ typedef struct wh_model_weights {
 typedef struct wh_model wh_model;   /* opaque: dims + copies of the pointer tables */
 typedef struct wh_task wh_task;     /* opaque: per-DecodingTask KV caches + workspace carve-up.  One call at a time per
                                      * handle: a second thread entering while a call runs gets WH_ERR_STATE (enforced) */
+/* Concurrency.  A wh_model is immutable and may be used by any number of threads and tasks at once.  Tasks on DIFFERENT
+ * streams, each driven by its own host thread (wh_task_greedy / wh_task_beam return when their loop has ended), run
+ * concurrently on the GPU, and for the decode chains of <= 8 rows that is worth 1.5 x the throughput (three passes in
+ * flight: DESIGN.md §3 "Lanes").  The library takes no lock: wh_encode calls that share a workspace must be enqueued on
+ * one stream and not from two threads at once; every task owns its workspace. */
 
 /* ---- library ------------------------------------------------------------------------------ */
 int wh_abi_version(void);
