@@ -29,6 +29,10 @@
 #include "kernels.h"
 #include <stdlib.h>
 
+#ifndef WH_GEMV8_MAX_ROWS
+#define WH_GEMV8_MAX_ROWS 24
+#endif
+
 namespace {
 
 // compiler-only fence: the machine scheduler otherwise hoists the (independent) weight loads above the
@@ -1076,6 +1080,7 @@ hipError_t launch_gemv8_nrt(const whk::GemvArgs& a, int fw, hipStream_t stream) 
 template <int PRO, int GS, int KS, int CSm, int XW>
 hipError_t launch_gemv8_cfg(const whk::GemvArgs& a, int fw, hipStream_t stream) {
   if (a.R <= 8) return launch_gemv8_nrt<PRO, GS, KS, CSm, XW, 1>(a, fw, stream);
+  if (a.R <= 16) return launch_gemv8_nrt<PRO, GS, KS, CSm, XW, 2>(a, fw, stream);
   // 16-wave workgroups have 128 VGPRs per lane: 3 row tiles of x fragments (60) + the weights (20) fit, 6 would spill
   if constexpr (GS * KS + XW < 16) {
     if (a.R > 24) return launch_gemv8_nrt<PRO, GS, KS, CSm, XW, 6>(a, fw, stream);
@@ -1494,9 +1499,18 @@ hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream) {
     // the 24 / 48-row forms of gemv8 take 6.5 / 8.6 / 14.3 / 11.4 / 14.9 / 18.4 us (out, cq, cout, qkv, fc1, fc2) against
     // 4.8 / 7.9 / 11.2 / 14.9 / 11.7 / 11.3 us for the 16-row LDS-staged MFMA tiles below — those keep the job wherever
     // they apply; gemv8's row blocks serve the remaining shapes (row counts 9..96 outside the 16-row form's limits).
-    if (rows48_applies(a)) return launch_rows48(a, stream);
-    if (rows48_stream_applies(a)) return launch_rows48_stream(a, stream);
-    const bool rows16 = a.R > 8 && a.variant <= 0 && a.K % 128 == 0 && a.K <= 5120 && (a.K / 32 <= 40 || a.pro == whk::PRO_PLAIN);
+    if (a.R > WH_GEMV8_MAX_ROWS || a.epi == whk::EPI_F32) {
+      if (rows48_applies(a)) return launch_rows48(a, stream);
+      if (rows48_stream_applies(a)) return launch_rows48_stream(a, stream);
+    }
+    bool rows16 = a.R > 8 && a.variant <= 0 && a.K % 128 == 0 && a.K <= 5120 && (a.K / 32 <= 40 || a.pro == whk::PRO_PLAIN);
+    // Round 5: 9 - 24 rows run on gemv8_kernel with TWO / THREE row tiles per weight fragment (the weights are streamed once,
+    // every weight wave holds that many sets of x fragments) instead of the 16-row LDS-staged tiles / the 48-row LayerNorm
+    // kernels: the whole step of large-v3 at 16 rows 2680 -> 2073 us, 12 rows 2472 -> 1855, 2 x 5 beam rows 2276 -> 1646,
+    // 3 x 5 2355 -> 1740, 4 x 5 2228 -> 1949, 24 rows 2862 -> 2609.  Beyond 24 rows it loses: 4 / 5 / 6 tiles at 32 / 40 rows
+    // 3526 / 3030 vs 3207 / 2571 us (every weight wave fetches all tiles' x fragments itself, the LayerNorm waves take 5 rows
+    // each), so 25 - 48 rows keep the LDS-staged forms (profiles/r05_rows24.txt).  WH_GEMV8_MAX_ROWS is the knob of that A/B.
+    if (a.R <= WH_GEMV8_MAX_ROWS) rows16 = false;
     if (a.R <= 96 && !rows16) {
       const hipError_t e = launch_gemv8(a, stream);
       if (e != hipErrorNotSupported) return e;
