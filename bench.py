@@ -528,6 +528,14 @@ def main():
                 # algorithmic bytes (weights once + every audio's cross K/V once + the rows' self K/V + logits)
                 extras["beam_search"].update(step_roofline(model, model.encode(mel), B, args.beam, T0 + args.beam_steps // 2))
                 log(f"beam {args.beam}: {bms:.1f} ms per pass of {B} clips x {args.beam_steps} steps")
+            # the headline model's decode step at 16 and 20 rows (9 - 24 rows run on gemv8_kernel's row tiles since round 5)
+            if args.model == "large-v3" and B == 8:
+                f8 = model.encode(whisper_amd.log_mel_spectrogram(audio, dims.n_mels))
+                extras["step_at_other_row_counts"] = {
+                    "16_rows": step_roofline(model, torch.cat([f8, f8]).contiguous(), 16, 1, T0 + 32),
+                    "4x5_beam_rows": step_roofline(model, f8[:4].contiguous(), 4, 5, T0 + 32)}
+                log(f"decode step at 16 rows: {extras['step_at_other_row_counts']['16_rows']['step_us']} us, "
+                    f"at 4 x 5 beam rows: {extras['step_at_other_row_counts']['4x5_beam_rows']['step_us']} us")
             # BASELINE configs[4] shape: word timestamps (cross-attention alignment + DTW) for every clip of the batch
             if args.word_timestamps:
                 from whisper_amd.timing import find_alignment_batch
