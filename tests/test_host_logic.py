@@ -903,6 +903,21 @@ def test_api_surface_matches_reference(ref):
     loose = m.load_state_dict({"decoder.ln.weight": theirs_sd["decoder.ln.weight"], "extra": torch.zeros(1)}, strict=False)
     assert loose.unexpected_keys == ["extra"] and "decoder.ln.bias" in loose.missing_keys
     assert m.half() is m and m._half and m.float() is m and not m._half and m.eval() is m and m.train(False) is m
+    # nn.Module.to as an inference user calls it: a dtype is half() / float(), a device moves, both at once work
+    assert m.to(torch.float16) is m and m._half and m.to(dtype=torch.float32) is m and not m._half
+    assert m.to("cpu", torch.float16) is m and m._half and m.device == torch.device("cpu") and m.to(device="cpu") is m
+    m.float()
+    with pytest.raises(TypeError):
+        m.to(torch.int8)
+    with pytest.raises(TypeError):
+        m.to(torch.zeros(1))
+    # load_state_dict COPIES (torch does): a later in-place edit of the caller's tensors does not reach the model
+    mine_w = theirs_sd["decoder.ln.weight"].clone()
+    m.load_state_dict({"decoder.ln.weight": mine_w}, strict=False)
+    mine_w.add_(1.0)
+    assert torch.equal(m.state_dict()["decoder.ln.weight"], theirs_sd["decoder.ln.weight"])
+    with pytest.raises(TypeError):
+        m.load_state_dict({"decoder.ln.weight": [1.0] * int(theirs_sd["decoder.ln.weight"].numel())}, strict=False)
     # alignment heads: default = upper half of the decoder layers (model.py:270-276); dumps decode like the reference's
     dense = m.alignment_heads.to_dense()
     assert dense.shape == (fm.dims.n_text_layer, fm.dims.n_text_head) and bool(dense[fm.dims.n_text_layer // 2:].all())
