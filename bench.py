@@ -273,24 +273,31 @@ def main():
                 n = one_pass(0)
             return n
         import threading
-        res = [0] * F
+        res, done, errors = [0] * F, [0] * F, []
         nxt, lock = [0], threading.Lock()
 
         def worker(i):
-            torch.cuda.set_device(device)
-            while True:
-                with lock:                       # the next pass goes to whichever lane is free first
-                    j = nxt[0]
-                    nxt[0] += 1
-                if j >= k:
-                    return
-                res[i] = one_pass(i)
+            try:
+                torch.cuda.set_device(device)
+                while True:
+                    with lock:                   # the next pass goes to whichever lane is free first
+                        j = nxt[0]
+                        nxt[0] += 1
+                    if j >= k or errors:
+                        return
+                    res[i] = one_pass(i)
+                    done[i] += 1
+            except BaseException as e:           # noqa: BLE001 — re-raised below: a lost pass must never shorten the timed region
+                errors.append(e)
         th = [threading.Thread(target=worker, args=(i,)) for i in range(min(F, k))]
         for t_ in th:
             t_.start()
         for t_ in th:
             t_.join()
-        return max(res)
+        if errors:
+            raise errors[0]
+        assert sum(done) == k, (done, k)         # exactly k passes ran
+        return min(r for r, d in zip(res, done) if d)
 
     def barrier():
         torch.cuda.synchronize(device)
