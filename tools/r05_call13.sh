@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
-timeout 1200 python -m pytest tests/test_wide_gpu.py -q -m gpu -k "prefill_and_steps" 2>&1 | grep -v Warning | tail -6
+timeout 600 python tools/two_stream_ab.py 2>&1 | grep -v amdgpu.ids

@@ -24,8 +24,8 @@ params = hip.GreedyParams(sample_begin=T0, max_steps=N, n_ctx=dims.n_text_ctx, e
                           no_timestamps=tok.no_timestamps, max_initial_timestamp_index=50, suppress_blank=1,
                           blank_token=tok.encode(" ")[0], suppress_mask=mask.data_ptr())
 g = torch.Generator(device=dev).manual_seed(4)
-feats = (torch.randn(16, dims.n_audio_ctx, dims.n_audio_state, generator=g, device=dev)
-         + 3.0 * torch.randn(16, 1, dims.n_audio_state, generator=g, device=dev)).half()
+feats = (torch.randn(48, dims.n_audio_ctx, dims.n_audio_state, generator=g, device=dev)
+         + 3.0 * torch.randn(48, 1, dims.n_audio_state, generator=g, device=dev)).half()
 init_t = torch.tensor(init, device=dev)
 sot_index = tok.sot_sequence.index(tok.sot)
 
@@ -65,3 +65,8 @@ for label, jobs, clips in (("one task, 8 rows", [j8], 8), ("one task, 4 rows", [
 ref = j8.tokens[:, : T0 + N].clone()
 both = torch.cat([j4a.tokens, j4b.tokens])[:, : T0 + N]
 print("  tokens of the two 4-row tasks equal to the 8-row task's:", bool((both == ref).all()), flush=True)
+# round 5, after 9 - 24 rows moved to gemv8_kernel's row tiles: do chains of 16 rows overlap as chains of 8 do?
+j16 = [Job(slice(16 * i, 16 * i + 16), s[i]) for i in range(3)]
+for label, jobs, clips in (("one task, 16 rows", j16[:1], 16), ("two tasks of 16 rows at once", j16[:2], 32), ("three tasks of 16 rows at once", j16, 48)):
+    best, ts = timed(jobs)
+    print(f"  {label:32s}: {best:7.1f} ms per 224-step decode = {best / N * 1e3:7.1f} us per step, {clips * 30.0 / (best * 1e-3):7.1f} audio-s/s of decode  {[round(x, 1) for x in ts]}", flush=True)
