@@ -95,6 +95,7 @@ def parse():
     p.add_argument("--task-form", type=int, default=-1, help="developer A/B: 0 = the fused step launches of csrc/xattn.hip, 1 = self attention "
                                                             "as two launches, 2 = cross attention as two launches, 3 = both; default -1: 0 for one "
                                                             "pass at a time, 1 in lanes (what HipModel.acquire_task gives a lane's task)")
+    p.add_argument("--lane-encoders", action="store_true", help="developer A/B: every lane encodes on its own stream with its own workspace")
     p.add_argument("--lane-priority", type=int, default=0, help="HIP stream priority of the lanes' streams (-1 = high; the encoder's stream stays at 0)")
     p.add_argument("--in-flight", type=int, default=3, help="passes (batches of --batch clips) in flight at once on this GPU: each on "
                                                             "its own task, HIP stream and host thread (1 = one pass after the other)")
@@ -247,17 +248,23 @@ def main():
     lanes = []
     for i in range(F):
         st = torch.cuda.Stream(device=device, priority=args.lane_priority) if F > 1 else torch.cuda.current_stream(device)
-        lanes.append((st, hip.HipTask(model, B, 1, max(T0, 8), stream=st if F > 1 else None,
+        # developer A/B (--lane-encoders): an engine handle of its own per lane on the SAME weight blob, its stream the lane's:
+        # every lane then encodes on its own stream with its own workspace (F streams instead of F + 1)
+        eng_i = model
+        if F > 1 and args.lane_encoders:
+            eng_i = hip.HipModel(dims, dtype, blob)
+            eng_i.stream = st
+        lanes.append((st, hip.HipTask(eng_i, B, 1, max(T0, 8), stream=st if F > 1 else None,
                                       two_launch_self=bool(args.task_form & 1), two_launch_cross=bool(args.task_form & 2)),
-                      torch.zeros(B, T0 + N + 1, dtype=torch.int64, device=device)))
+                      torch.zeros(B, T0 + N + 1, dtype=torch.int64, device=device), eng_i))
     task, tokens = lanes[0][1], lanes[0][2]
     torch.cuda.synchronize(device)
 
     def one_pass(lane=0):
-        st, tk, toks = lanes[lane]
+        st, tk, toks, eng_i = lanes[lane]
         with torch.cuda.stream(st):
             mel = log_mel_spectrogram(audio, dims.n_mels)            # (B, n_mels, 3000) fp32 on device
-            feats = model.encode(mel)
+            feats = eng_i.encode(mel)
             tk.reset()
             tk.set_audio(feats)
             toks.zero_()

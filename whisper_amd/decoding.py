@@ -817,7 +817,10 @@ def run_in_lanes(model: "Whisper", jobs: Sequence, in_flight: int = 3, dtype: Op
     `in_flight` of them running at once, each on a host thread and a HIP stream of its own (`HipModel.lane`); results in job
     order.  No counterpart in the reference.  Why it pays: one decode chain is ~190 dependent launches per token and leaves the
     chip idle between them, so independent chains fill each other's gaps (large-v3, 8 clips per job, greedy, 224 tokens: 692
-    audio-s/s one after the other, 917 / 1025 with 2 / 3 in flight, identical tokens).  Jobs must be independent of each other;
+    audio-s/s one after the other, 917 / 1025 with 2 / 3 in flight, identical tokens).  Three is the useful maximum: the lanes'
+    streams and the engine's encoder stream then occupy the GPU's four hardware queues; with four lanes the streams share queues,
+    throughput drops (953 audio-s/s) and the fused step kernels' bounded hand-off spins start to run out (36 time-outs in one run —
+    the affected task then finishes on its two-launch kernels, results unchanged).  Jobs must be independent of each other;
     an exception in a job is re-raised here after the others have finished."""
     import threading
     jobs = list(jobs)
