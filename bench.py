@@ -442,6 +442,8 @@ def main():
         out["handoff_fallbacks"] = sum(ln[1].handoff_fallbacks for ln in lanes)
     for ln in lanes:
         ln[1].close()
+    if F > 1:
+        model.adopt_lane_streams([ln[0] for ln in lanes])      # the public-API legs below run their lanes on the same streams
 
     # ---- the same workload through the public drop-in surface ----------------------------------------------------
     if rank == 0 and world == 1 and not args.no_extras:      # single-GPU runs only: the scaling runs stay short

@@ -50,7 +50,11 @@ namespace {
 
 typedef unsigned long long u64;
 constexpr float XSCALE = 0.125f;      // d_head^-0.5 for d_head = 64
-constexpr int X_MAX_SPINS = 8192;
+// Bound of every hand-off spin (one poll is 0.3 - 1 us: 20 - 65 ms in all).  8192 until round 5: enough for a chain that has the chip
+// to itself and for the GEMM side-stream of the contention test, but with three decode chains AND the encoder's stream on the GPU's
+// four hardware queues a producer workgroup was now and then dispatched milliseconds late (36 - 42 time-outs in 3 of ~25 runs; the task
+// then finishes on the two-launch kernels — correct, slower).  A time-out is a safety net against a hang, not a scheduling tool.
+constexpr int X_MAX_SPINS = 1 << 16;
 
 __device__ __forceinline__ float qk_unit8(half8v q, half8v k) {
   float d = __builtin_amdgcn_fdot2(half2v{q[0], q[1]}, half2v{k[0], k[1]}, 0.f, false);

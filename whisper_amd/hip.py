@@ -397,6 +397,7 @@ class HipModel:
         self._lock = threading.RLock()                  # task cache, workspace (re)allocation
         self._enc_lock = threading.Lock()               # one encoder's launches are enqueued without another's in between
         self._tls = threading.local()                   # .stream: the lane stream of the calling thread (None: self.stream)
+        self._lane_pool: List[torch.cuda.Stream] = []   # idle lane streams (`lane`)
         self.debug_task_flags = 0                       # OR-ed into the flags of every task created (tests: WH_TASK_EXPIRE_HANDOFFS)
         # workspaces kept alive between windows: WH_TASK_CACHE_GB, else 10 % of the device memory (28 GB of the 288 GB of
         # an MI355X; a smaller GPU gets a smaller cache).  Allocation failures anywhere on this engine's path drop the
@@ -416,7 +417,16 @@ class HipModel:
         log-mel, sampling and decode chains overlap those of other threads' lanes.  Without it all tasks of an engine share
         `self.stream` and run one after the other.  The encoder stays on the engine's stream (one workspace): encoders of
         different lanes are ordered among themselves and overlap the other lanes' decode chains."""
-        st = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        # lane streams are pooled: the GPU has four hardware queues, and every stream ever created keeps its place on one of
+        # them — a fresh stream per lane and call would soon have two live lanes sharing a queue
+        own = stream is None
+        if own:
+            with self._lock:
+                st = self._lane_pool.pop() if self._lane_pool else None
+            if st is None:
+                st = torch.cuda.Stream(device=self.device)
+        else:
+            st = stream
         prev = getattr(self._tls, "stream", None)
         self._tls.stream = st
         try:
@@ -424,6 +434,17 @@ class HipModel:
                 yield st
         finally:
             self._tls.stream = prev
+            if own:
+                with self._lock:
+                    self._lane_pool.append(st)
+
+    def adopt_lane_streams(self, streams: Sequence[torch.cuda.Stream]) -> None:
+        """hand idle streams to the lane pool (a caller that ran its own lanes, like bench.py, gives its streams back so that
+        later `lane()` calls reuse them instead of creating more streams than the GPU has hardware queues)"""
+        with self._lock:
+            for st in streams:
+                if all(st is not x for x in self._lane_pool):
+                    self._lane_pool.append(st)
 
     def task_stream(self) -> torch.cuda.Stream:
         """the stream tasks acquired by the calling thread run on"""
