@@ -34,7 +34,7 @@ enum {
   WH_ERR_HIP = 3,        /* a HIP runtime call failed; see wh_last_hip_error() */
   WH_ERR_STATE = 4,      /* call sequence violation (e.g. step before prefill) */
   WH_ERR_LIMIT = 5,      /* exceeds a compiled-in limit (rows, LDS) */
-  WH_ERR_HANDOFF = 6     /* a bounded in-kernel hand-off spin of the fused decode-step launches ran out (csrc/xattn.hip):
+  WH_ERR_HANDOFF = 6,    /* a bounded in-kernel hand-off spin of the fused decode-step launches ran out (csrc/xattn.hip):
                           * the results of the call are NOT valid.  Never seen on a healthy, unshared device; a GPU
                           * time-sliced between processes may stretch a spin past its bound.  wh_task_greedy /
                           * wh_task_beam do not return it: they check the counter before they return, and on a time-out
@@ -42,6 +42,8 @@ enum {
                           * from the prompt (wh_task_info(t, 4) counts these re-runs).  After host-driven wh_task_step
                           * calls ask wh_task_info(t, 1); create the task with WH_TASK_TWO_LAUNCH_SELF |
                           * WH_TASK_TWO_LAUNCH_CROSS to stay off the fused kernels from the start. */
+  WH_RUNNING = 7         /* not an error: wh_task_poll — the loop begun with wh_task_greedy_begin / wh_task_beam_begin has not
+                          * ended yet; call again */
 };
 
 /* element type of weights / activations / KV caches. Accumulation is always fp32. */
@@ -118,10 +120,11 @@ typedef struct wh_model wh_model;   /* opaque: dims + copies of the pointer tabl
 typedef struct wh_task wh_task;     /* opaque: per-DecodingTask KV caches + workspace carve-up.  One call at a time per
                                      * handle: a second thread entering while a call runs gets WH_ERR_STATE (enforced) */
 /* Concurrency.  A wh_model is immutable and may be used by any number of threads and tasks at once.  Tasks on DIFFERENT
- * streams, each driven by its own host thread (wh_task_greedy / wh_task_beam return when their loop has ended), run
- * concurrently on the GPU, and for the decode chains of <= 8 rows that is worth 1.5 x the throughput (three passes in
- * flight: DESIGN.md §3 "Lanes").  The library takes no lock: wh_encode calls that share a workspace must be enqueued on
- * one stream and not from two threads at once; every task owns its workspace. */
+ * streams run concurrently on the GPU, and for decode chains of few rows that is worth up to 1.5 x the throughput
+ * (DESIGN.md §3 "Lanes").  Either every task is driven by its own host thread (wh_task_greedy / wh_task_beam return when
+ * their loop has ended; the thread sleeps while it waits), or ONE thread drives them all through wh_task_greedy_begin /
+ * wh_task_beam_begin + wh_task_poll, which never wait.  The library takes no lock: wh_encode calls that share a workspace
+ * must be enqueued on one stream and not from two threads at once; every task owns its workspace. */
 
 /* ---- library ------------------------------------------------------------------------------ */
 int wh_abi_version(void);
@@ -155,14 +158,20 @@ int wh_encode(const wh_model *m, const void *mel, int mel_is_f16, int batch, voi
 enum {
   WH_TASK_CAPTURE_Q = 1,         /* keep cross-attention queries of every layer (word timestamps) */
   /* decode step: projection and attention as separate launches even where the fused kernels of csrc/xattn.hip apply
-   * (A/B and tests: the results must agree) — for the self attention / for the cross attention */
+   * (A/B and tests: the results must agree) — for the self attention (the default since round 6, see
+   * WH_TASK_FUSED_SELF; the flag is accepted and wins over it) / for the cross attention */
   WH_TASK_TWO_LAUNCH_SELF = 2,
   WH_TASK_TWO_LAUNCH_CROSS = 4,
   /* 8: reserved (development builds of the library only; ignored here) */
   /* Fault injection for the hand-off protocol of the fused step kernels: every consumer gives up after its FIRST poll, as
    * if its bounded spin had run out.  The step's result is then invalid by construction; wh_task_greedy / wh_task_beam
    * must notice (WH_ERR_HANDOFF internally), move the task to the two-launch kernels and re-run — what the tests check. */
-  WH_TASK_EXPIRE_HANDOFFS = 16
+  WH_TASK_EXPIRE_HANDOFFS = 16,
+  /* decode step of <= 8 rows (fp16): LayerNorm + QKV projection + cache append + self attention as ONE launch
+   * (sattn8_kernel, csrc/xattn.hip; bit-identical to the two launches).  Opt-in since round 6: alone on the chip the two
+   * forms take the same time, beside other decode chains the fused one is slower (its consumers spin for q / k / v), so
+   * the default step keeps only the cross attention fused (where the K/V stream hides the projection). */
+  WH_TASK_FUSED_SELF = 32
 };
 /* The workspace holds the cross-attention K/V of n_audio segments, the self-attention cache of n_audio * n_group rows
  * and the step buffers.  WH_F16 tasks with n_group > 1 (beam search) additionally hold a transposed copy of the
@@ -246,6 +255,24 @@ typedef struct wh_greedy_params {
 int wh_task_greedy(wh_task *t, const wh_greedy_params *p, int64_t *tokens, int64_t token_stride,
                    int sot_index, int no_speech_token, float *sum_logprobs, float *no_speech_probs,
                    int32_t *n_tokens_out, void *stream);
+/*
+ * The same loop without a blocked caller: DecodingTask._main_loop (decoding.py:680-710) split at the points where the host
+ * would wait for the device.  wh_task_greedy_begin queues the prompt pass and the first sampling decision on `stream` and
+ * returns at once (it never synchronises); wh_task_poll(t, &n) then queues further decode steps — never more than about
+ * ten ahead of the device — and returns WH_RUNNING until the loop has ended, WH_OK (n = final token count per row,
+ * results in the buffers given to _begin) once it has, or an error.  It never waits either: the host only asks whether an
+ * event has been reached.  So ONE host thread can keep any number of tasks on different streams going by polling them in
+ * turn (several decode chains in flight on a GPU: DESIGN.md §3 "Lanes"); call it at least every millisecond or two per
+ * task, or the device runs out of queued steps.  Between _begin and the poll that reports the end, the task refuses every
+ * other call (WH_ERR_STATE), and the buffers and `p->suppress_mask` must stay valid.  A hand-off time-out of the fused
+ * step kernels is handled inside wh_task_poll exactly as inside wh_task_greedy (the loop is re-run on the two-launch
+ * kernels; polls keep returning WH_RUNNING meanwhile).  wh_task_greedy == wh_task_greedy_begin + wh_task_poll until done,
+ * with sleeping waits in place of the queries — the same sequence of device operations.
+ */
+int wh_task_greedy_begin(wh_task *t, const wh_greedy_params *p, int64_t *tokens, int64_t token_stride,
+                         int sot_index, int no_speech_token, float *sum_logprobs, float *no_speech_probs,
+                         void *stream);
+int wh_task_poll(wh_task *t, int32_t *n_tokens_out);
 
 /*
  * Fused beam search loop == DecodingTask._main_loop with BeamSearchDecoder (decoding.py:301-404) and the stock logit
@@ -267,6 +294,11 @@ typedef struct wh_beam_params {
 int wh_task_beam(wh_task *t, const wh_beam_params *p, int64_t *tokens, int64_t token_stride, int sot_index,
                  int no_speech_token, float *sum_logprobs, float *no_speech_probs, int64_t *fin_tokens,
                  int32_t *fin_len, float *fin_scores, int32_t *fin_count, int32_t *n_tokens_out, void *stream);
+/* wh_task_beam without a blocked caller: begin, then wh_task_poll until it stops returning WH_RUNNING (see
+ * wh_task_greedy_begin; n_tokens_out of wh_task_poll = length of the live beams' rows). */
+int wh_task_beam_begin(wh_task *t, const wh_beam_params *p, int64_t *tokens, int64_t token_stride, int sot_index,
+                       int no_speech_token, float *sum_logprobs, float *no_speech_probs, int64_t *fin_tokens,
+                       int32_t *fin_len, float *fin_scores, int32_t *fin_count, void *stream);
 
 /* cross-attention QK of chosen heads for the cached positions — the `qk` captured by the hooks of
  * find_alignment (whisper/timing.py:186-197; model.py:130-137 manual path): for every pair

@@ -324,3 +324,27 @@ def margins_of(dec: Dict) -> Dict:
         out["rule_min"] = float(min(rule))
         out["rule_n"] = len(rule)
     return out
+
+
+def build_reference(dims, sd: Dict[str, torch.Tensor], audio: np.ndarray, initial_tokens: List[int], n_steps: int,
+                    r: SamplingRules, seed: int = 0, margin: Tuple[float, float] = (0.35, 3.0),
+                    text_run: Tuple[int, int] = (4, 14), passes: int = 2, log=None, sdpa: bool = True) -> Dict:
+    """The checker's side of an END-TO-END parity statement on raw audio (what bench.py's `oracle_side` does for the headline,
+    as one call for the other configurations and for tests): oracle log-mel (audio.py:110-157) -> oracle AudioEncoder
+    (model.py:188-204) on `audio` (B, n_samples) fp32, `center_cross_values` + `condition_greedy` on those features — `sd` is
+    edited IN PLACE (cross-attention value biases, tied-embedding rows): pack the engines from it AFTERWARDS — then the plain
+    oracle's greedy decode of `n_steps` tokens with every step's filtered logits kept.
+    Returns {"om", "mel", "feats", "dec" (greedy_decode(..., keep_logits=True)), "margins", "edited_rows", "consistent"}."""
+    from .decoding import greedy_decode
+    from .mel import log_mel_spectrogram, mel_filterbank
+    om = OracleModel(dims, sd, sdpa=sdpa)
+    filt = mel_filterbank(dims.n_mels)
+    with torch.no_grad():
+        mel = torch.stack([torch.as_tensor(log_mel_spectrogram(audio[b], filt)) for b in range(audio.shape[0])])
+        feats = om.encoder(mel)
+        center_cross_values(om, feats)
+        built = condition_greedy(om, feats, initial_tokens, n_steps, r, seed=seed, margin=margin, text_run=text_run,
+                                 log=log, passes=passes)
+        dec = greedy_decode(om, feats, initial_tokens, n_steps, r, keep_logits=True)
+    return {"om": om, "mel": mel, "feats": feats, "dec": dec, "margins": margins_of(dec), "edited_rows": len(built["rows"]),
+            "consistent": bool(torch.equal(built["tokens"], dec["tokens"]))}

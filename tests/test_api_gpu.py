@@ -529,7 +529,8 @@ def test_device_beam_search_equals_host_loop(setup, gpu_device, kw):
 
 
 def test_beam_search_survives_a_handoff_timeout(setup, gpu_device):
-    """2 clips x beam 4 = 8 rows in the fp16 engine: the step runs the fused self-attention launch.  With every hand-off
+    """2 clips x beam 4 = 8 rows in the fp16 engine, the task created with WH_TASK_FUSED_SELF (opt-in since round 6; a beam task
+    cannot take the fused cross attention, which wants one row per audio): the step runs the fused self-attention launch.  With every hand-off
     forced to time out (WH_TASK_EXPIRE_HANDOFFS, fresh task) wh_task_beam re-runs the search on the two-launch kernels
     inside the call; decode() returns what it returns without the time-outs (the fused self attention is bit-identical
     to the two-launch form, so ids and scores agree exactly)."""
@@ -540,7 +541,7 @@ def test_beam_search_survives_a_handoff_timeout(setup, gpu_device):
     eng.drop_cached_tasks()
     want = whisper_amd.decode(model, mels, opts)
     eng.drop_cached_tasks()                                  # the next task is created with the fault-injection flag
-    eng.debug_task_flags = hip.WH_TASK_EXPIRE_HANDOFFS
+    eng.debug_task_flags = hip.WH_TASK_EXPIRE_HANDOFFS | hip.WH_TASK_FUSED_SELF
     try:
         got = whisper_amd.decode(model, mels, opts)
     finally:
@@ -674,11 +675,14 @@ def test_incremental_decoder_with_kv_cache_hooks(setup, gpu_device):
 
 @pytest.mark.parametrize("fp16,beam", [(False, None), (True, None), (False, 3)])
 def test_decode_many_in_lanes_equals_sequential(setup, fp16, beam):
-    """whisper_amd.decode_many: several batches decoded with up to 3 in flight — each on a host thread and HIP stream of its own
-    (HipModel.lane), the encoder on the engine's one stream — must give exactly what decode() gives batch by batch: token ids,
-    avg_logprob, no_speech_prob; greedy and beam search, both engines; raw audio batches take their log-mel inside the lane.
-    Batches of different sizes (different task shapes), more batches than lanes (a lane runs several), twice in a row (the
-    lanes' tasks come back from the engine's cache)."""
+    """whisper_amd.decode_many: several batches decoded with up to 3 chains in flight — each on a HIP stream of its own
+    (HipModel.lane), all driven from the calling thread (run_interleaved: wh_task_*_begin + wh_task_poll in turn), the encoder on
+    the engine's one stream.  With chain_rows=None every batch is its own chain and must give exactly what decode() gives batch by
+    batch: token ids, avg_logprob, no_speech_prob; greedy and beam search, both engines; raw audio batches take their log-mel
+    per batch.  Batches of different sizes (different task shapes), more batches than lanes (a lane runs several), twice in a
+    row (the lanes' tasks come back from the engine's cache).  With the default chain_rows=24 consecutive batches are coalesced
+    into wider chains: exact in the fp32 engine, equal ids and log-probabilities to 5e-3 in the fp16 engine (the order of fp32
+    partial sums follows the row count)."""
     key, dims, sd, model, mel = setup
     dev = mel.device
     clips = [audio(50 + i) for i in range(9)]
@@ -687,22 +691,56 @@ def test_decode_many_in_lanes_equals_sequential(setup, fp16, beam):
     opts = whisper_amd.DecodingOptions(language="en", fp16=fp16, sample_len=16, beam_size=beam)
     want = [whisper_amd.decode(model, (b.half() if fp16 else b), opts) for b in batches]
     for _ in range(2):
-        got = whisper_amd.decode_many(model, [(b.half() if fp16 else b) for b in batches], opts, in_flight=3)
+        got = whisper_amd.decode_many(model, [(b.half() if fp16 else b) for b in batches], opts, in_flight=3, chain_rows=None)
         assert len(got) == len(want)
         for g, w in zip(got, want):
             assert [r.tokens for r in g] == [r.tokens for r in w]
             assert np.allclose([r.avg_logprob for r in g], [r.avg_logprob for r in w], atol=1e-6)
             assert np.allclose([r.no_speech_prob for r in g], [r.no_speech_prob for r in w], atol=1e-6)
-    # raw audio in, log-mel inside the lane
+    # coalesced (default chain_rows=24): greedy 3 + 1 + 2 + 3 + 2 = 11 rows in one chain; beam 3: 9 + 3 + 6 | 9 + 6 rows
+    got = whisper_amd.decode_many(model, [(b.half() if fp16 else b) for b in batches], opts, in_flight=2)
+    assert [len(g) for g in got] == [len(w) for w in want]
+    for g, w in zip(got, want):
+        assert [r.tokens for r in g] == [r.tokens for r in w]
+        tol = 5e-3 if fp16 else 1e-6
+        assert np.allclose([r.avg_logprob for r in g], [r.avg_logprob for r in w], atol=tol)
+        assert np.allclose([r.no_speech_prob for r in g], [r.no_speech_prob for r in w], atol=tol)
+    # raw audio in, log-mel per batch
     raw = [torch.from_numpy(np.stack(clips[0:3])).to(dev), torch.from_numpy(np.stack(clips[4:6])).to(dev)]
-    got = whisper_amd.decode_many(model, raw, opts, in_flight=2)
+    got = whisper_amd.decode_many(model, raw, opts, in_flight=2, chain_rows=None)
     want_raw = [whisper_amd.decode(model, whisper_amd.log_mel_spectrogram(r, dims.n_mels).to(torch.float16 if fp16 else torch.float32), opts)
                 for r in raw]
     assert [[r.tokens for r in g] for g in got] == [[r.tokens for r in w] for w in want_raw]
-    # an exception inside a lane reaches the caller
+    # an exception inside a chain reaches the caller, and the engine keeps working afterwards
     with pytest.raises(Exception):
-        whisper_amd.decode_many(model, [batches[0], torch.zeros(2, dims.n_mels, 17, device=dev)], opts, in_flight=2)
+        whisper_amd.decode_many(model, [batches[0], torch.zeros(2, dims.n_mels, 17, device=dev)], opts, in_flight=2, chain_rows=None)
     assert [r.tokens for r in whisper_amd.decode(model, (batches[1].half() if fp16 else batches[1]), opts)] == [r.tokens for r in want[1]]
+
+
+def test_run_in_lanes_threads_and_seeds(setup):
+    """whisper_amd.run_in_lanes (one host thread + HIP stream per lane, for arbitrary callables): results in job order; an
+    exception raised by a job reaches the caller; and sampling seeds are a function of torch's generator state and the JOB's
+    index, not of which lane runs a job when — two runs under the same torch.manual_seed draw the same tokens at temperature 0.7
+    (lanes used to race for draws from the process-wide generator)."""
+    key, dims, sd, model, mel = setup
+    dev = mel.device
+    mels = [whisper_amd.pad_or_trim(whisper_amd.log_mel_spectrogram(audio(70 + i), dims.n_mels, device=dev), 3000)[None] for i in range(5)]
+    opts = whisper_amd.DecodingOptions(language="en", fp16=False, sample_len=12, temperature=0.7, best_of=2)
+
+    def run():
+        torch.manual_seed(1234)
+        return whisper_amd.run_in_lanes(model, [lambda m=m: whisper_amd.decode(model, m, opts) for m in mels], 3, torch.float32)
+    a, b = run(), run()
+    assert [[r.tokens for r in x] for x in a] == [[r.tokens for r in x] for x in b]
+    torch.manual_seed(99)
+    c = whisper_amd.run_in_lanes(model, [lambda m=m: whisper_amd.decode(model, m, opts) for m in mels], 3, torch.float32)
+    assert [[r.tokens for r in x] for x in c] != [[r.tokens for r in x] for x in a]        # another seed, other draws
+
+    def boom():
+        raise ValueError("job failed")
+    with pytest.raises(ValueError):
+        whisper_amd.run_in_lanes(model, [lambda: 1, boom, lambda: 3], 2, torch.float32)
+    assert whisper_amd.run_in_lanes(model, [lambda i=i: i * i for i in range(7)], 3, torch.float32) == [i * i for i in range(7)]
 
 
 def test_transcribe_batch_in_flight_equals_one_lane(setup):

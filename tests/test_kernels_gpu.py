@@ -421,3 +421,134 @@ def test_task_handle_refuses_concurrent_callers(micro, gpu_device):
         assert task.prefill(tokens[:, :len(init)].contiguous()).shape == (2, len(init), dims.n_vocab)
     finally:
         task.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the fused loops without a blocked caller: wh_task_greedy_begin / wh_task_beam_begin + wh_task_poll
+# ---------------------------------------------------------------------------------------------------
+def _loop_setup(micro, gpu_device, dt, B, n_steps, eot_ok=True):
+    dims, sd, om, models = micro["micro.en"]
+    model = models[dt]
+    rules = _rules(dims, 1, True)
+    mask = torch.zeros(dims.n_vocab, dtype=torch.uint8)
+    mask[list(rules.suppress_tokens) + ([] if eot_ok else [rules.eot])] = 1
+    mask = mask.to(gpu_device)
+    p = hip.GreedyParams(sample_begin=1, max_steps=n_steps, n_ctx=dims.n_text_ctx, eot=rules.eot,
+                         timestamp_begin=rules.timestamp_begin, no_timestamps=rules.no_timestamps,
+                         max_initial_timestamp_index=50, suppress_blank=1, blank_token=220, suppress_mask=mask.data_ptr())
+    return dims, om, model, rules, p, mask
+
+
+@pytest.mark.parametrize("dt", [hip.WH_F32, hip.WH_F16])
+@pytest.mark.parametrize("n_steps", [1, 2, 9, 40])
+def test_greedy_begin_poll_equals_blocking_call(micro, gpu_device, dt, n_steps):
+    """wh_task_greedy_begin + wh_task_poll (the loop of decoding.py:680-710 split where the host would wait; nothing in them
+    waits for the device) against wh_task_greedy on the same inputs: token ids, sum_logprobs and no-speech probabilities
+    BIT-identical, same token count (both run one state machine, the blocking call with sleeping waits in place of the event
+    queries).  While the loop runs the task refuses every other call (WH_ERR_STATE) and takes them again afterwards; a poll
+    without a loop is refused too."""
+    import time
+    dims, om, model, rules, p, mask = _loop_setup(micro, gpu_device, dt, 3, n_steps)
+    B = 3
+    feats = _feats(om, dims, B, seed=31).to(gpu_device, model.torch_dtype).contiguous()
+
+    def fresh():
+        t = torch.zeros(B, 1 + n_steps + 1, dtype=torch.int64, device=gpu_device)
+        t[:, 0] = 50257
+        return t
+    task = hip.HipTask(model, B, 1, 8)
+    try:
+        task.set_audio(feats)
+        want_tok = fresh()
+        n0, lp0, ns0 = task.greedy(want_tok, p, 0, rules.no_speech)
+        assert hip.lib().wh_task_poll(task.handle, None) == 4                  # no loop begun: WH_ERR_STATE
+        task.reset()
+        got_tok = fresh()
+        pend = task.greedy_begin(got_tok, p, 0, rules.no_speech)
+        polls, refused = 0, hip.lib().wh_task_reset(task.handle, None)
+        t_end = time.time() + 30
+        while True:
+            res = pend.poll()
+            polls += 1
+            if res is not None:
+                break
+            assert time.time() < t_end, "loop never ended"
+        assert refused == 4                                                     # the task was busy with its loop
+        n1, lp1, ns1 = res
+        torch.cuda.synchronize()
+        assert n1 == n0 and torch.equal(got_tok, want_tok)
+        assert torch.equal(lp1, lp0) and torch.equal(ns1, ns0)
+        assert pend.poll() is res                                               # idempotent once ended
+        task.reset()                                                            # ... and the task takes calls again
+        assert task.prefill(got_tok[:, :1].contiguous()).shape == (B, 1, dims.n_vocab)
+    finally:
+        task.close()
+
+
+def test_two_loops_polled_from_one_thread(micro, gpu_device):
+    """ONE host thread keeps two tasks on two streams going by polling them in turn (what whisper_amd.run_interleaved does):
+    each task's 120-step result equals what it returns alone through the blocking call, and at some point both loops were
+    running at once (neither had ended when the other was polled)."""
+    dims, om, model, rules, p, mask = _loop_setup(micro, gpu_device, hip.WH_F16, 2, 120, eot_ok=False)
+    streams = [torch.cuda.Stream(device=gpu_device) for _ in range(2)]
+    feats = [_feats(om, dims, 2, seed=40 + i).to(gpu_device, torch.float16).contiguous() for i in range(2)]
+    torch.cuda.synchronize()
+    tasks = [hip.HipTask(model, 2, 1, 8, stream=streams[i]) for i in range(2)]
+
+    def fresh():
+        t = torch.zeros(2, 1 + 120 + 1, dtype=torch.int64, device=gpu_device)
+        t[:, 0] = 50257
+        return t
+    try:
+        want = []
+        for i in range(2):
+            tasks[i].set_audio(feats[i])
+            tk = fresh()
+            n, lp, _ = tasks[i].greedy(tk, p, 0, -1)
+            want.append((n, tk.clone(), lp.clone()))
+            tasks[i].reset()
+        toks = [fresh(), fresh()]
+        pend = [tasks[i].greedy_begin(toks[i], p, 0, -1) for i in range(2)]
+        res, both_running = [None, None], 0
+        while res[0] is None or res[1] is None:
+            for i in range(2):
+                if res[i] is None:
+                    res[i] = pend[i].poll()
+            both_running += int(res[0] is None and res[1] is None)
+        torch.cuda.synchronize()
+        assert both_running > 0
+        for i in range(2):
+            assert res[i][0] == want[i][0] == 121
+            assert torch.equal(toks[i], want[i][1]) and torch.equal(res[i][1], want[i][2])
+    finally:
+        for t in tasks:
+            t.close()
+
+
+@pytest.mark.parametrize("n_steps", [3, 20])
+def test_beam_begin_poll_equals_blocking_call(micro, gpu_device, n_steps):
+    """wh_task_beam_begin + wh_task_poll against wh_task_beam: live beams, sum_logprobs, finished lists (tokens, lengths, scores,
+    counts) bit-identical; 2 clips x beam 3, fp32 engine."""
+    dims, om, model, rules, p, mask = _loop_setup(micro, gpu_device, hip.WH_F32, 2, n_steps)
+    B, G = 2, 3
+    feats = _feats(om, dims, B, seed=33).to(gpu_device).contiguous()
+    bp = hip.BeamParams(rules=p, beam_size=G, max_candidates=G)
+
+    def fresh():
+        t = torch.zeros(2, B * G, 1 + n_steps + 2, dtype=torch.int64, device=gpu_device)
+        t[0, :, 0] = 50257
+        return t
+    task = hip.HipTask(model, B, G, 8)
+    try:
+        task.set_audio(feats)
+        t0 = fresh()
+        n0, lp0, ns0, fin0 = task.beam(t0, bp, 0, rules.no_speech)
+        task.reset()
+        t1 = fresh()
+        n1, lp1, ns1, fin1 = task.beam_begin(t1, bp, 0, rules.no_speech).wait()
+        torch.cuda.synchronize()
+        assert n1 == n0 and torch.equal(t1[0, :, :n1], t0[0, :, :n0]) and torch.equal(lp1, lp0) and torch.equal(ns1, ns0)
+        assert torch.equal(fin1[3], fin0[3]) and torch.equal(fin1[1], fin0[1]) and torch.equal(fin1[2], fin0[2])
+        assert torch.equal(fin1[0], fin0[0])
+    finally:
+        task.close()

@@ -20,7 +20,8 @@ from typing import List, Optional, Union
 import torch
 
 from .audio import load_audio, log_mel_spectrogram, pad_or_trim
-from .decoding import DecodingOptions, DecodingResult, decode, decode_many, detect_language, run_in_lanes
+from .decoding import (DecodingOptions, DecodingResult, decode, decode_many, detect_language, run_in_lanes,
+                       run_interleaved)
 from .model import ModelDimensions, Whisper
 from .registry import ALIGNMENT_HEADS as _ALIGNMENT_HEADS
 from .registry import MODEL_URLS as _MODELS

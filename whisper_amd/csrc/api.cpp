@@ -36,6 +36,7 @@ extern "C" const char* wh_status_string(int s) {
     case WH_ERR_STATE: return "invalid call sequence";
     case WH_ERR_LIMIT: return "compiled-in limit exceeded";
     case WH_ERR_HANDOFF: return "in-kernel hand-off timed out (results invalid)";
+    case WH_RUNNING: return "loop still running (call wh_task_poll again)";
     default: return "unknown status";
   }
 }
@@ -263,6 +264,7 @@ extern "C" int wh_encode(const wh_model* m, const void* mel, int mel_is_f16, int
 // ------------------------------------------------------------------------------------------------
 // decoding task
 // ------------------------------------------------------------------------------------------------
+struct wh_loop;
 struct wh_task {
   const wh_model* m;
   int B, G, R, Tmax, flags;
@@ -286,8 +288,13 @@ struct wh_task {
   int* d_pos; int* d_alive; int* d_sel; int* d_src;
   int* d_lag;              // [R] ragged prompts: row r is lag[r] tokens shorter than the longest row (zeros otherwise)
   int* h_lag;              // host copy
-  int* h_poll;             // pinned host word the fused loops copy the completion counter into
+  int* h_poll;             // pinned host words the fused loops copy the completion counter / flags / results into
   hipEvent_t poll_event;   // recorded behind that copy: the loop waits for it two steps later, with work already queued
+  hipEvent_t done_event;   // recorded behind a fused loop's last copies
+  struct wh_loop* loop;    // state of the fused greedy / beam loop (wh_task_*_begin / wh_task_poll)
+  int loop_kind;           // LOOP_IDLE, or the loop that is running: every entry point but wh_task_poll is refused meanwhile
+  int* h_sel;              // pinned: row indices of the prefill's selected positions (source of an async copy)
+  hipEvent_t sel_event;    // recorded behind that copy; waited for before h_sel is rewritten
   bool lag_on;
   bool needs_reset;        // created, position counter / lag not zeroed yet
   std::atomic<int> busy;   // handles are not thread-safe: a second thread entering while a call runs gets WH_ERR_STATE
@@ -309,12 +316,34 @@ struct wh_task {
   size_t total;
 };
 
+// state of a fused greedy / beam loop between wh_task_*_begin and the wh_task_poll that reports its end
+enum { LOOP_IDLE = 0, LOOP_GREEDY = 1, LOOP_BEAM = 2 };
+enum { PH_STEPPING = 0, PH_DRAINING = 1 };
+struct wh_loop {
+  int phase;
+  hipStream_t s;
+  // the caller's arguments (kept for the hand-off fallback's second run)
+  wh_beam_params bp;                 // .rules are the greedy parameters
+  int64_t* tokens; int64_t token_stride; int sot_index, no_speech_token;
+  float* sum_logprobs; float* no_speech_probs;
+  int64_t* fin_tokens; int32_t* fin_len; float* fin_scores; int32_t* fin_count;
+  // loop state
+  SampleArgs sa; BeamArgs ba;
+  bool fused_embed, pending, wait_due;
+  int ntok, steps, ntok_at_copy, cur;
+  int n_tokens;                      // result
+};
+
 // One call at a time per task handle (include/whisper_hip.h: "not thread-safe per handle"), enforced instead of only
 // documented: the second caller is refused, nothing is corrupted.
 struct TaskGuard {
   wh_task* t; bool ok;
-  explicit TaskGuard(wh_task* task) : t(task), ok(false) {
-    if (t) { int expected = 0; ok = t->busy.compare_exchange_strong(expected, 1); }
+  // loop_call: wh_task_poll, the one call a task takes while a fused loop begun with wh_task_*_begin is running
+  explicit TaskGuard(wh_task* task, bool loop_call = false) : t(task), ok(false) {
+    if (t) {
+      int expected = 0; ok = t->busy.compare_exchange_strong(expected, 1);
+      if (ok && !loop_call && t->loop_kind != 0) { t->busy.store(0); ok = false; }
+    }
   }
   ~TaskGuard() { if (t && ok) t->busy.store(0); }
 };
@@ -415,7 +444,7 @@ extern "C" int wh_task_create(const wh_model* m, int n_audio, int n_group, int m
   }
   t->fused_xattn = !(flags & WH_TASK_TWO_LAUNCH_CROSS) && m->dtype == WH_F16 && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) &&
                    xattn_supported(m->d.n_text_state, m->d.n_text_head, t->R, t->G, m->d.n_audio_ctx, t->cross_splits);
-  t->fused_sattn = !(flags & WH_TASK_TWO_LAUNCH_SELF) && m->dtype == WH_F16 && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) && t->self_splits == 1 &&
+  t->fused_sattn = (flags & WH_TASK_FUSED_SELF) && !(flags & WH_TASK_TWO_LAUNCH_SELF) && m->dtype == WH_F16 && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) && t->self_splits == 1 &&
                    sattn_supported(m->d.n_text_state, m->d.n_text_head, t->R, m->d.n_text_ctx);
   // attn.out + residual as phase 0 of the cross-attention launch (needs plain attention rows: one key split): a rejected
   // experiment, slower than the two launches (xattn.hip, out0_issue) — development builds only, WH_FUSED_XOUT=1
@@ -452,7 +481,11 @@ extern "C" void wh_task_destroy(wh_task* t) {
   }
   free(t->h_lag);
   if (t->h_poll) (void)hipHostFree(t->h_poll);
+  if (t->h_sel) (void)hipHostFree(t->h_sel);
   if (t->poll_event) (void)hipEventDestroy(t->poll_event);
+  if (t->done_event) (void)hipEventDestroy(t->done_event);
+  if (t->sel_event) (void)hipEventDestroy(t->sel_event);
+  delete t->loop;
   delete t;
 }
 
@@ -704,7 +737,13 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
   }
   // logits of the selected positions
   if (logits_out && n_sel > 0) {
-    std::vector<int> sel((size_t)R * n_sel);
+    // the row indices go through pinned memory the task owns, so that the copy needs no host synchronisation behind it (the
+    // fused loops' begin calls must not wait for the device); an earlier call's copy has to have executed before the words
+    // are rewritten — it has, unless calls follow each other faster than the stream drains
+    if (!t->h_sel) HIPCHK(hipHostMalloc((void**)&t->h_sel, (size_t)t->R * t->Tmax * sizeof(int), hipHostMallocDefault));
+    if (!t->sel_event) HIPCHK(hipEventCreateWithFlags(&t->sel_event, hipEventDisableTiming));
+    else HIPCHK(hipEventSynchronize(t->sel_event));
+    int* sel = t->h_sel;
     for (int r = 0; r < R; ++r)
       for (int i = 0; i < n_sel; ++i) {
         const int p = (sel_pos ? sel_pos[i] : i) - (sel_pos ? t->h_lag[r * lag_step] : 0);   // selected positions shift with the row
@@ -712,8 +751,8 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
         sel[(size_t)r * n_sel + i] = r * T0 + p;
       }
     const int Ms = R * n_sel;
-    HIPCHK(hipMemcpyAsync(t->d_sel, sel.data(), sel.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));   // `sel` is host stack memory
+    HIPCHK(hipMemcpyAsync(t->d_sel, sel, (size_t)Ms * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(t->sel_event, s));
     HIPCHK(launch_gather_rows(t->x, t->d_sel, Ms, D, t->xsel, s));
     if (Ms <= SKINNY_ROWS && D <= 2048) {          // LayerNorm + tied logits projection as one streaming launch
       GemvArgs g; memset(&g, 0, sizeof(g));
@@ -978,12 +1017,18 @@ extern "C" int wh_task_rearrange(wh_task* t, const int32_t* source_indices, void
   return WH_OK;
 }
 
-// ---- fused greedy loop -----------------------------------------------------------------------------
-// A bounded hand-off spin of the fused step launches ran out during a device-side loop (never observed on an unshared
-// device; a GPU time-sliced between processes could stretch a spin past its bound): what the loop produced is not valid.
-// The task leaves the fused kernels for good — its step graphs are dropped and rebuilt from the two-launch kernels, which
-// wait for nothing — and the caller re-runs the loop from the prompt, which is still in place: the prefill starts at
-// position 0 again, the cross K/V and the rows' lags are untouched.
+// ---- fused greedy / beam loops as resumable state machines ---------------------------------------------------------
+// wh_task_greedy_begin / wh_task_beam_begin queue the prompt pass and the first sampling decision and return;
+// wh_task_poll queues more decode steps — never more than ~10 ahead of the device, the look-ahead the blocking loops have
+// always had — and returns WH_RUNNING until the loop has ended, without ever waiting for the device.  wh_task_greedy /
+// wh_task_beam are begin + poll-until-done with blocking waits in place of the event queries: one code path, the same
+// sequence of device operations either way.
+//
+// A bounded hand-off spin of the fused step launches that ran out during a loop (never observed on an unshared device; a
+// GPU time-sliced between processes could stretch a spin past its bound) makes what the loop produced invalid.  The task
+// then leaves the fused kernels for good — its step graphs are dropped and rebuilt from the two-launch kernels, which wait
+// for nothing — and the loop is re-run from the prompt, which is still in place: the prefill starts at position 0 again,
+// the cross K/V and the rows' lags are untouched.  The caller only ever sees the second result.
 static int handoff_fallback(wh_task* t, hipStream_t s) {
   t->fused_xattn = t->fused_sattn = t->fused_out = t->fused_xout = false;
   for (int i = 0; i < 2; ++i) {
@@ -997,62 +1042,61 @@ static int handoff_fallback(wh_task* t, hipStream_t s) {
   return WH_OK;
 }
 
-static int greedy_impl(wh_task* t, const wh_greedy_params* p, int64_t* tokens, int64_t token_stride,
-                       int sot_index, int no_speech_token, float* sum_logprobs, float* no_speech_probs,
-                       int32_t* n_tokens_out, void* stream_);
-extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* tokens, int64_t token_stride,
-                              int sot_index, int no_speech_token, float* sum_logprobs, float* no_speech_probs,
-                              int32_t* n_tokens_out, void* stream_) {
-  TASK_ENTER(t);
-  int rc = greedy_impl(t, p, tokens, token_stride, sot_index, no_speech_token, sum_logprobs, no_speech_probs, n_tokens_out, stream_);
-  if (rc == WH_ERR_HANDOFF) {
-    rc = handoff_fallback(t, (hipStream_t)stream_);
-    if (rc == WH_OK)
-      rc = greedy_impl(t, p, tokens, token_stride, sot_index, no_speech_token, sum_logprobs, no_speech_probs, n_tokens_out, stream_);
-  }
-  return rc;
+// pinned words behind the B per-segment completion flags of h_poll
+enum { HP_ALIVE = 0, HP_ERR = 8, HP_ERR0 = 9, HP_ALIVE_INIT = 10, HP_APPLIED = 11, HP_WORDS = 32 };
+
+static int loop_resources(wh_task* t) {
+  if (!t->h_poll) HIPCHK(hipHostMalloc((void**)&t->h_poll, ((size_t)t->B + HP_WORDS) * 4, hipHostMallocDefault));
+  // waits on these events SLEEP (hipEventBlockingSync) instead of spinning: a host thread that drives a loop costs no core
+  if (!t->poll_event) HIPCHK(hipEventCreateWithFlags(&t->poll_event, hipEventDisableTiming | hipEventBlockingSync));
+  if (!t->done_event) HIPCHK(hipEventCreateWithFlags(&t->done_event, hipEventDisableTiming | hipEventBlockingSync));
+  if (!t->loop) { t->loop = new (std::nothrow) wh_loop(); if (!t->loop) return WH_ERR_ARG; memset((void*)t->loop, 0, sizeof(wh_loop)); }
+  return WH_OK;
 }
-static int greedy_impl(wh_task* t, const wh_greedy_params* p, int64_t* tokens, int64_t token_stride,
-                       int sot_index, int no_speech_token, float* sum_logprobs, float* no_speech_probs,
-                       int32_t* n_tokens_out, void* stream_) {
-  if (!t || !p || !tokens || !sum_logprobs || !n_tokens_out) return WH_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream_;
+
+// wait for (block) or ask about (!block) an event: WH_OK = reached, WH_RUNNING = not yet
+static int event_reached(hipEvent_t e, bool block) {
+  if (block) { HIPCHK(hipEventSynchronize(e)); return WH_OK; }
+  const hipError_t q = hipEventQuery(e);
+  if (q == hipSuccess) return WH_OK;
+  if (q == hipErrorNotReady) { (void)hipGetLastError(); return WH_RUNNING; }
+  g_last_hip = q;
+  return WH_ERR_HIP;
+}
+
+static int greedy_start(wh_task* t) {
+  wh_loop* L = t->loop;
+  hipStream_t s = L->s;
+  const wh_greedy_params* p = &L->bp.rules;
   const wh_dims& d = t->m->d;
   const int V = d.n_vocab, R = t->R, T0 = p->sample_begin;
-  if (t->pos != 0 || T0 <= 0 || T0 > t->Tmax || p->max_steps <= 0) return WH_ERR_ARG;
-  if (token_stride < (int64_t)T0 + p->max_steps) return WH_ERR_ARG;
-  // ragged rows share one step counter: no row may reach the context limit before the step budget runs out
-  if (t->lag_on && (T0 + p->max_steps > p->n_ctx || T0 + p->max_steps > d.n_text_ctx)) return WH_ERR_ARG;
-
+  int* hp = t->h_poll + t->B;
   // hand-off time-outs are judged per call: the counter as it stands when this call's work starts (stream-ordered copy)
   // is the baseline, so time-outs of earlier host-driven wh_task_step calls on a cached task do not trigger a fallback here
-  if (!t->h_poll) HIPCHK(hipHostMalloc((void**)&t->h_poll, ((size_t)t->B + 16) * 4, hipHostMallocDefault));
-  int* h_err0 = t->h_poll + t->B + 9;
-  HIPCHK(hipMemcpyAsync(h_err0, t->d_err, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(hp + HP_ERR0, t->d_err, 4, hipMemcpyDeviceToHost, s));
 
   int32_t sel[2]; int n_sel;
-  const bool want_ns = no_speech_token >= 0 && no_speech_probs != nullptr;
-  if (want_ns && sot_index != T0 - 1) { sel[0] = sot_index; sel[1] = T0 - 1; n_sel = 2; }
+  const bool want_ns = L->no_speech_token >= 0 && L->no_speech_probs != nullptr;
+  if (want_ns && L->sot_index != T0 - 1) { sel[0] = L->sot_index; sel[1] = T0 - 1; n_sel = 2; }
   else { sel[0] = T0 - 1; n_sel = 1; }
-  int rc = prefill_impl(t, tokens, token_stride, T0, sel, n_sel, t->logits, V, s);
+  int rc = prefill_impl(t, L->tokens, L->token_stride, T0, sel, n_sel, t->logits, V, s);
   if (rc != WH_OK) return rc;
-  if (want_ns) HIPCHK(launch_no_speech(t->logits, (int64_t)n_sel * V, R, V, no_speech_token, no_speech_probs, s));
-  HIPCHK(hipMemsetAsync(sum_logprobs, 0, (size_t)R * 4, s));
-  int alive_init = T0 - 1;
-  HIPCHK(hipMemcpyAsync(t->d_alive, &alive_init, 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipStreamSynchronize(s));
+  if (want_ns) HIPCHK(launch_no_speech(t->logits, (int64_t)n_sel * V, R, V, L->no_speech_token, L->no_speech_probs, s));
+  HIPCHK(hipMemsetAsync(L->sum_logprobs, 0, (size_t)R * 4, s));
+  hp[HP_ALIVE_INIT] = T0 - 1;                          // pinned: read when the copy executes; rewritten only by a later loop
+  HIPCHK(hipMemcpyAsync(t->d_alive, hp + HP_ALIVE_INIT, 4, hipMemcpyHostToDevice, s));
 
-  SampleArgs sa; memset(&sa, 0, sizeof(sa));
-  sa.R = R; sa.V = V; sa.tokens = tokens; sa.token_stride = token_stride; sa.d_ntok = t->d_pos; sa.lag = t->d_lag;
+  SampleArgs& sa = L->sa; memset(&sa, 0, sizeof(sa));
+  sa.R = R; sa.V = V; sa.tokens = L->tokens; sa.token_stride = L->token_stride; sa.d_ntok = t->d_pos; sa.lag = t->d_lag;
   sa.sample_begin = T0; sa.eot = p->eot; sa.timestamp_begin = p->timestamp_begin; sa.no_timestamps = p->no_timestamps;
   sa.max_initial_ts = p->max_initial_timestamp_index; sa.suppress_blank = p->suppress_blank;
-  sa.blank_token = p->blank_token; sa.suppress_mask = p->suppress_mask; sa.sum_logprobs = sum_logprobs;
+  sa.blank_token = p->blank_token; sa.suppress_mask = p->suppress_mask; sa.sum_logprobs = L->sum_logprobs;
   sa.step_tokens = t->step_tokens; sa.d_alive_step = t->d_alive; sa.partials = t->samp_part;
   sa.row_state = t->samp_state;
   HIPCHK(hipMemsetAsync(t->samp_state, 0, (size_t)R * 16, s));
   // the sampler also writes the next step's input row (token embedding + position): the step graph starts at layer 0
-  const bool fused_embed = !WH_DEV_FLAG("WH_NO_FUSED_EMBED");   // developer A/B switch
-  if (fused_embed) {
+  L->fused_embed = !WH_DEV_FLAG("WH_NO_FUSED_EMBED");   // developer A/B switch
+  if (L->fused_embed) {
     sa.x_next = t->x; sa.tok_emb = t->m->w.tok_emb; sa.pos_emb = t->m->w.dec_pos; sa.D = d.n_text_state;
     sa.emb_f16 = t->m->dtype == WH_F16 ? 1 : 0; sa.n_pos = d.n_text_ctx;
   }
@@ -1060,45 +1104,12 @@ static int greedy_impl(wh_task* t, const wh_greedy_params* p, int64_t* tokens, i
     sa.inv_temperature = 1.0f / p->temperature;
     sa.seed_lo = (uint32_t)(p->seed & 0xffffffffu); sa.seed_hi = (uint32_t)(p->seed >> 32);
   }
-
   sa.logits = t->logits + (size_t)(n_sel - 1) * V; sa.logits_ld = (int64_t)n_sel * V;
   HIPCHK(launch_greedy_sample(sa, s));
-  int ntok = T0 + 1, steps = 1, alive = T0;
   sa.logits = t->logits; sa.logits_ld = V;
-  bool done = false;
-  // Completion is polled every 8 tokens WITHOUT draining the queue: the counter is copied to pinned memory behind step
-  // k, an event is recorded, two more steps are queued, and only then does the host wait for the event — the GPU is
-  // two steps behind the host at that point and never idles for a launch.  At most two steps run past completion.
-  if (!t->poll_event) HIPCHK(hipEventCreateWithFlags(&t->poll_event, hipEventDisableTiming));
-  bool pending = false;
-  int ntok_at_copy = 0;
-  while (steps < p->max_steps && ntok <= p->n_ctx && ntok <= d.n_text_ctx) {
-    rc = step_run(t, s, fused_embed);
-    if (rc != WH_OK) return rc;
-    HIPCHK(launch_greedy_sample(sa, s));
-    ++ntok; ++steps;
-    if (pending && (steps & 7) == 2) {
-      HIPCHK(hipEventSynchronize(t->poll_event));
-      pending = false;
-      if (*t->h_poll < ntok_at_copy - 1) { done = true; break; }
-    }
-    if ((steps & 7) == 0) {
-      HIPCHK(hipMemcpyAsync(t->h_poll, t->d_alive, 4, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipEventRecord(t->poll_event, s));
-      pending = true; ntok_at_copy = ntok;
-    }
-  }
-  HIPCHK(hipMemcpyAsync(t->h_poll, t->d_alive, 4, hipMemcpyDeviceToHost, s));
-  int* h_err = t->h_poll + t->B + 8;                                               // pinned: past the per-segment flags
-  HIPCHK(hipMemcpyAsync(h_err, t->d_err, 4, hipMemcpyDeviceToHost, s));            // fused launches: hand-off timeouts
-  HIPCHK(hipStreamSynchronize(s));
-  if ((t->fused_xattn || t->fused_sattn) && *h_err != *h_err0) return WH_ERR_HANDOFF;
-  alive = *t->h_poll;
-  (void)done;
-  // the sampler that appended token index c ran with ntok == c; "completed" first holds at c = alive + 1
-  int final_len = alive + 2;
-  if (final_len > ntok) final_len = ntok;
-  *n_tokens_out = final_len;
+  L->ntok = T0 + 1; L->steps = 1;
+  L->pending = L->wait_due = false; L->ntok_at_copy = 0;
+  L->phase = PH_STEPPING;
   return WH_OK;
 }
 
@@ -1122,34 +1133,178 @@ static int replicate_leader_rows(wh_task* t, int T0, float* logits, int n_sel, h
   return WH_OK;
 }
 
-// ---- fused beam search loop --------------------------------------------------------------------------
-static int beam_impl(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int64_t token_stride, int sot_index,
-                     int no_speech_token, float* sum_logprobs, float* no_speech_probs, int64_t* fin_tokens,
-                     int32_t* fin_len, float* fin_scores, int32_t* fin_count, int32_t* n_tokens_out, void* stream_);
-extern "C" int wh_task_beam(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int64_t token_stride, int sot_index,
-                            int no_speech_token, float* sum_logprobs, float* no_speech_probs, int64_t* fin_tokens,
-                            int32_t* fin_len, float* fin_scores, int32_t* fin_count, int32_t* n_tokens_out,
-                            void* stream_) {
-  TASK_ENTER(t);
-  int rc = beam_impl(t, bp, tokens, token_stride, sot_index, no_speech_token, sum_logprobs, no_speech_probs, fin_tokens,
-                     fin_len, fin_scores, fin_count, n_tokens_out, stream_);
-  if (rc == WH_ERR_HANDOFF) {          // (fused step kernels run with <= 8 rows only: a beam task of 2 x 4 rows, say)
-    rc = handoff_fallback(t, (hipStream_t)stream_);
-    if (rc == WH_OK)
-      rc = beam_impl(t, bp, tokens, token_stride, sot_index, no_speech_token, sum_logprobs, no_speech_probs, fin_tokens,
-                     fin_len, fin_scores, fin_count, n_tokens_out, stream_);
-  }
-  return rc;
+// one BeamSearchDecoder.update on the device (3 launches) + rearrange_kv_cache (decoding.py:172-176): new beam i continues
+// the cache of row src[i]
+static int beam_update(wh_task* t, const float* logits, int64_t logits_ld, int first) {
+  wh_loop* L = t->loop;
+  const wh_dims& d = t->m->d;
+  const size_t es = t->m->esize;
+  const int R = t->R, B = t->B, G = t->G;
+  const int64_t row_bytes = (int64_t)d.n_text_ctx * d.n_text_state * es;
+  int64_t* buf[2] = {L->tokens, L->tokens + (int64_t)R * L->token_stride};
+  int* done[2] = {t->beam_flags, t->beam_flags + B};
+  BeamArgs& a = L->ba;
+  a.logits = logits; a.logits_ld = logits_ld; a.first = first;
+  a.tokens_in = buf[L->cur]; a.tokens_out = buf[L->cur ^ 1];
+  a.done_prev = done[L->cur]; a.done_next = done[L->cur ^ 1];
+  HIPCHK(launch_beam_step(a, B, L->s));
+  L->cur ^= 1;
+  HIPCHK(launch_permute_groups(t->self_k, t->self_v, d.n_text_layer, (int64_t)R * row_bytes, B, G, row_bytes,
+                               (int64_t)t->pos * d.n_text_state * es, t->d_src, a.copy_from,
+                               (int64_t)d.n_text_state * es, L->s));
+  return WH_OK;
 }
-static int beam_impl(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int64_t token_stride, int sot_index,
-                     int no_speech_token, float* sum_logprobs, float* no_speech_probs, int64_t* fin_tokens,
-                     int32_t* fin_len, float* fin_scores, int32_t* fin_count, int32_t* n_tokens_out, void* stream_) {
-  if (!t || !bp || !tokens || !sum_logprobs || !fin_tokens || !fin_len || !fin_scores || !fin_count || !n_tokens_out)
-    return WH_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream_;
-  const wh_greedy_params* p = &bp->rules;
+
+static int beam_start(wh_task* t) {
+  wh_loop* L = t->loop;
+  hipStream_t s = L->s;
+  const wh_greedy_params* p = &L->bp.rules;
   const wh_dims& d = t->m->d;
   const int V = d.n_vocab, R = t->R, B = t->B, G = t->G, T0 = p->sample_begin;
+  int* hp = t->h_poll + B;
+  HIPCHK(hipMemcpyAsync(hp + HP_ERR0, t->d_err, 4, hipMemcpyDeviceToHost, s));      // time-out counter at call entry (see greedy_start)
+
+  int32_t sel[2]; int n_sel;
+  const bool want_ns = L->no_speech_token >= 0 && L->no_speech_probs != nullptr;
+  if (want_ns && L->sot_index != T0 - 1) { sel[0] = L->sot_index; sel[1] = T0 - 1; n_sel = 2; }
+  else { sel[0] = T0 - 1; n_sel = 1; }
+  // the G beams of a segment hold the same prompt: one row per segment through the decoder, then replicate (A/B:
+  // WH_BEAM_FULL_PREFILL=1 feeds all R rows as the reference does)
+  const bool leaders = !WH_DEV_FLAG("WH_BEAM_FULL_PREFILL");
+  int rc = prefill_impl(t, L->tokens, L->token_stride, T0, sel, n_sel, t->logits, V, s, leaders);
+  if (rc != WH_OK) return rc;
+  if (leaders) { rc = replicate_leader_rows(t, T0, t->logits, n_sel, s); if (rc != WH_OK) return rc; }
+  if (want_ns) HIPCHK(launch_no_speech(t->logits, (int64_t)n_sel * V, R, V, L->no_speech_token, L->no_speech_probs, s));
+  HIPCHK(hipMemsetAsync(L->sum_logprobs, 0, (size_t)R * 4, s));
+  HIPCHK(hipMemsetAsync(L->fin_count, 0, (size_t)B * 4, s));
+  HIPCHK(hipMemsetAsync(t->beam_flags, 0, (2 * (size_t)B + 1) * 4, s));
+
+  BeamArgs& a = L->ba; memset(&a, 0, sizeof(a));
+  a.R = R; a.V = V; a.G = G; a.K = G + 1; a.token_stride = L->token_stride; a.d_ntok = t->d_pos; a.lag = t->d_lag;
+  a.sample_begin = T0; a.eot = p->eot; a.timestamp_begin = p->timestamp_begin; a.no_timestamps = p->no_timestamps;
+  a.max_initial_ts = p->max_initial_timestamp_index; a.suppress_blank = p->suppress_blank;
+  a.blank_token = p->blank_token; a.suppress_mask = p->suppress_mask; a.sum_logprobs = L->sum_logprobs;
+  beam_scratch_carve(a, t->beam_scratch, R, V);
+  a.fin_tok = L->fin_tokens; a.fin_len = L->fin_len; a.fin_score = L->fin_scores; a.fin_count = L->fin_count;
+  a.max_candidates = L->bp.max_candidates;
+  a.src = t->d_src; a.step_tokens = t->step_tokens; a.d_applied = t->beam_flags + 2 * B;
+  // shared-history bookkeeping for the cache permutation (beams that descend from one ancestor hold the same K/V up to
+  // the point where they split: those positions are never copied).  "Everything so far" to start with: all beams of a
+  // segment hold the same prompt.  Not used with ragged prompts (positions are row-local there).
+  const bool lcp_on = !WH_DEV_FLAG("WH_BEAM_FULL_PERMUTE");   // developer A/B switch
+  if (lcp_on && !t->lag_on) {
+    a.lcp = t->beam_lcp; a.copy_from = t->beam_lcp + (size_t)B * 64;
+    HIPCHK(hipMemsetAsync(t->beam_lcp, 0x7f, (size_t)B * 64 * 4, s));
+  }
+  L->cur = 0;
+  rc = beam_update(t, t->logits + (size_t)(n_sel - 1) * V, (int64_t)n_sel * V, 1);
+  if (rc != WH_OK) return rc;
+  L->ntok = T0 + 1; L->steps = 1;
+  L->pending = L->wait_due = false;
+  L->phase = PH_STEPPING;
+  return WH_OK;
+}
+
+// Queue what can be queued and report: WH_OK = the loop has ended and its results are in place (L->n_tokens), WH_RUNNING
+// = call again (never returned with block), anything else = error (the loop is abandoned).
+// Completion is polled every 8 tokens WITHOUT draining the queue: the counter (greedy: index of the last live token; beam:
+// the per-segment completion flags) is copied to pinned memory behind step k, an event is recorded, two more steps are
+// queued, and only then is the event waited for / asked about — the device is two steps behind the host at that point and
+// never idles for a launch.  At most two steps run past completion (they change nothing: finished rows keep emitting EOT
+// without accumulating, a beam update whose segments are all done leaves the state untouched).
+static int loop_pump(wh_task* t, bool block) {
+  wh_loop* L = t->loop;
+  hipStream_t s = L->s;
+  const wh_greedy_params* p = &L->bp.rules;
+  const wh_dims& d = t->m->d;
+  const int B = t->B;
+  int* hp = t->h_poll + B;
+  for (;;) {
+    if (L->phase == PH_STEPPING) {
+      bool finished = false;
+      for (;;) {
+        if (L->pending && L->wait_due) {
+          const int rc = event_reached(t->poll_event, block);
+          if (rc != WH_OK) return rc;
+          L->pending = L->wait_due = false;
+          if (t->loop_kind == LOOP_GREEDY) {
+            if (t->h_poll[0] < L->ntok_at_copy - 1) { finished = true; break; }
+          } else {
+            bool fin = true;
+            for (int b = 0; b < B; ++b) fin = fin && t->h_poll[b] != 0;
+            if (fin) { finished = true; break; }
+          }
+        }
+        if (!(L->steps < p->max_steps && L->ntok <= p->n_ctx && L->ntok <= d.n_text_ctx)) break;
+        int rc = step_run(t, s, t->loop_kind == LOOP_GREEDY && L->fused_embed);
+        if (rc != WH_OK) return rc;
+        if (t->loop_kind == LOOP_GREEDY) HIPCHK(launch_greedy_sample(L->sa, s));
+        else { rc = beam_update(t, t->logits, d.n_vocab, 0); if (rc != WH_OK) return rc; }
+        ++L->ntok; ++L->steps;
+        if (L->pending && (L->steps & 7) == 2) L->wait_due = true;
+        if ((L->steps & 7) == 0) {
+          if (t->loop_kind == LOOP_GREEDY) HIPCHK(hipMemcpyAsync(t->h_poll, t->d_alive, 4, hipMemcpyDeviceToHost, s));
+          else HIPCHK(hipMemcpyAsync(t->h_poll, (L->cur ? t->beam_flags + B : t->beam_flags), (size_t)B * 4, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipEventRecord(t->poll_event, s));
+          L->pending = true; L->wait_due = false; L->ntok_at_copy = L->ntok;
+        }
+      }
+      (void)finished;
+      // the loop's results, behind everything queued so far
+      if (t->loop_kind == LOOP_GREEDY) {
+        HIPCHK(hipMemcpyAsync(hp + HP_ALIVE, t->d_alive, 4, hipMemcpyDeviceToHost, s));
+      } else {
+        HIPCHK(hipMemcpyAsync(hp + HP_APPLIED, t->beam_flags + 2 * B, 4, hipMemcpyDeviceToHost, s));
+        if (L->cur == 1)
+          HIPCHK(hipMemcpyAsync(L->tokens, L->tokens + (int64_t)t->R * L->token_stride, (size_t)t->R * L->token_stride * 8,
+                                hipMemcpyDeviceToDevice, s));
+      }
+      HIPCHK(hipMemcpyAsync(hp + HP_ERR, t->d_err, 4, hipMemcpyDeviceToHost, s));       // fused launches: hand-off time-outs
+      HIPCHK(hipEventRecord(t->done_event, s));
+      L->phase = PH_DRAINING;
+    }
+    {
+      const int rc = event_reached(t->done_event, block);
+      if (rc != WH_OK) return rc;
+    }
+    if ((t->fused_xattn || t->fused_sattn) && hp[HP_ERR] != hp[HP_ERR0]) {
+      // a hand-off spin ran out: once more from the prompt, on the two-launch kernels
+      int rc = handoff_fallback(t, s);
+      if (rc == WH_OK) rc = t->loop_kind == LOOP_GREEDY ? greedy_start(t) : beam_start(t);
+      if (rc != WH_OK) return rc;
+      continue;
+    }
+    if (t->loop_kind == LOOP_GREEDY) {
+      // the sampler that appended token index c ran with ntok == c; "completed" first holds at c = alive + 1
+      int final_len = hp[HP_ALIVE] + 2;
+      if (final_len > L->ntok) final_len = L->ntok;
+      L->n_tokens = final_len;
+    } else {
+      L->n_tokens = p->sample_begin + hp[HP_APPLIED];
+    }
+    return WH_OK;
+  }
+}
+
+static int greedy_check(const wh_task* t, const wh_greedy_params* p, const int64_t* tokens, int64_t token_stride,
+                        const float* sum_logprobs) {
+  if (!t || !p || !tokens || !sum_logprobs) return WH_ERR_ARG;
+  const wh_dims& d = t->m->d;
+  const int T0 = p->sample_begin;
+  if (t->pos != 0 || T0 <= 0 || T0 > t->Tmax || p->max_steps <= 0) return WH_ERR_ARG;
+  if (token_stride < (int64_t)T0 + p->max_steps) return WH_ERR_ARG;
+  // ragged rows share one step counter: no row may reach the context limit before the step budget runs out
+  if (t->lag_on && (T0 + p->max_steps > p->n_ctx || T0 + p->max_steps > d.n_text_ctx)) return WH_ERR_ARG;
+  return WH_OK;
+}
+
+static int beam_check(const wh_task* t, const wh_beam_params* bp, const int64_t* tokens, int64_t token_stride,
+                      const float* sum_logprobs, const int64_t* fin_tokens, const int32_t* fin_len, const float* fin_scores,
+                      const int32_t* fin_count) {
+  if (!t || !bp || !tokens || !sum_logprobs || !fin_tokens || !fin_len || !fin_scores || !fin_count) return WH_ERR_ARG;
+  const wh_greedy_params* p = &bp->rules;
+  const wh_dims& d = t->m->d;
+  const int R = t->R, G = t->G, T0 = p->sample_begin;
   if (G < 2 || G > 8 || bp->beam_size != G || bp->max_candidates < 1 || !t->beam_scratch) return WH_ERR_ARG;
   if (t->pos != 0 || T0 <= 0 || T0 > t->Tmax || p->max_steps <= 0) return WH_ERR_ARG;
   if (token_stride < (int64_t)T0 + p->max_steps + 1) return WH_ERR_ARG;
@@ -1159,98 +1314,90 @@ static int beam_impl(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int6
     if (T0 + p->max_steps > p->n_ctx || T0 + p->max_steps > d.n_text_ctx) return WH_ERR_ARG;
     for (int r = 0; r < R; ++r) if (t->h_lag[r] != t->h_lag[r / G * G]) return WH_ERR_ARG;
   }
-
-  if (!t->h_poll) HIPCHK(hipHostMalloc((void**)&t->h_poll, ((size_t)t->B + 16) * 4, hipHostMallocDefault));
-  int* h_err0 = t->h_poll + t->B + 9;                    // time-out counter at call entry (see greedy_impl)
-  HIPCHK(hipMemcpyAsync(h_err0, t->d_err, 4, hipMemcpyDeviceToHost, s));
-
-  int32_t sel[2]; int n_sel;
-  const bool want_ns = no_speech_token >= 0 && no_speech_probs != nullptr;
-  if (want_ns && sot_index != T0 - 1) { sel[0] = sot_index; sel[1] = T0 - 1; n_sel = 2; }
-  else { sel[0] = T0 - 1; n_sel = 1; }
-  // the G beams of a segment hold the same prompt: one row per segment through the decoder, then replicate (A/B:
-  // WH_BEAM_FULL_PREFILL=1 feeds all R rows as the reference does)
-  const bool leaders = !WH_DEV_FLAG("WH_BEAM_FULL_PREFILL");
-  int rc = prefill_impl(t, tokens, token_stride, T0, sel, n_sel, t->logits, V, s, leaders);
-  if (rc != WH_OK) return rc;
-  if (leaders) { rc = replicate_leader_rows(t, T0, t->logits, n_sel, s); if (rc != WH_OK) return rc; }
-  if (want_ns) HIPCHK(launch_no_speech(t->logits, (int64_t)n_sel * V, R, V, no_speech_token, no_speech_probs, s));
-  HIPCHK(hipMemsetAsync(sum_logprobs, 0, (size_t)R * 4, s));
-  HIPCHK(hipMemsetAsync(fin_count, 0, (size_t)B * 4, s));
-  HIPCHK(hipMemsetAsync(t->beam_flags, 0, (2 * (size_t)B + 1) * 4, s));
-
-  int64_t* buf[2] = {tokens, tokens + (int64_t)R * token_stride};
-  int* done[2] = {t->beam_flags, t->beam_flags + B};
-  int* d_applied = t->beam_flags + 2 * B;
-  BeamArgs a; memset(&a, 0, sizeof(a));
-  a.R = R; a.V = V; a.G = G; a.K = G + 1; a.token_stride = token_stride; a.d_ntok = t->d_pos; a.lag = t->d_lag;
-  a.sample_begin = T0; a.eot = p->eot; a.timestamp_begin = p->timestamp_begin; a.no_timestamps = p->no_timestamps;
-  a.max_initial_ts = p->max_initial_timestamp_index; a.suppress_blank = p->suppress_blank;
-  a.blank_token = p->blank_token; a.suppress_mask = p->suppress_mask; a.sum_logprobs = sum_logprobs;
-  beam_scratch_carve(a, t->beam_scratch, R, V);
-  a.fin_tok = fin_tokens; a.fin_len = fin_len; a.fin_score = fin_scores; a.fin_count = fin_count;
-  a.max_candidates = bp->max_candidates;
-  a.src = t->d_src; a.step_tokens = t->step_tokens; a.d_applied = d_applied;
-  // shared-history bookkeeping for the cache permutation (beams that descend from one ancestor hold the same K/V up to
-  // the point where they split: those positions are never copied).  "Everything so far" to start with: all beams of a
-  // segment hold the same prompt.  Not used with ragged prompts (positions are row-local there).
-  const bool lcp_on = !WH_DEV_FLAG("WH_BEAM_FULL_PERMUTE");   // developer A/B switch
-  if (lcp_on && !t->lag_on) {
-    a.lcp = t->beam_lcp; a.copy_from = t->beam_lcp + (size_t)B * 64;
-    HIPCHK(hipMemsetAsync(t->beam_lcp, 0x7f, (size_t)B * 64 * 4, s));
-  }
-
-  const size_t es = t->m->esize;
-  const int64_t row_bytes = (int64_t)d.n_text_ctx * d.n_text_state * es;
-  int cur = 0;
-  auto update = [&](const float* logits, int64_t logits_ld, int first) -> int {
-    a.logits = logits; a.logits_ld = logits_ld; a.first = first;
-    a.tokens_in = buf[cur]; a.tokens_out = buf[cur ^ 1];
-    a.done_prev = done[cur]; a.done_next = done[cur ^ 1];
-    HIPCHK(launch_beam_step(a, B, s));
-    cur ^= 1;
-    // rearrange_kv_cache (decoding.py:172-176): new beam i continues the cache of row src[i]
-    HIPCHK(launch_permute_groups(t->self_k, t->self_v, d.n_text_layer, (int64_t)R * row_bytes, B, G, row_bytes,
-                                 (int64_t)t->pos * d.n_text_state * es, t->d_src, a.copy_from,
-                                 (int64_t)d.n_text_state * es, s));
-    return WH_OK;
-  };
-
-  rc = update(t->logits + (size_t)(n_sel - 1) * V, (int64_t)n_sel * V, 1);
-  if (rc != WH_OK) return rc;
-  int ntok = T0 + 1, steps = 1;
-  // completion flags are polled every 8 steps without draining the queue (see wh_task_greedy): snapshot behind step k,
-  // wait for it two steps later.  Once every segment is done an update leaves the state untouched, so the extra steps
-  // change nothing.
-  if (!t->poll_event) HIPCHK(hipEventCreateWithFlags(&t->poll_event, hipEventDisableTiming));
-  bool pending = false;
-  while (steps < p->max_steps && ntok <= p->n_ctx && ntok <= d.n_text_ctx) {
-    rc = step_run(t, s);
-    if (rc != WH_OK) return rc;
-    rc = update(t->logits, V, 0);
-    if (rc != WH_OK) return rc;
-    ++ntok; ++steps;
-    if (pending && (steps & 7) == 2) {
-      HIPCHK(hipEventSynchronize(t->poll_event));
-      pending = false;
-      bool fin = true;
-      for (int b = 0; b < B; ++b) fin = fin && t->h_poll[b] != 0;
-      if (fin) break;
-    }
-    if ((steps & 7) == 0) {
-      HIPCHK(hipMemcpyAsync(t->h_poll, done[cur], (size_t)B * 4, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipEventRecord(t->poll_event, s));
-      pending = true;
-    }
-  }
-  int applied = 0, err_now = 0;
-  HIPCHK(hipMemcpyAsync(&applied, d_applied, 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(&err_now, t->d_err, 4, hipMemcpyDeviceToHost, s));
-  if (cur == 1) HIPCHK(hipMemcpyAsync(buf[0], buf[1], (size_t)R * token_stride * 8, hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipStreamSynchronize(s));
-  if ((t->fused_xattn || t->fused_sattn) && err_now != *h_err0) return WH_ERR_HANDOFF;
-  *n_tokens_out = T0 + applied;
   return WH_OK;
+}
+
+static int loop_begin(wh_task* t, int kind, const wh_beam_params* bp, int64_t* tokens, int64_t token_stride, int sot_index,
+                      int no_speech_token, float* sum_logprobs, float* no_speech_probs, int64_t* fin_tokens,
+                      int32_t* fin_len, float* fin_scores, int32_t* fin_count, void* stream_) {
+  int rc = loop_resources(t);
+  if (rc != WH_OK) return rc;
+  wh_loop* L = t->loop;
+  memset((void*)L, 0, sizeof(*L));
+  L->s = (hipStream_t)stream_;
+  L->bp = *bp;
+  L->tokens = tokens; L->token_stride = token_stride; L->sot_index = sot_index; L->no_speech_token = no_speech_token;
+  L->sum_logprobs = sum_logprobs; L->no_speech_probs = no_speech_probs;
+  L->fin_tokens = fin_tokens; L->fin_len = fin_len; L->fin_scores = fin_scores; L->fin_count = fin_count;
+  t->loop_kind = kind;
+  rc = kind == LOOP_GREEDY ? greedy_start(t) : beam_start(t);
+  if (rc != WH_OK) t->loop_kind = LOOP_IDLE;
+  return rc;
+}
+
+extern "C" int wh_task_greedy_begin(wh_task* t, const wh_greedy_params* p, int64_t* tokens, int64_t token_stride,
+                                    int sot_index, int no_speech_token, float* sum_logprobs, float* no_speech_probs,
+                                    void* stream_) {
+  TASK_ENTER(t);
+  int rc = greedy_check(t, p, tokens, token_stride, sum_logprobs);
+  if (rc != WH_OK) return rc;
+  wh_beam_params bp; memset(&bp, 0, sizeof(bp)); bp.rules = *p;
+  return loop_begin(t, LOOP_GREEDY, &bp, tokens, token_stride, sot_index, no_speech_token, sum_logprobs, no_speech_probs,
+                    nullptr, nullptr, nullptr, nullptr, stream_);
+}
+
+extern "C" int wh_task_beam_begin(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int64_t token_stride, int sot_index,
+                                  int no_speech_token, float* sum_logprobs, float* no_speech_probs, int64_t* fin_tokens,
+                                  int32_t* fin_len, float* fin_scores, int32_t* fin_count, void* stream_) {
+  TASK_ENTER(t);
+  int rc = beam_check(t, bp, tokens, token_stride, sum_logprobs, fin_tokens, fin_len, fin_scores, fin_count);
+  if (rc != WH_OK) return rc;
+  return loop_begin(t, LOOP_BEAM, bp, tokens, token_stride, sot_index, no_speech_token, sum_logprobs, no_speech_probs,
+                    fin_tokens, fin_len, fin_scores, fin_count, stream_);
+}
+
+extern "C" int wh_task_poll(wh_task* t, int32_t* n_tokens_out) {
+  if (!t) return WH_ERR_ARG;
+  TaskGuard guard(t, /*loop_call=*/true);
+  if (!guard.ok) return WH_ERR_STATE;
+  if (!t->loop || t->loop_kind == LOOP_IDLE) return WH_ERR_STATE;
+  const int rc = loop_pump(t, false);
+  if (rc == WH_RUNNING) return rc;
+  if (rc == WH_OK && n_tokens_out) *n_tokens_out = t->loop->n_tokens;
+  t->loop_kind = LOOP_IDLE;                       // ended (or failed): the task takes other calls again
+  return rc;
+}
+
+extern "C" int wh_task_greedy(wh_task* t, const wh_greedy_params* p, int64_t* tokens, int64_t token_stride,
+                              int sot_index, int no_speech_token, float* sum_logprobs, float* no_speech_probs,
+                              int32_t* n_tokens_out, void* stream_) {
+  TASK_ENTER(t);
+  if (!n_tokens_out) return WH_ERR_ARG;
+  int rc = greedy_check(t, p, tokens, token_stride, sum_logprobs);
+  if (rc != WH_OK) return rc;
+  wh_beam_params bp; memset(&bp, 0, sizeof(bp)); bp.rules = *p;
+  rc = loop_begin(t, LOOP_GREEDY, &bp, tokens, token_stride, sot_index, no_speech_token, sum_logprobs, no_speech_probs,
+                  nullptr, nullptr, nullptr, nullptr, stream_);
+  if (rc == WH_OK) rc = loop_pump(t, true);
+  if (rc == WH_OK) *n_tokens_out = t->loop->n_tokens;
+  if (t->loop) t->loop_kind = LOOP_IDLE;
+  return rc;
+}
+
+extern "C" int wh_task_beam(wh_task* t, const wh_beam_params* bp, int64_t* tokens, int64_t token_stride, int sot_index,
+                            int no_speech_token, float* sum_logprobs, float* no_speech_probs, int64_t* fin_tokens,
+                            int32_t* fin_len, float* fin_scores, int32_t* fin_count, int32_t* n_tokens_out,
+                            void* stream_) {
+  TASK_ENTER(t);
+  if (!n_tokens_out) return WH_ERR_ARG;
+  int rc = beam_check(t, bp, tokens, token_stride, sum_logprobs, fin_tokens, fin_len, fin_scores, fin_count);
+  if (rc != WH_OK) return rc;
+  rc = loop_begin(t, LOOP_BEAM, bp, tokens, token_stride, sot_index, no_speech_token, sum_logprobs, no_speech_probs,
+                  fin_tokens, fin_len, fin_scores, fin_count, stream_);
+  if (rc == WH_OK) rc = loop_pump(t, true);
+  if (rc == WH_OK) *n_tokens_out = t->loop->n_tokens;
+  if (t->loop) t->loop_kind = LOOP_IDLE;
+  return rc;
 }
 
 // ---- measurement hook ----------------------------------------------------------------------------------

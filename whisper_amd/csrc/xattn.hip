@@ -50,11 +50,14 @@ namespace {
 
 typedef unsigned long long u64;
 constexpr float XSCALE = 0.125f;      // d_head^-0.5 for d_head = 64
-// Bound of every hand-off spin (one poll is 0.3 - 1 us: 20 - 65 ms in all).  8192 until round 5: enough for a chain that has the chip
-// to itself and for the GEMM side-stream of the contention test, but with three decode chains AND the encoder's stream on the GPU's
-// four hardware queues a producer workgroup was now and then dispatched milliseconds late (36 - 42 time-outs in 3 of ~25 runs; the task
-// then finishes on the two-launch kernels — correct, slower).  A time-out is a safety net against a hang, not a scheduling tool.
-constexpr int X_MAX_SPINS = 1 << 16;
+// Bound of every hand-off spin (one poll is 0.3 - 1 us: 2.5 - 8 ms in all).  A hang guard, not a scheduling tool: producers never
+// wait, so a consumer only ever waits for a producer workgroup of its own launch to be DISPATCHED, which on a chip that is not held
+// by something else for milliseconds takes microseconds.  (Round 5 ran 65 536 for a while: with three decode chains of fused self-
+// AND cross-attention launches plus the encoder's stream on the GPU's four hardware queues, 8192 polls ran out in 3 of ~25 fresh
+// processes.  Since round 6 the self attention of the default step is two plain launches and the headline is one wide chain, so the
+// only spinning kernel left on the default path is xattn8_kernel of <= 8-row tasks; profiles/r06_lanes.txt counts its time-outs over
+// 25 fresh processes with three such chains in flight.)  When a spin does run out the loop is re-run on the two-launch kernels (api.cpp).
+constexpr int X_MAX_SPINS = 1 << 13;
 
 __device__ __forceinline__ float qk_unit8(half8v q, half8v k) {
   float d = __builtin_amdgcn_fdot2(half2v{q[0], q[1]}, half2v{k[0], k[1]}, 0.f, false);

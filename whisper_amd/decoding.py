@@ -33,6 +33,33 @@ from .utils import compression_ratio
 if TYPE_CHECKING:
     from .model import Whisper
 
+import threading
+
+# the generator the calling thread's sampling seeds are drawn from: None = torch's process-wide CPU generator (so that
+# torch.manual_seed makes a run repeatable, as in the reference); `run_in_lanes` / `run_interleaved` give every JOB a generator of
+# its own, seeded on the caller's thread from the process-wide one plus the job's index — several lanes must not race for draws
+_SEEDS = threading.local()
+
+
+def _draw_seed() -> int:
+    gen = getattr(_SEEDS, "gen", None)
+    return int(torch.randint(0, 2 ** 62, (1,), generator=gen).item())
+
+
+def _job_generator(base: int, index: int) -> torch.Generator:
+    return torch.Generator().manual_seed((base + 0x9E3779B97F4A7C15 * (index + 1)) % (2 ** 63))
+
+
+@contextlib.contextmanager
+def _job_seeds(gen: torch.Generator):
+    """seeds drawn by the calling thread inside the block come from `gen` (one generator per job, kept across resumes)"""
+    prev = getattr(_SEEDS, "gen", None)
+    _SEEDS.gen = gen
+    try:
+        yield
+    finally:
+        _SEEDS.gen = prev
+
 
 # ---------------------------------------------------------------------------------------------------------------
 # language identification (reference decoding.py:18-77)
@@ -235,6 +262,10 @@ class GreedyDecoder(TokenDecoder):
         self.temperature = temperature
         self.eot = eot
         self._buf: Optional[Tensor] = None
+        # True only while DecodingTask._host_loop drives this decoder: it hands every returned `tokens` straight back, so the new
+        # column can be written in place.  Any other caller gets the reference's semantics — a fresh tensor per update
+        # (torch.cat, decoding.py:290) that never aliases an earlier result.
+        self._in_place = False
 
     def reset(self):
         self._buf = None
@@ -244,6 +275,8 @@ class GreedyDecoder(TokenDecoder):
         the sequences live in a buffer with spare columns; as long as the caller hands back the view this method returned,
         the new column is written in place and a one-column-wider view of the same storage goes out.  Any other `tokens`
         (first call, a caller that built its own tensor) is copied into a fresh buffer — same values either way."""
+        if not self._in_place:
+            return torch.cat([tokens, picked[:, None]], dim=-1)
         n = tokens.shape[1]
         buf = self._buf
         if (buf is None or buf.shape[0] != tokens.shape[0] or buf.dtype != tokens.dtype or buf.device != tokens.device
@@ -604,10 +637,24 @@ class DecodingTask:
             suppress_mask=mask.data_ptr())
         if type(self.decoder) is GreedyDecoder and self.options.temperature > 0:
             params.temperature = float(self.options.temperature)
-            params.seed = int(torch.randint(0, 2 ** 62, (1,)).item())     # torch.manual_seed makes runs repeatable
+            params.seed = _draw_seed()                                    # torch.manual_seed makes runs repeatable
         return params, mask
 
-    def _main_loop_beam_fused(self, audio_features: Tensor, tokens: Tensor):
+    # The device-side loops are written as GENERATORS: with `wait` they make the blocking C call (wh_task_greedy / wh_task_beam)
+    # and never yield; without it they begin the loop (wh_task_*_begin), then yield while `wh_task_poll` says it is still running —
+    # the caller (`run_interleaved`) resumes other tasks' generators meanwhile, all from one host thread.
+    def _await(self, pend: "hip.PendingLoop"):
+        try:
+            while True:
+                res = pend.poll()
+                if res is not None:
+                    return res
+                yield
+        except GeneratorExit:            # abandoned mid-loop: the task must not go back to the cache with a loop running
+            pend.wait()
+            raise
+
+    def _main_loop_beam_fused(self, audio_features: Tensor, tokens: Tensor, wait: bool = True):
         """BeamSearchDecoder.update for every step on the device; leaves the decoder's finished_sequences as the
         host loop would (same dict order) for finalize()"""
         tk = self.tokenizer
@@ -624,7 +671,11 @@ class DecodingTask:
             row_lag = [lag for lag in self.row_lag for _ in range(self.n_group)] if ragged else None
             if ragged:
                 task.set_lag(row_lag)
-            n, sum_logprobs, nsp, (fin_tok, fin_len, fin_score, fin_count) = task.beam(buf, params, self.sot_index, no_speech)
+            if wait:
+                res = task.beam(buf, params, self.sot_index, no_speech)
+            else:
+                res = yield from self._await(task.beam_begin(buf, params, self.sot_index, no_speech))
+            n, sum_logprobs, nsp, (fin_tok, fin_len, fin_score, fin_count) = res
             no_speech_probs = nsp.tolist() if nsp is not None else [np.nan] * n_rows
             fin_tok, fin_len, fin_score, fin_count = fin_tok.cpu(), fin_len.tolist(), fin_score.tolist(), fin_count.tolist()
             # rows with a shorter prompt hold fewer tokens: left-pad (as the greedy path does) so that every sequence's
@@ -642,7 +693,7 @@ class DecodingTask:
         finally:
             self.inference.cleanup_caching()
 
-    def _main_loop_fused(self, audio_features: Tensor, tokens: Tensor):
+    def _main_loop_fused(self, audio_features: Tensor, tokens: Tensor, wait: bool = True):
         tk = self.tokenizer
         dev = audio_features.device
         n_rows, T0 = tokens.shape
@@ -656,7 +707,11 @@ class DecodingTask:
             row_lag = [lag for lag in self.row_lag for _ in range(self.n_group)] if ragged else None
             if ragged:
                 task.set_lag(row_lag)
-            n, sum_logprobs, nsp = task.greedy(buf, params, self.sot_index, no_speech)
+            if wait:
+                res = task.greedy(buf, params, self.sot_index, no_speech)
+            else:
+                res = yield from self._await(task.greedy_begin(buf, params, self.sot_index, no_speech))
+            n, sum_logprobs, nsp = res
             no_speech_probs = nsp.tolist() if nsp is not None else [np.nan] * n_rows
             if not ragged:
                 return buf[:, :n], sum_logprobs, no_speech_probs
@@ -678,7 +733,8 @@ class DecodingTask:
         fused = self._fused_greedy_ok(None) or (type(self.decoder) is BeamSearchDecoder and self._beam_shape_ok())
         return self.n_ctx - self.sample_len if fused else None
 
-    def _main_loop(self, audio_features: Tensor, tokens: Tensor):
+    def _main_loop(self, audio_features: Tensor, tokens: Tensor, wait: bool = True):
+        """generator (see `_await`); returns (tokens, sum_logprobs, no_speech_probs)"""
         if self._ragged():
             limit = self.ragged_limit()
             if limit is None:
@@ -688,9 +744,9 @@ class DecodingTask:
                 raise ValueError(f"prompts of different lengths: the longest initial sequence ({self.sample_begin}) "
                                  f"+ sample_len ({self.sample_len}) exceeds n_text_ctx ({self.n_ctx})")
         if self._fused_greedy_ok(tokens):
-            return self._main_loop_fused(audio_features, tokens)
+            return (yield from self._main_loop_fused(audio_features, tokens, wait))
         if self._fused_beam_ok():
-            return self._main_loop_beam_fused(audio_features, tokens)
+            return (yield from self._main_loop_beam_fused(audio_features, tokens, wait))
         if type(self.inference) is not HipInference:
             return self._host_loop(audio_features, tokens)[:3]
         first = tokens.clone()
@@ -712,6 +768,9 @@ class DecodingTask:
         timed_out = False
         if type(self.inference) is HipInference:   # only two positions of the first pass are ever read
             self.inference.positions = sorted({self.sot_index, tokens.shape[1] - 1})
+        in_place = type(self.decoder) is GreedyDecoder
+        if in_place:
+            self.decoder._in_place = True           # this loop hands every returned `tokens` straight back (see _append)
         try:
             for i in range(self.sample_len):
                 logits = self.inference.logits(tokens, audio_features)
@@ -742,11 +801,25 @@ class DecodingTask:
             if type(self.inference) is HipInference and not timed_out:
                 timed_out = self.inference.handoff_timed_out()
         finally:
+            if in_place:
+                self.decoder._in_place = False
             self.inference.cleanup_caching()
         return tokens, sum_logprobs, no_speech_probs, timed_out
 
     @torch.no_grad()
     def run(self, mel: Tensor) -> List[DecodingResult]:
+        """decoding.py:713-789.  (`run_steps(mel, wait=False)` is the same as a generator that yields wherever this would
+        wait for a device-side loop: `run_interleaved` drives several of those from one thread.)"""
+        steps = self.run_steps(mel, wait=True)
+        try:
+            while True:
+                next(steps)                      # with wait=True nothing ever yields
+        except StopIteration as done:
+            return done.value
+
+    def run_steps(self, mel: Tensor, wait: bool = False):
+        """`run` as a generator (resume it under torch.no_grad(), as `run_interleaved` does: a grad-mode context must not be
+        held across a yield, several generators share the thread)"""
         self.decoder.reset()
         tokenizer: Tokenizer = self.tokenizer
         n_audio: int = mel.shape[0]
@@ -767,7 +840,7 @@ class DecodingTask:
 
         # one row per (audio, beam / sample); the kernels map row -> audio as row // n_group
         tokens = tokens.repeat_interleave(self.n_group, dim=0).to(audio_features.device)
-        tokens, sum_logprobs, no_speech_probs = self._main_loop(audio_features, tokens)
+        tokens, sum_logprobs, no_speech_probs = yield from self._main_loop(audio_features, tokens, wait)
 
         no_speech_probs = no_speech_probs[:: self.n_group]
         assert audio_features.shape[0] == len(no_speech_probs) == n_audio
@@ -815,14 +888,15 @@ def decode(model: "Whisper", mel: Tensor, options: DecodingOptions = DecodingOpt
 def run_in_lanes(model: "Whisper", jobs: Sequence, in_flight: int = 3, dtype: Optional[torch.dtype] = None) -> list:
     """Call every job — a zero-argument callable that drives this model (log-mel, encoder, a decode loop, ...) — with up to
     `in_flight` of them running at once, each on a host thread and a HIP stream of its own (`HipModel.lane`); results in job
-    order.  No counterpart in the reference.  Why it pays: one decode chain is ~190 dependent launches per token and leaves the
-    chip idle between them, so independent chains fill each other's gaps (large-v3, 8 clips per job, greedy, 224 tokens: 692
-    audio-s/s one after the other, 917 / 1025 with 2 / 3 in flight, identical tokens).  Three is the useful maximum: the lanes'
-    streams and the engine's encoder stream then occupy the GPU's four hardware queues; with four lanes the streams share queues,
-    throughput drops (953 audio-s/s) and the fused step kernels' bounded hand-off spins start to run out (36 time-outs in one run —
-    the affected task then finishes on its two-launch kernels, results unchanged).  Jobs must be independent of each other;
-    an exception in a job is re-raised here after the others have finished."""
-    import threading
+    order.  No counterpart in the reference.  Why it pays: a decode chain of few rows is ~190 dependent launches per token and
+    leaves the chip idle between them, so independent chains fill each other's gaps (large-v3, 8 clips per job, greedy, 224
+    tokens: 692 audio-s/s one after the other, 917 / 1025 with 2 / 3 in flight, identical tokens; base x 1 clip: 564 -> 1330).
+    Three is the useful maximum: the lanes' streams and the engine's encoder stream then occupy the GPU's four hardware queues.
+    The threads SLEEP while their loop runs on the device (the library waits on blocking events), so a lane costs no host core;
+    `run_interleaved` / `decode_many` need no threads at all.  When there are enough clips, WIDER chains beat more chains:
+    `decode_many(chain_rows=24)`.  Jobs must be independent of each other; sampling seeds (temperature > 0) are a function of
+    torch's generator state at the call and the job's INDEX, not of which lane runs it when.  An exception in a job — or in a
+    lane's own set-up — is re-raised here after the other lanes have stopped; every job either has its result or the call raises."""
     jobs = list(jobs)
     n = max(1, min(int(in_flight), len(jobs)))
     if n <= 1:
@@ -830,26 +904,28 @@ def run_in_lanes(model: "Whisper", jobs: Sequence, in_flight: int = 3, dtype: Op
     # the engine is built here, once, before the threads start (packing weights is not something to race on)
     engine = model.engine(dtype if dtype is not None else torch.float16)
     caller = torch.cuda.current_stream(engine.device)        # what the jobs' inputs were produced on
-    results, errors, streams = [None] * len(jobs), [], []
+    base = _draw_seed()                                       # ONE draw on the caller's thread; job i derives its own from (base, i)
+    missing = object()
+    results, errors, streams = [missing] * len(jobs), [], []
     nxt = [0]
     lock = threading.Lock()
 
     def worker():
-        with engine.lane() as st:
-            st.wait_stream(caller)
-            with lock:
-                streams.append(st)
-            while True:
+        try:
+            with engine.lane() as st:
+                st.wait_stream(caller)
                 with lock:
-                    i = nxt[0]
-                    nxt[0] += 1
-                if i >= len(jobs) or errors:
-                    return
-                try:
-                    results[i] = jobs[i]()
-                except BaseException as e:      # noqa: BLE001 — handed to the caller's thread
-                    errors.append(e)
-                    return
+                    streams.append(st)
+                while True:
+                    with lock:
+                        i = nxt[0]
+                        nxt[0] += 1
+                    if i >= len(jobs) or errors:
+                        return
+                    with _job_seeds(_job_generator(base, i)):
+                        results[i] = jobs[i]()
+        except BaseException as e:      # noqa: BLE001 — a job's or the lane's own (stream creation, out of memory): to the caller's thread
+            errors.append(e)
     threads = [threading.Thread(target=worker, name=f"whisper-lane-{k}") for k in range(n)]
     for t in threads:
         t.start()
@@ -859,25 +935,123 @@ def run_in_lanes(model: "Whisper", jobs: Sequence, in_flight: int = 3, dtype: Op
         caller.wait_stream(st)
     if errors:
         raise errors[0]
+    if any(r is missing for r in results):
+        raise RuntimeError("run_in_lanes: a lane ended without running its jobs")
+    return results
+
+
+def run_interleaved(model: "Whisper", jobs: Sequence, in_flight: int = 3, dtype: Optional[torch.dtype] = None,
+                    sleep_s: float = 2e-4) -> list:
+    """`run_in_lanes` without threads: every job is a GENERATOR (e.g. `DecodingTask(...).run_steps(mel)`) that yields wherever it
+    would otherwise wait for a device-side loop; up to `in_flight` of them are kept going from THIS thread, each inside a lane
+    (HIP stream) of its own, by resuming them in turn — a resumed job asks its loop whether it has ended (`wh_task_poll`, which
+    also queues the next decode steps and never waits) and yields again.  Returns the generators' return values in job order.
+    The device sees the same streams and launches as with one host thread per lane; the host spends one thread, mostly asleep
+    (`sleep_s` between rounds in which nothing ended; a task has ~10 decode steps queued at any time, so 0.2 ms is early enough
+    even for the smallest model).  An exception in a job is re-raised here after the others have been closed (a job abandoned
+    mid-loop drains its loop first)."""
+    import time
+    jobs = list(jobs)
+    if not jobs:
+        return []
+    n = max(1, min(int(in_flight), len(jobs)))
+    engine = model.engine(dtype if dtype is not None else torch.float16)
+    caller = torch.cuda.current_stream(engine.device)
+    base = _draw_seed()
+    with engine._lock:
+        streams = [engine._lane_pool.pop() if engine._lane_pool else None for _ in range(n)]
+    streams = [st if st is not None else torch.cuda.Stream(device=engine.device) for st in streams]
+    results = [None] * len(jobs)
+    active: Dict[int, Tuple[int, object, torch.Generator]] = {}          # lane -> (job index, generator, its seed generator)
+    nxt, error = 0, None
+
+    def resume(lane: int) -> bool:
+        """one turn of the job in `lane`; True when it has ended"""
+        i, gen, seeds = active[lane]
+        with engine.lane(streams[lane]), torch.no_grad(), _job_seeds(seeds):
+            try:
+                next(gen)
+                return False
+            except StopIteration as done:
+                results[i] = done.value
+                return True
+    try:
+        while nxt < len(jobs) or active:
+            for lane in range(n):
+                if lane not in active and nxt < len(jobs):
+                    streams[lane].wait_stream(caller)
+                    active[lane] = (nxt, jobs[nxt], _job_generator(base, nxt))
+                    nxt += 1
+            ended = False
+            for lane in list(active):
+                if resume(lane):
+                    del active[lane]
+                    ended = True
+            if not ended and active:
+                time.sleep(sleep_s)
+    except BaseException as e:      # noqa: BLE001
+        error = e
+    finally:
+        for lane, (i, gen, _) in list(active.items()):
+            try:
+                with engine.lane(streams[lane]):
+                    gen.close()
+            except BaseException:   # noqa: BLE001 — the first error is the one reported
+                pass
+        for st in streams:
+            caller.wait_stream(st)
+        engine.adopt_lane_streams(streams)
+    if error is not None:
+        raise error
     return results
 
 
 def decode_many(model: "Whisper", mels: Sequence[Tensor], options: DecodingOptions = DecodingOptions(), in_flight: int = 3,
-                **kwargs) -> List[List[DecodingResult]]:
-    """`decode(model, mel, options)` for every batch of `mels` — each a (B, n_mels, 3000) tensor (or raw (B, 480000) audio when
-    it has two dimensions of that length: the log-mel then runs inside the lane too) — with up to `in_flight` batches decoding
-    at once (`run_in_lanes`).  Every batch is decoded exactly as `decode` decodes it alone (same kernels, same tokens); only the
-    scheduling differs.  Returns the per-batch result lists in order."""
+                chain_rows: Optional[int] = 24, **kwargs) -> List[List[DecodingResult]]:
+    """`decode(model, mel, options)` for every batch of `mels` — each a (B, n_mels, 3000) tensor, or raw (B, 480000) audio (its
+    log-mel is then taken here, per batch: audio.py:155 clamps against the maximum over the tensor it is given) — scheduled for
+    throughput; returns the per-batch result lists in order.  No counterpart in the reference.  Two levers:
+      * `chain_rows`: consecutive batches are COALESCED into one decode chain while its rows (clips x beams / samples) stay within
+        this bound — one task, one prompt pass, one decode step per token for all of them.  The decoder's weights are then
+        streamed once per step for up to 24 rows instead of once per batch (large-v3, three batches of 8 clips, greedy: 1.6 GB x 3
+        per step become 1.6 GB; 24 rows is where the row-tiled projection kernels of csrc/gemv.hip end).  Every clip's result is
+        what `decode` gives it in its own batch: exactly in the fp32 engine; in the fp16 engine up to the order of fp32 partial
+        sums (the number of cross-attention key splits depends on the row count), which can only move a decision that was a
+        tie to within rounding.  None / 0: every batch is its own chain.
+      * `in_flight`: up to this many chains are decoded at once, each on a HIP stream of its own, all driven from the calling
+        thread (`run_interleaved`): chains of few rows leave the chip idle between their dependent launches and fill each other's
+        gaps.  Chains of 16+ rows of a large model gain little from it."""
     if kwargs:
         options = replace(options, **kwargs)
     dtype = torch.float16 if options.fp16 else torch.float32
+    mels = list(mels)
+    group = options.beam_size or options.best_of or 1
 
-    def job(m):
-        def run():
-            x = m
+    def rows_of(m: Tensor) -> int:
+        return (m.shape[0] if m.dim() >= 2 else 1) * group
+
+    chains: List[List[int]] = []
+    for i, m in enumerate(mels):
+        if m.dim() < 2:
+            raise ValueError("decode_many takes batches: (B, n_mels, 3000) spectrograms or (B, 480000) audio")
+        if (chains and chain_rows and sum(rows_of(mels[j]) for j in chains[-1]) + rows_of(m) <= chain_rows):
+            chains[-1].append(i)
+        else:
+            chains.append([i])
+
+    def chain_steps(idx: List[int]):
+        parts = []
+        for i in idx:
+            x = mels[i]
             if x.dim() == 2 and x.shape[-1] == 480000:
                 from .audio import log_mel_spectrogram
                 x = log_mel_spectrogram(x, model.dims.n_mels)
-            return decode(model, x, options)
-        return run
-    return run_in_lanes(model, [job(m) for m in mels], in_flight, dtype)
+            parts.append(x.to(dtype))
+        res = yield from DecodingTask(model, options).run_steps(parts[0] if len(parts) == 1 else torch.cat(parts), wait=False)
+        out, at = [], 0
+        for p_ in parts:
+            out.append(res[at: at + p_.shape[0]])
+            at += p_.shape[0]
+        return out
+    done = run_interleaved(model, [chain_steps(c) for c in chains], in_flight, dtype)
+    return [r for chain in done for r in chain]

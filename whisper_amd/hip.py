@@ -25,6 +25,7 @@ WH_TASK_CAPTURE_Q = 1
 WH_TASK_TWO_LAUNCH_SELF = 2
 WH_TASK_TWO_LAUNCH_CROSS = 4
 WH_TASK_EXPIRE_HANDOFFS = 16        # fault injection (include/whisper_hip.h): every hand-off poll gives up at once
+WH_TASK_FUSED_SELF = 32             # opt-in: LN + QKV + cache append + self attention as one launch (sattn8_kernel)
 WH_WEIGHTS_DEC_LN_FOLDED = 1
 WH_WEIGHTS_ENC_QK_SCALED = 2
 # sqrt(0.125 * log2 e): with it in both the query and the key projection, K.Q^T is the exp2 argument of the softmax
@@ -107,6 +108,11 @@ SIGNATURES = {
     "wh_task_beam": (C.c_int, [C.c_void_p, C.POINTER(BeamParams), C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.POINTER(C.c_int32), C.c_void_p]),
+    "wh_task_greedy_begin": (C.c_int, [C.c_void_p, C.POINTER(GreedyParams), C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "wh_task_beam_begin": (C.c_int, [C.c_void_p, C.POINTER(BeamParams), C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "wh_task_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "wh_task_cross_qk": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "wh_task_bench_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_void_p]),
@@ -147,6 +153,7 @@ def lib():
 
 
 WH_ERR_HANDOFF = 6
+WH_RUNNING = 7                      # wh_task_poll: the loop begun with wh_task_*_begin has not ended yet
 
 
 def check(rc: int, what: str = "") -> None:
@@ -463,11 +470,6 @@ class HipModel:
             max_prefill = self.dims.n_text_ctx
         if stream is None:
             stream = self.task_stream()
-        # a task of a LANE (several chains share the chip) keeps its self attention as two launches: the fused launch
-        # (csrc/xattn.hip, 1024-thread workgroups whose consumers spin for their q / k / v) is the better form for a chain that
-        # has the chip to itself (r03) and the worse one beside other chains — 3 lanes: 1042 vs 1008 audio-s/s, same tokens
-        # (bit-identical forms), `bench.py --task-form`, profiles/r05_lanes.txt.  The cross attention stays fused in both.
-        in_lane = getattr(self._tls, "stream", None) is not None and stream is self._tls.stream
         key = (n_audio, n_group, max_prefill, capture_q, stream)
         task = None
         with self._lock:
@@ -478,7 +480,7 @@ class HipModel:
         if task is not None:
             task.reset()
             return task
-        task = HipTask(self, n_audio, n_group, max_prefill, capture_q=capture_q, stream=stream, two_launch_self=in_lane)
+        task = HipTask(self, n_audio, n_group, max_prefill, capture_q=capture_q, stream=stream)
         task._cached = True
         return task
 
@@ -566,15 +568,18 @@ class HipTask:
 
     def __init__(self, model: HipModel, n_audio: int, n_group: int, max_prefill: int, capture_q: bool = False,
                  stream: Optional[torch.cuda.Stream] = None, two_launch_self: bool = False, two_launch_cross: bool = False,
-                 expire_handoffs: bool = False, extra_flags: int = 0):
+                 expire_handoffs: bool = False, extra_flags: int = 0, fused_self: bool = False):
         self.model = model
         self.n_audio, self.n_group, self.n_rows = n_audio, n_group, n_audio * n_group
         self.max_prefill = max_prefill
         self.capture_q = capture_q
         flags = ((WH_TASK_CAPTURE_Q if capture_q else 0) | (WH_TASK_TWO_LAUNCH_SELF if two_launch_self else 0)
                  | (WH_TASK_TWO_LAUNCH_CROSS if two_launch_cross else 0)
-                 | (WH_TASK_EXPIRE_HANDOFFS if expire_handoffs else 0) | int(extra_flags) | int(model.debug_task_flags))
-        self.stream = stream if stream is not None else model.stream   # independent tasks may run on own streams
+                 | (WH_TASK_EXPIRE_HANDOFFS if expire_handoffs else 0) | (WH_TASK_FUSED_SELF if fused_self else 0)
+                 | int(extra_flags) | int(model.debug_task_flags))
+        # the calling thread's lane stream (`HipModel.lane`) when it has one, else the engine's: a task a lane creates for
+        # itself (e.g. HipInference's two-launch task after a hand-off time-out) must not land on the encoder's stream
+        self.stream = stream if stream is not None else model.task_stream()
         with torch.cuda.device(model.device):
             need = lib().wh_task_workspace_bytes(model.handle, n_audio, n_group, max_prefill, flags)
             if need == 0:
@@ -742,6 +747,47 @@ class HipTask:
                                      stream_ptr(self.stream)), "wh_task_beam")
         return n_out.value, sum_lp, nsp, (fin_tok, fin_len, fin_score, fin_count)
 
+    # -- the same loops without a blocked caller (wh_task_greedy_begin / wh_task_beam_begin + wh_task_poll) ----------------
+    def greedy_begin(self, tokens: torch.Tensor, params: GreedyParams, sot_index: int, no_speech_token: int) -> "PendingLoop":
+        """`greedy` split at the points where the host would wait: queues the prompt pass and the first decision and returns a
+        `PendingLoop`; call its `poll()` until it returns the result tuple of `greedy` (None while the loop runs).  Nothing
+        here waits for the device, so one host thread can keep several tasks on different streams going."""
+        assert tokens.is_cuda and tokens.dtype == torch.int64 and tokens.stride(1) == 1
+        dev = tokens.device
+        sum_lp = torch.empty(self.n_rows, dtype=torch.float32, device=dev)
+        nsp = torch.empty(self.n_rows, dtype=torch.float32, device=dev) if no_speech_token >= 0 else None
+        pend = PendingLoop(self, (tokens, params, sum_lp, nsp), lambda n: (n, sum_lp, nsp))
+        with torch.cuda.device(self.model.device):
+            pend.caller = torch.cuda.current_stream(self.model.device)
+            self.stream.wait_stream(pend.caller)
+            check(lib().wh_task_greedy_begin(self.handle, C.byref(params), tokens.data_ptr(), tokens.stride(0), sot_index,
+                                             no_speech_token, sum_lp.data_ptr(), _ptr(nsp), stream_ptr(self.stream)),
+                  "wh_task_greedy_begin")
+        return pend
+
+    def beam_begin(self, tokens: torch.Tensor, params: BeamParams, sot_index: int, no_speech_token: int) -> "PendingLoop":
+        """`beam` without a blocked caller (see `greedy_begin`); `poll()` returns the result tuple of `beam` at the end"""
+        assert tokens.is_cuda and tokens.dtype == torch.int64 and tokens.dim() == 3 and tokens.is_contiguous()
+        assert tokens.shape[0] == 2 and tokens.shape[1] == self.n_rows
+        dev = tokens.device
+        n_audio, mc, stride = self.n_rows // params.beam_size, params.max_candidates, tokens.shape[2]
+        sum_lp = torch.empty(self.n_rows, dtype=torch.float32, device=dev)
+        nsp = torch.empty(self.n_rows, dtype=torch.float32, device=dev) if no_speech_token >= 0 else None
+        fin_tok = torch.zeros(n_audio, mc, stride, dtype=torch.int64, device=dev)
+        fin_len = torch.zeros(n_audio, mc, dtype=torch.int32, device=dev)
+        fin_score = torch.zeros(n_audio, mc, dtype=torch.float32, device=dev)
+        fin_count = torch.zeros(n_audio, dtype=torch.int32, device=dev)
+        pend = PendingLoop(self, (tokens, params, sum_lp, nsp, fin_tok, fin_len, fin_score, fin_count),
+                           lambda n: (n, sum_lp, nsp, (fin_tok, fin_len, fin_score, fin_count)))
+        with torch.cuda.device(self.model.device):
+            pend.caller = torch.cuda.current_stream(self.model.device)
+            self.stream.wait_stream(pend.caller)
+            check(lib().wh_task_beam_begin(self.handle, C.byref(params), tokens.data_ptr(), stride, sot_index, no_speech_token,
+                                           sum_lp.data_ptr(), _ptr(nsp), fin_tok.data_ptr(), fin_len.data_ptr(),
+                                           fin_score.data_ptr(), fin_count.data_ptr(), stream_ptr(self.stream)),
+                  "wh_task_beam_begin")
+        return pend
+
     def bench_kernel(self, kind: int, iters: int) -> Tuple[float, float]:
         """(average ms per launch, algorithmic bytes per launch): `iters` layer-rotated launches replayed from a hipGraph
         and timed with HIP events on the launch stream inside wh_task_bench_kernel (best of 3 replays)"""
@@ -803,6 +849,38 @@ class HipTask:
         for t_ in (cost, trace, jumps, plen, sizes):
             t_.record_stream(self.stream)
         return cost, jumps, plen
+
+
+class PendingLoop:
+    """A fused greedy / beam loop that has been begun (`HipTask.greedy_begin` / `beam_begin`).  `poll()` queues further
+    decode steps and returns None while the loop runs — it never waits for the device — and the loop's results once it has
+    ended (from then on the task takes other calls again).  `wait()` polls to the end, sleeping in between."""
+
+    def __init__(self, task: "HipTask", keep, result):
+        self.task, self._keep, self._result = task, keep, result     # _keep: every buffer the loop reads or writes
+        self.caller: Optional[torch.cuda.Stream] = None
+        self.done = None
+
+    def poll(self):
+        if self.done is not None:
+            return self.done
+        n = C.c_int32(0)
+        with torch.cuda.device(self.task.model.device):            # the library launches on the thread's CURRENT device
+            rc = lib().wh_task_poll(self.task.handle, C.byref(n))
+            if rc == WH_RUNNING:
+                return None
+            check(rc, "wh_task_poll")
+            self.caller.wait_stream(self.task.stream)               # as `_call` does after a blocking call
+        self.done = self._result(n.value)
+        return self.done
+
+    def wait(self, sleep_s: float = 2e-4):
+        import time
+        while True:
+            r = self.poll()
+            if r is not None:
+                return r
+            time.sleep(sleep_s)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -463,18 +463,26 @@ def transcribe_batch(model: "Whisper", audios, *, batch_size: int = 16, max_acti
     their whole-file spectrogram on the device; the next file starts when one finishes.
     `in_flight` > 1: the files are dealt round-robin into that many groups and every group is driven as described above on a
     host thread and HIP stream of its own (decoding.run_in_lanes): the groups' decode chains overlap on the GPU — each is a
-    chain of dependent launches that leaves the chip idle between them — while every file's result stays exactly what it is
-    with in_flight = 1 (a file's windows never depend on another file).  Worth it from about 2 * batch_size files on."""
+    chain of dependent launches that leaves the chip idle between them — while every file's result at temperature 0 stays
+    exactly what it is with in_flight = 1 (a file's windows never depend on another file; the draws of the temperature ladder
+    are repeatable under torch.manual_seed but belong to the group, so they differ from the in_flight = 1 draws).  `batch_size`
+    applies per group; an explicit `max_active_files` is divided between the groups, so that bound on resident spectrograms holds
+    for the call as a whole (the default is 2 * batch_size per group), while each group keeps its own cached decoding tasks (workspaces scale with the number of groups).  Prefer
+    a larger `batch_size` (rows per decode chain, up to 24) over more groups when there are enough files: a wider chain streams
+    the decoder's weights once for all its rows.  Worth it from about 2 * batch_size files on."""
     audios = list(audios)
     if in_flight > 1 and len(audios) > 1:
         from .decoding import run_in_lanes
         n = min(int(in_flight), len(audios))
         groups = [list(range(k, len(audios), n)) for k in range(n)]
         fp16 = kwargs.get("fp16", True)
+        # an explicit bound holds for the call as a whole; the default (None) stays 2 * batch_size PER GROUP, so that every
+        # group can fill its batches
+        per_group = None if max_active_files is None else max(1, int(max_active_files) // n)
 
         def job(ids):
             return lambda: transcribe_batch(model, [audios[i] for i in ids], batch_size=batch_size,
-                                            max_active_files=max_active_files, in_flight=1, **kwargs)
+                                            max_active_files=per_group, in_flight=1, **kwargs)
         parts = run_in_lanes(model, [job(ids) for ids in groups], n, torch.float16 if fp16 else torch.float32)
         merged: List[Optional[dict]] = [None] * len(audios)
         for ids, part in zip(groups, parts):
