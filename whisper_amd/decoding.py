@@ -975,17 +975,29 @@ def run_interleaved(model: "Whisper", jobs: Sequence, in_flight: int = 3, dtype:
             except StopIteration as done:
                 results[i] = done.value
                 return True
+    # A new job starts only when every job already running is past its FRONT part (log-mel, encoder, prompt pass and the first
+    # decode steps it queued before it first yielded — an event recorded on its stream at that point): jobs started in the same
+    # instant would run their encoders back to back with nothing to overlap them, then decode in lock-step and all end together;
+    # staggered, one chain's encoder runs under the others' decode steps from the first round on.
+    front: Dict[int, torch.cuda.Event] = {}
     try:
         while nxt < len(jobs) or active:
+            ended = False
             for lane in range(n):
-                if lane not in active and nxt < len(jobs):
+                if lane not in active and nxt < len(jobs) and all(ev.query() for ev in front.values()):
                     streams[lane].wait_stream(caller)
                     active[lane] = (nxt, jobs[nxt], _job_generator(base, nxt))
                     nxt += 1
-            ended = False
+                    if resume(lane):
+                        del active[lane]
+                        ended = True
+                    else:
+                        front[lane] = torch.cuda.Event()
+                        front[lane].record(streams[lane])
             for lane in list(active):
                 if resume(lane):
                     del active[lane]
+                    front.pop(lane, None)
                     ended = True
             if not ended and active:
                 time.sleep(sleep_s)

@@ -355,6 +355,26 @@ def pack_weights(sd: Dict[str, torch.Tensor], dims, dtype: int, device: torch.de
     return blob
 
 
+_FROZEN = False
+
+
+def _freeze_startup_objects() -> None:
+    """Once per process, when the first engine is created: move everything the cyclic garbage collector tracks so far — ~170 000
+    objects, nearly all of them `import torch`'s functions, tuples and dicts, which live as long as the process — into the
+    permanent generation (gc.freeze, the standard advice for long-running services).  A full (generation 2) collection otherwise
+    walks all of them, 40 - 80 ms on the host, and it falls into whichever call happens to allocate the container that trips
+    the threshold: round 5's word-timestamp leg showed it as one call in five taking 111 - 134 ms instead of 76
+    (tools/wts_gc_probe.py: the slow call contains exactly one generation-2 pass of 40 ms; none after the freeze).  Objects
+    created later are collected as always.  WHISPER_AMD_NO_GC_FREEZE=1 leaves the collector alone."""
+    global _FROZEN
+    if _FROZEN or os.environ.get("WHISPER_AMD_NO_GC_FREEZE") == "1":
+        return
+    _FROZEN = True
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 class HipModel:
     """wh_model handle + the weight blob it points into."""
 
@@ -415,6 +435,7 @@ class HipModel:
         else:
             with torch.cuda.device(self.device):
                 self.task_cache_bytes = int(torch.cuda.mem_get_info()[1] * 0.10)
+        _freeze_startup_objects()
 
     # -- decoding tasks are expensive to set up (GBs of workspace, a 250-node graph capture): keep them -------------
     @contextlib.contextmanager
