@@ -17,6 +17,8 @@ model = hip.HipModel(dims, hip.WH_F16, hip.pack_weights(sd, dims, hip.WH_F16, de
 g = torch.Generator(device=dev).manual_seed(4)
 print("library:", os.environ.get("WHISPER_AMD_LIB", "whisper_amd/libwhisper_hip.so"), "model:", name, flush=True)
 shapes = ((8, 1), (8, 5), (16, 1), (32, 1), (4, 5)) if name == "large-v3" else ((1, 1), (1, 5), (8, 1))
+if os.environ.get("ROWS_SHAPES"):                # e.g. ROWS_SHAPES=24x1,20x1,17x1
+    shapes = tuple(tuple(int(v) for v in sh.split("x")) for sh in os.environ["ROWS_SHAPES"].split(","))
 for B, G in shapes:
     feats = torch.randn(B, dims.n_audio_ctx, dims.n_audio_state, generator=g, device=dev).half()
     r = bench.step_roofline(model, feats, B, G, 35)

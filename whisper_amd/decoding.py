@@ -733,7 +733,17 @@ class DecodingTask:
         fused = self._fused_greedy_ok(None) or (type(self.decoder) is BeamSearchDecoder and self._beam_shape_ok())
         return self.n_ctx - self.sample_len if fused else None
 
-    def _main_loop(self, audio_features: Tensor, tokens: Tensor, wait: bool = True):
+    def _main_loop(self, audio_features: Tensor, tokens: Tensor):
+        """decoding.py:680-710: (tokens, sum_logprobs, no_speech_probs), waiting for the device-side loops (the reference's name and
+        signature; `_main_loop_steps` is the same as a generator)"""
+        steps = self._main_loop_steps(audio_features, tokens, wait=True)
+        try:
+            while True:
+                next(steps)                      # with wait=True nothing ever yields
+        except StopIteration as done:
+            return done.value
+
+    def _main_loop_steps(self, audio_features: Tensor, tokens: Tensor, wait: bool = True):
         """generator (see `_await`); returns (tokens, sum_logprobs, no_speech_probs)"""
         if self._ragged():
             limit = self.ragged_limit()
@@ -840,7 +850,7 @@ class DecodingTask:
 
         # one row per (audio, beam / sample); the kernels map row -> audio as row // n_group
         tokens = tokens.repeat_interleave(self.n_group, dim=0).to(audio_features.device)
-        tokens, sum_logprobs, no_speech_probs = yield from self._main_loop(audio_features, tokens, wait)
+        tokens, sum_logprobs, no_speech_probs = yield from self._main_loop_steps(audio_features, tokens, wait)
 
         no_speech_probs = no_speech_probs[:: self.n_group]
         assert audio_features.shape[0] == len(no_speech_probs) == n_audio
