@@ -100,7 +100,7 @@ def parse():
     p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = all usable cores)")
     p.add_argument("--task-form", type=int, default=0, help="developer A/B for chains of <= 8 rows: 0 = the default step (cross attention fused with its "
                                                            "query projection, csrc/xattn.hip), 1 = the self attention fused too (WH_TASK_FUSED_SELF), "
-                                                           "2 = cross attention as two launches")
+                                                           "2 = cross attention as two launches (the default with --in-flight > 1), 4 = keep the fused cross attention with --in-flight > 1")
     p.add_argument("--chain-batches", type=int, default=3, help="passes coalesced into one decode chain (rows of a chain = this x --batch; the row-tiled "
                                                                 "projection kernels take up to 24 rows)")
     p.add_argument("--in-flight", type=int, default=1, help="decode chains in flight at once on this GPU, each on its own task and HIP stream, all driven "
@@ -245,23 +245,30 @@ def main():
     # one workspace); the decode loop is wh_task_greedy (F = 1) or wh_task_greedy_begin + wh_task_poll in turn (F > 1).
     sched = chain_schedule(args, world)
     CB, F, CR = sched["chain_batches"], sched["chains_in_flight"], sched["chain_rows"]      # CR: rows of a full chain
-    form = dict(fused_self=bool(args.task_form & 1), two_launch_cross=bool(args.task_form & 2))
+    # several chains in flight: no spinning kernel beside other chains (what HipModel.acquire_task gives a lane's task; --task-form 4
+    # keeps the fused cross attention there for A/B)
+    form = dict(fused_self=bool(args.task_form & 1), two_launch_cross=bool(args.task_form & 2) or (F > 1 and not args.task_form & 4))
 
     class Lane:
-        def __init__(self, stream):
-            self.stream = stream
+        def __init__(self, stream, form):
+            self.stream, self.form = stream, form
             self.tasks, self.tokens = {}, {}
 
         def task(self, nb):
             if nb not in self.tasks:
-                self.tasks[nb] = hip.HipTask(model, nb * B, 1, max(T0, 8), stream=self.stream, **form)
+                self.tasks[nb] = hip.HipTask(model, nb * B, 1, max(T0, 8), stream=self.stream, **self.form)
                 self.tokens[nb] = torch.zeros(nb * B, T0 + N + 1, dtype=torch.int64, device=device)
             return self.tasks[nb], self.tokens[nb]
 
-    lanes = [Lane(torch.cuda.Stream(device=device) if F > 1 else None) for _ in range(F)]
+    lanes = [Lane(torch.cuda.Stream(device=device) if F > 1 else None, form) for _ in range(F)]
     for ln in lanes:
         ln.task(CB)
-    lanes[0].task(1)                                      # the one-pass-at-a-time figure (and the tail chains of K % CB passes)
+    if F > 1 and CB == 1:
+        # the one-pass-at-a-time figure is ONE chain alone on the chip: the default step (fused cross attention), not a lane's
+        serial_lane = Lane(lanes[0].stream, dict(fused_self=bool(args.task_form & 1), two_launch_cross=bool(args.task_form & 2)))
+    else:
+        serial_lane = lanes[0]
+    serial_lane.task(1)                                   # the one-pass-at-a-time figure (and the tail chains of K % CB passes)
     torch.cuda.synchronize(device)
 
     def enqueue_chain(ln, nb, begin_only):
@@ -335,13 +342,13 @@ def main():
     audio_s = 30.0 * B * world * args.steps
     value = audio_s / elapsed
     # the same passes ONE AT A TIME as chains of B rows (what rounds 1-4 reported as the headline), measured in the same run
-    task, tokens = lanes[0].task(1)
+    task, tokens = serial_lane.task(1)
     ks = max(2, min(args.steps, 6))
-    enqueue_chain(lanes[0], 1, False)
+    enqueue_chain(serial_lane, 1, False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(ks):
-        enqueue_chain(lanes[0], 1, False)
+        enqueue_chain(serial_lane, 1, False)
     barrier()
     ser = (time.perf_counter() - t0) / ks
     serial = {"value": round(30.0 * B * world / ser, 2), "ms_per_step": round(ser * 1e3, 3), "steps": ks,
@@ -460,7 +467,7 @@ def main():
         # (must be 0: with several chains on the chip a producer workgroup may be dispatched late, the bounds have to hold there too)
         out["handoff_timeouts"] = sum(t.handoff_timeouts() for ln in lanes for t in ln.tasks.values())
         out["handoff_fallbacks"] = sum(t.handoff_fallbacks for ln in lanes for t in ln.tasks.values())
-    for ln in lanes:
+    for ln in lanes + ([serial_lane] if serial_lane is not lanes[0] else []):
         for t in ln.tasks.values():
             t.close()
         ln.tasks.clear()

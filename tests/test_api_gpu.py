@@ -677,9 +677,9 @@ def test_incremental_decoder_with_kv_cache_hooks(setup, gpu_device):
 def test_decode_many_in_lanes_equals_sequential(setup, fp16, beam):
     """whisper_amd.decode_many: several batches decoded with up to 3 chains in flight — each on a HIP stream of its own
     (HipModel.lane), all driven from the calling thread (run_interleaved: wh_task_*_begin + wh_task_poll in turn), the encoder on
-    the engine's one stream.  With chain_rows=None every batch is its own chain and must give exactly what decode() gives batch by
-    batch: token ids, avg_logprob, no_speech_prob; greedy and beam search, both engines; raw audio batches take their log-mel
-    per batch.  Batches of different sizes (different task shapes), more batches than lanes (a lane runs several), twice in a
+    the engine's one stream.  With chain_rows=None every batch is its own chain and must give what decode() gives batch by
+    batch: token ids, avg_logprob, no_speech_prob (exactly in the fp32 engine); greedy and beam search, both engines; raw audio
+    batches take their log-mel per batch.  Batches of different sizes (different task shapes), more batches than lanes (a lane runs several), twice in a
     row (the lanes' tasks come back from the engine's cache).  With the default chain_rows=24 consecutive batches are coalesced
     into wider chains: exact in the fp32 engine, equal ids and log-probabilities to 5e-3 in the fp16 engine (the order of fp32
     partial sums follows the row count)."""
@@ -690,13 +690,16 @@ def test_decode_many_in_lanes_equals_sequential(setup, fp16, beam):
     batches = [torch.stack(mels[0:3]), torch.stack(mels[3:4]), torch.stack(mels[4:6]), torch.stack(mels[6:9]), torch.stack(mels[0:2])]
     opts = whisper_amd.DecodingOptions(language="en", fp16=fp16, sample_len=16, beam_size=beam)
     want = [whisper_amd.decode(model, (b.half() if fp16 else b), opts) for b in batches]
+    # a lane's task runs its cross attention as two launches (no spinning kernel beside other chains; decode() alone uses the fused
+    # launch, whose fp32 partial sums meet in another order): exact in the fp32 engine, ids equal and values to 5e-3 in the fp16 engine
+    tol = 5e-3 if fp16 else 1e-6
     for _ in range(2):
         got = whisper_amd.decode_many(model, [(b.half() if fp16 else b) for b in batches], opts, in_flight=3, chain_rows=None)
         assert len(got) == len(want)
         for g, w in zip(got, want):
             assert [r.tokens for r in g] == [r.tokens for r in w]
-            assert np.allclose([r.avg_logprob for r in g], [r.avg_logprob for r in w], atol=1e-6)
-            assert np.allclose([r.no_speech_prob for r in g], [r.no_speech_prob for r in w], atol=1e-6)
+            assert np.allclose([r.avg_logprob for r in g], [r.avg_logprob for r in w], atol=tol)
+            assert np.allclose([r.no_speech_prob for r in g], [r.no_speech_prob for r in w], atol=tol)
     # coalesced (default chain_rows=24): greedy 3 + 1 + 2 + 3 + 2 = 11 rows in one chain; beam 3: 9 + 3 + 6 | 9 + 6 rows
     got = whisper_amd.decode_many(model, [(b.half() if fp16 else b) for b in batches], opts, in_flight=2)
     assert [len(g) for g in got] == [len(w) for w in want]

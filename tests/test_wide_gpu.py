@@ -1162,11 +1162,11 @@ def test_conditioned_checkpoint_beam5_winners_exact_64_steps(large_v3, gpu_devic
 
 
 def test_large_v3_three_lanes_equal_one_chain_no_timeouts(large_v3, gpu_device):
-    """Lanes at full depth (round 5): three tasks of 8 rows decode AT ONCE on the fp16 engine — each on its own host thread and
-    HIP stream (`HipModel.lane`), as bench.py's headline and `decode_many` run — and every lane's 8 x 96 token ids equal the
-    ids the same task produces alone.  The fused step kernels hand q / k / v over through bounded spins that assume their
-    producer workgroups get dispatched in time; with two other chains' kernels on the same CUs that assumption is exercised
-    for real: the spins that ran out and the loops that fell back to the two-launch kernels are asserted to be 0."""
+    """Lanes at full depth: three tasks of 8 rows decode AT ONCE on the fp16 engine — each on its own host thread and HIP stream
+    (`HipModel.lane`) — and every lane's 8 x 96 token ids equal the ids the same task produces alone.  Since round 6 a lane's task
+    runs no kernel that spins (self AND cross attention as two launches: with other chains and their encoders on the chip the
+    fused launch's hang guard tripped in 2 of 25 fresh processes, profiles/r06_lanes.txt), so time-outs and fallbacks are 0 by
+    construction; asserted all the same.  Then the same three chains from ONE host thread (wh_task_greedy_begin + wh_task_poll)."""
     import threading
     fd = large_v3
     dims = fd.dims
@@ -1184,8 +1184,8 @@ def test_large_v3_three_lanes_equal_one_chain_no_timeouts(large_v3, gpu_device):
         assert n == T0 + n_steps
 
     alone = []
-    for f in feats:                                               # one chain at a time
-        t = hip.HipTask(eng, 8, 1, max(T0, 8))
+    for f in feats:                                               # one chain at a time, on the kernels a lane's task runs
+        t = hip.HipTask(eng, 8, 1, max(T0, 8), two_launch_cross=True)
         o = torch.zeros(8, T0 + n_steps + 1, dtype=torch.int64, device=gpu_device)
         decode(t, f, o)
         torch.cuda.synchronize()
@@ -1198,7 +1198,7 @@ def test_large_v3_three_lanes_equal_one_chain_no_timeouts(large_v3, gpu_device):
         try:
             with eng.lane() as st:
                 t = eng.acquire_task(8, 1, max(T0, 8))
-                assert t.stream is st
+                assert t.stream is st and not t.fused_cross_attention and not t.fused_self_attention     # a lane's task spins for nothing
                 o = torch.zeros(8, T0 + n_steps + 1, dtype=torch.int64, device=gpu_device)
                 for _ in range(3):                                # three passes per lane: the chains drift against each other
                     decode(t, feats[i], o)
@@ -1223,7 +1223,7 @@ def test_large_v3_three_lanes_equal_one_chain_no_timeouts(large_v3, gpu_device):
     # ---- the same three chains driven by ONE host thread (wh_task_greedy_begin + wh_task_poll in turn, no lane threads): the
     # same tokens, and not slower than three threads (<= 2 % asked; asserted at 5 %, printed)
     streams = [torch.cuda.Stream(device=gpu_device) for _ in range(3)]
-    tasks = [hip.HipTask(eng, 8, 1, max(T0, 8), stream=streams[i]) for i in range(3)]
+    tasks = [hip.HipTask(eng, 8, 1, max(T0, 8), stream=streams[i], two_launch_cross=True) for i in range(3)]
     outs = [torch.zeros(8, T0 + n_steps + 1, dtype=torch.int64, device=gpu_device) for _ in range(3)]
 
     def one_thread(passes):

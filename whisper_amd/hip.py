@@ -491,7 +491,15 @@ class HipModel:
             max_prefill = self.dims.n_text_ctx
         if stream is None:
             stream = self.task_stream()
-        key = (n_audio, n_group, max_prefill, capture_q, stream)
+        # A task of a LANE (several chains share the chip: `lane`, run_interleaved, run_in_lanes) runs NO kernel that spins: its cross
+        # attention is two launches like its self attention.  The fused launch (csrc/xattn.hip: consumers poll for q while their K/V
+        # streams in) wins where a chain has the chip to itself (13.1 vs 15.4 us per layer); beside other chains — and their encoders,
+        # whose persistent GEMM workgroups hold whole CUs — a producer workgroup is now and then dispatched milliseconds late, the
+        # 8192-poll hang guard trips and the task falls back to these same two-launch kernels after wasting a pass: 2 of 25 fresh
+        # processes with three 8-row chains in flight (876 instead of 1054 audio-s/s; results exact either way), against a steady 1015
+        # with the two-launch form (profiles/r06_lanes.txt).  Predictable beats 4 % faster most of the time.
+        in_lane = getattr(self._tls, "stream", None) is not None and stream is self._tls.stream
+        key = (n_audio, n_group, max_prefill, capture_q, stream, in_lane)
         task = None
         with self._lock:
             for i in range(len(self._task_cache) - 1, -1, -1):
@@ -501,7 +509,7 @@ class HipModel:
         if task is not None:
             task.reset()
             return task
-        task = HipTask(self, n_audio, n_group, max_prefill, capture_q=capture_q, stream=stream)
+        task = HipTask(self, n_audio, n_group, max_prefill, capture_q=capture_q, stream=stream, two_launch_cross=in_lane)
         task._cached = True
         return task
 
@@ -594,6 +602,7 @@ class HipTask:
         self.n_audio, self.n_group, self.n_rows = n_audio, n_group, n_audio * n_group
         self.max_prefill = max_prefill
         self.capture_q = capture_q
+        self.two_launch_cross = bool(two_launch_cross)
         flags = ((WH_TASK_CAPTURE_Q if capture_q else 0) | (WH_TASK_TWO_LAUNCH_SELF if two_launch_self else 0)
                  | (WH_TASK_TWO_LAUNCH_CROSS if two_launch_cross else 0)
                  | (WH_TASK_EXPIRE_HANDOFFS if expire_handoffs else 0) | (WH_TASK_FUSED_SELF if fused_self else 0)
@@ -615,7 +624,7 @@ class HipTask:
 
     @property
     def cache_key(self):
-        return (self.n_audio, self.n_group, self.max_prefill, self.capture_q, self.stream)
+        return (self.n_audio, self.n_group, self.max_prefill, self.capture_q, self.stream, self.two_launch_cross)
 
     def close(self):
         """release: into the engine's task cache when it came from `acquire_task`, otherwise destroy"""
