@@ -843,7 +843,7 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
     const float invK = 1.0f / (float)K;
     // LDS byte address of this lane's 4 elements of wave-load j, row r: + j * 1024 + (r / 8) * FRAG * 16 + (r % 8) * 16
     const uint32_t fbase = (uint32_t)((lane >> 4) * NU * 64 + 16 * ((lane >> 1) & 3) + 8 * ((lane >> 3) & 1)) * 16u + (uint32_t)(lane & 1) * 8u;
-    constexpr int RB = NR > 2 ? 2 : NR;                    // rows in flight per wave (register budget)
+    constexpr int RB = NR > 3 ? 3 : NR;                    // rows in flight per wave (register budget: 3 x NU float4 = 60 VGPRs)
 #pragma unroll
     for (int i0 = 0; i0 < NR; i0 += RB) {
       float4v v[RB][NU];
