@@ -27,12 +27,22 @@ def test_library_exports_header():
     assert sorted(hip.SIGNATURES) == syms, "ctypes binding and header disagree"
 
 
+def test_library_exports_nothing_but_the_header():
+    """the dynamic symbol table of libwhisper_hip.so holds exactly the wh_* functions include/whisper_hip.h
+    declares — no whk::launch_* host wrappers, no kernel stubs (linker version script csrc/exports.map)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", hip.lib_path()], check=True, capture_output=True, text=True).stdout
+    defined = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert defined == header_symbols(), sorted(set(defined) ^ set(header_symbols()))
+
+
 def test_status_strings_and_version():
     lib = hip.lib()
     assert lib.wh_abi_version() == 1
     assert lib.wh_status_string(0) == b"ok"
     assert b"workspace" in lib.wh_status_string(2)
     assert b"hand-off" in lib.wh_status_string(6) and lib.wh_status_string(99) == b"unknown status"
+    assert b"running" in lib.wh_status_string(7)                     # WH_RUNNING: wh_task_poll, not an error
 
 
 def test_argument_validation_without_gpu():
@@ -43,6 +53,8 @@ def test_argument_validation_without_gpu():
     assert lib.wh_dtw_trace(None, 4, 4, None, None) == 1
     assert lib.wh_encoder_workspace_bytes(None, 1) == 0
     assert lib.wh_task_workspace_bytes(None, 1, 1, 8, 0) == 0
+    assert lib.wh_task_poll(None, None) == 1
+    assert lib.wh_task_greedy_begin(None, None, None, 0, 0, -1, None, None, None) == 1       # null task: refused before any device work
 
 
 def test_blob_layout_is_deterministic():
