@@ -533,6 +533,22 @@ def main():
                 extras["greedy_sample_len_64"]["coalesced"] = {"chain_rows": CR, "chains_in_flight": F, "ms_per_pass": round(l64, 2),
                                                                "audio_s_per_s": round(B * 30.0 / (l64 / 1e3), 1), "passes": 3 * CB * F}
                 log(f"greedy, 64 steps: {ms64:.1f} ms per pass = {B * 30.0 / (ms64 / 1e3):.0f} audio-s/s")
+            # NOT the headline (BASELINE configs[2] fixes 8 clips per batch; the headline keeps 24 clips resident as round 5 did): what the
+            # same engine does when MORE clips are pending — two / three 24-row chains in flight (48 / 72 clips resident), one host thread
+            if args.model == "large-v3" and B == 8 and CR == 24:
+                more = {}
+                for nf in (2, 3):
+                    whisper_amd.decode_many(wmodel, [audio] * (3 * nf), opts, in_flight=nf, chain_rows=24)
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    many = whisper_amd.decode_many(wmodel, [audio] * (6 * nf), opts, in_flight=nf, chain_rows=24)
+                    torch.cuda.synchronize(device)
+                    mms = (time.perf_counter() - t0) / (6 * nf) * 1e3
+                    more[f"{24 * nf}_clips_resident"] = {
+                        "chains_in_flight": nf, "chain_rows": 24, "ms_per_pass": round(mms, 2), "audio_s_per_s": round(30.0 * B / (mms * 1e-3), 1),
+                        "passes": 6 * nf, "tokens_equal_direct": all(r.tokens == direct_tokens[i, T0:].tolist() for rs in many for i, r in enumerate(rs))}
+                    log(f"{24 * nf} clips resident ({nf} chains of 24 rows in flight): {mms:.1f} ms per pass = {30.0 * B / (mms * 1e-3):.0f} audio-s/s")
+                extras["more_clips_resident"] = more
             # BASELINE configs[3] shape: beam search (beam 5) on this GPU's clips, device-side beam loop
             if args.beam >= 2:
                 bopts = whisper_amd.DecodingOptions(language="en", fp16=True, sample_len=args.beam_steps, beam_size=args.beam,
