@@ -349,6 +349,11 @@ struct TaskGuard {
 };
 #define TASK_ENTER(task) TaskGuard _guard(task); if ((task) && !_guard.ok) return WH_ERR_STATE
 
+// the few-row prefill (see prefill_impl): bounds used by the workspace carve-up as well
+static const int SKINNY_ROWS = 96;          // rows x prompt tokens (round 6: 48 -> 96, so that the prompt pass of a 24-row chain — 24 x 4 tokens —
+                                            // stays off 128 x 128 GEMM tiles that fill 10 workgroups: 10 -> ~4 ms per chain)
+static const int SKINNY_LOGIT_ROWS = 48;    // selected rows the streaming logits launch takes
+
 // key-range splits of the decode attention: enough for the register-resident tile to hold a split
 // (attn_decode_capacity) and enough workgroups (>= ~640) to cover the 256 CUs with loads in flight
 static int pick_splits(int R, int H, int max_keys, int dtype) {
@@ -391,7 +396,10 @@ static void task_carve(wh_task* t, void* base) {
   t->att = c.take(Mx * D * es);
   t->h = c.take(Mx * 4 * D * es);
   t->qbuf = c.take(R * D * es);
-  const size_t Rp = R > 48 ? R : 48;          // the few-row prefill runs its cross attention through the decode kernel
+  // the few-row prefill (<= SKINNY_ROWS rows x tokens) runs its cross attention through the decode kernel: one partial per (row, token)
+  size_t Rp = Mx < (size_t)SKINNY_ROWS ? Mx : (size_t)SKINNY_ROWS;
+  if (Rp < R) Rp = R;
+  if (Rp < 48) Rp = 48;
   t->part_o = c.take(Rp * H * DEC_ATTN_MAX_SPLITS * 64 * 4);
   t->part_ml = (float*)c.take(Rp * H * DEC_ATTN_MAX_SPLITS * 2 * 4);
   t->logits = (float*)c.take(R * 2 * V * 4);
@@ -609,7 +617,6 @@ static inline void* cross_layer(const wh_task* t, int l) {
 // The usual prefill is a handful of rows (batch x 3-4 initial tokens): a 128x128 MFMA tile would be > 80 % padding
 // and its launch fills 10-40 workgroups, so up to SKINNY_ROWS rows go through the decode-step projection kernels
 // (LayerNorm / residual fused, weights streamed once); long prompts keep the GEMM path.
-static const int SKINNY_ROWS = 48;
 
 static hipError_t proj_ln(const wh_model* m, const float* x, int rows, const float* ln_w, const float* ln_b, const void* W,
                           const float* bias, int N, int K, void* y, int64_t y_ld, bool gelu, hipStream_t s) {
@@ -754,7 +761,7 @@ static int prefill_impl(wh_task* t, const int64_t* tokens, int64_t token_stride,
     HIPCHK(hipMemcpyAsync(t->d_sel, sel, (size_t)Ms * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(t->sel_event, s));
     HIPCHK(launch_gather_rows(t->x, t->d_sel, Ms, D, t->xsel, s));
-    if (Ms <= SKINNY_ROWS && D <= 2048) {          // LayerNorm + tied logits projection as one streaming launch
+    if (Ms <= SKINNY_LOGIT_ROWS && D <= 2048) {    // LayerNorm + tied logits projection as one streaming launch
       GemvArgs g; memset(&g, 0, sizeof(g));
       g.pro = PRO_LN; g.xf = t->xsel; g.xf_ld = D; g.ln_w = m->w.dec_ln_w; g.ln_b = m->w.dec_ln_b;
       g.W = m->w.tok_emb; g.N = V; g.K = D; g.R = Ms;
