@@ -22,7 +22,7 @@ import json, os, sys
 out = {"source": "tests/test_wide_gpu.py (pytest -m gpu) via tests/conftest.py::write_report, MI355X"}
 for name in ("fp16_large_v3_greedy", "fp16_large_v3_beam5", "turbo_dims", "conditioned_large_v3", "conditioned_turbo",
              "conditioned_large_v3_beam5", "alignment_conditioned_turbo", "alignment_conditioned_large_v3",
-             "conditioned_base_x1", "lanes_one_thread"):
+             "conditioned_base_x1", "lanes_one_thread", "conditioned_large_v3_24_rows"):
     p = os.path.join("gpurun_out", "parity", name + ".json")
     if os.path.exists(p):
         out[name] = json.load(open(p))
