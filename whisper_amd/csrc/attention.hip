@@ -833,6 +833,153 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_group_mfma_kernel(whk:
 }
 
 // =============================================================================================
+// The same beam-group cross attention with WHOLE cache lines per request (round 6).  In the kernel above an MFMA operand row is
+// shared by 4 lanes, so a wave instruction fetches 16 half lines (64 B of a key's 128-byte head row, or of a V^T row): 256 half-line
+// requests per 64 keys, and the launch streams at 3.5 TB/s where the per-row kernel (8 lanes per key, whole lines) reaches 5.
+// Here both products use the "diagonal" tile of gemv8_kernel: the 16 A rows are 8 keys x the 2 halves of the head (first product) /
+// 8 head dims x the 2 halves of a 64-key block (second product), the 16 B columns the 8 beams x the same 2 halves; lane
+// l = 16 c + 8 half + i requests 16 bytes at offset 64 half + 16 c of row i — 8 lanes per row, 8 whole lines per wave instruction,
+// 128 line requests per 64 keys.  Of each 16 x 16 product only the two diagonal 8 x 8 blocks (same half on both sides) mean
+// anything: S[key][beam] = C[key][beam] + C[8 + key][8 + beam] (one DPP row_ror:8 + one v_permlane32_swap per register); half of the
+// MFMA work is discarded, irrelevant next to the stream.  P goes from the S accumulators (4 consecutive keys per lane, 16 lanes) to
+// the B operand of the second product (8 consecutive keys per lane) through 1 KB of wave-private LDS per 64-key block.
+// One 64-key block per wave, everything requested up front (one HBM round trip), WAVES x 64 keys per (split, head, audio).
+// =============================================================================================
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attn_decode_group_diag_kernel(whk::DecAttnArgs a) {
+  pin_kernargs(a);
+  __shared__ float red_o[WAVES][8][64];
+  __shared__ float red_m[WAVES][8], red_l[WAVES][8];
+  __shared__ __attribute__((aligned(16))) half_t p_lds[WAVES][8][64];          // [wave][beam][key of the block]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int S = a.splits, G = a.kv_group, Tk = a.Tk;
+  int chunk = (Tk + S - 1) / S;
+  chunk = (chunk + 127) / 128 * 128;                                  // (<= WAVES * 64 keys: launcher)
+  const int k0 = s * chunk;
+  int k1 = k0 + chunk; if (k1 > Tk) k1 = Tk;
+  const int nkeys = k1 > k0 ? k1 - k0 : 0;
+  const int i8 = lane & 7, half = (lane >> 3) & 1, c4 = lane >> 4;    // lane = 16 c4 + 8 half + i8
+  const int eoff = 32 * half + 8 * c4;                                // element offset inside a 64-element row
+  const int64_t hs = a.kv_hs ? a.kv_hs : 64;
+  const int kb = k0 + wave * 64;                                      // this wave's block of 64 keys
+
+  // q: B operand of the first product — lane (c4, half, beam i8) holds head dims [32 half + 8 c4, +8), pre-scaled (exact in fp16)
+  const half8v qf = scale_q(*(const half8v*)((const half_t*)a.q + (int64_t)(b * G + (i8 < G ? i8 : G - 1)) * a.q_ld + h * 64 + eoff));
+  asm volatile("" ::: "memory");
+  // K: 8 wave-loads, load j = keys kb + 8 j + i8 (whole 128-byte head rows); V^T: 8 wave-loads, load g = head dims 8 g + i8, keys
+  // kb .. kb + 63 (whole lines of the transposed rows)
+  const half_t* kp = (const half_t*)a.k + (int64_t)b * a.k_bs + h * hs + eoff;
+  const int klast = nkeys > 0 ? k1 - 1 : 0;
+  const uint32_t ldk = (uint32_t)a.k_ld;
+  half8v kf[8], vf[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int key = kb + 8 * j + i8;
+    if (key > klast) key = klast;                                     // masked below; the load stays in bounds
+    kf[j] = __builtin_nontemporal_load((const half8v*)(kp + (uint32_t)key * ldk));
+  }
+  {
+    // the rows are padded to S * chunk keys (zeros beyond Tk: task_reset_impl); a block that lies wholly beyond this split's keys has
+    // P = 0 everywhere and is pointed at the last 64 columns of the row, so that what it multiplies by 0 is finite and inside the row
+    int col = kb; if (col > (int)a.vt_ld - 64) col = (int)a.vt_ld - 64;
+    const half_t* vp = (const half_t*)a.vt + (int64_t)b * a.vt_bs + (int64_t)(h * 64 + i8) * a.vt_ld + col + eoff;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) vf[g] = __builtin_nontemporal_load((const half8v*)(vp + (int64_t)(8 * g) * a.vt_ld));
+  }
+  // every request goes out before the first use (see the kernel above)
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- scores: after the diagonal sum lane (c4 < 2, half = 0, beam i8) — and its three mirror lanes — holds keys kb + 8 j + 4 c4 + e
+  const int ka = 4 * (c4 & 1);
+  float4v sc[8];
+  float mx = WH_NEG_INF;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float4v c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[j], qf, c, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      // C[key][beam] + C[8 + key][8 + beam]: the partner is lane ^ 40 (ror 8 inside the row of 16, then the other half of the wave).
+      // Exact in the lanes that are used below (c4 < 2, half = 0) and their partners; the other lanes hold sums nobody reads.
+      float p_, q_; lane_swap32(lane_xor8(c[e]), p_, q_);
+      float z = c[e] + (lane < 32 ? q_ : p_);
+      if (kb + 8 * j + ka + e >= k1) z = WH_NEG_INF;
+      c[e] = z;
+      mx = fmaxf(mx, z);
+    }
+    sc[j] = c;
+  }
+  // lanes (c4, beam) and (c4 ^ 1, beam) hold the two halves of the block's keys for that beam: xor 16
+  { float a_, b_; lane_swap16(mx, a_, b_); mx = fmaxf(a_, b_); }
+  if (lane < 8) red_m[wave][lane] = mx;
+  __syncthreads();
+  float M = red_m[0][i8];
+#pragma unroll
+  for (int w = 1; w < WAVES; ++w) M = fmaxf(M, red_m[w][i8]);
+
+  // ---- p = exp(s - M): row sums, and P into LDS as [beam][key] (the 16 lanes c4 < 2, half = 0 write; every lane computes)
+  float lsum = 0.f;
+  half_t* pw = &p_lds[wave][i8][0];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    half4v p4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float p = (sc[j][e] == WH_NEG_INF) ? 0.f : __expf(sc[j][e] - M);
+      lsum += p;
+      p4[e] = (half_t)p;
+    }
+    if (lane < 32 && half == 0) *(half4v*)(pw + 8 * j + ka) = p4;
+  }
+  { float a_, b_; lane_swap16(lsum, a_, b_); lsum = a_ + b_; }          // both key halves of the block
+  if (lane < 8) red_l[wave][lane] = lsum;
+  // B operand of the second product: lane (c4, half, beam i8) = P[keys 32 half + 8 c4 .. + 7][beam].  Wave-private LDS: the LDS
+  // queue of a wave is in order, so no workgroup barrier — only the compiler must not move the read above the writes
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+  const half8v pf = *(const half8v*)(&p_lds[wave][i8][eoff]);
+
+  // ---- O^T[dim][beam] = V^T . P on the diagonal tile, 8 head dims per product
+  float4v oacc[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    float4v c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[g], pf, c, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float p_, q_; lane_swap32(lane_xor8(c[e]), p_, q_);
+      c[e] += lane < 32 ? q_ : p_;
+    }
+    oacc[g] = c;
+  }
+  // lane (c4 < 2, half = 0, beam i8) holds dims 8 g + 4 c4 + e
+  if (lane < 32 && half == 0) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) *(float4v*)&red_o[wave][i8][8 * g + ka] = oacc[g];
+  }
+  __syncthreads();
+  for (int t = tid; t < G * 64; t += WAVES * 64) {
+    const int g = t >> 6, d = t & 63;
+    float o = red_o[0][g][d], l = red_l[0][g], m = red_m[0][g];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) { o += red_o[w][g][d]; l += red_l[w][g]; m = fmaxf(m, red_m[w][g]); }
+    const int r = b * G + g;
+    if (S == 1) {
+      ((half_t*)a.out)[(int64_t)r * a.o_ld + h * 64 + d] = (half_t)(o / l);
+    } else {
+      const int64_t pi = ((int64_t)s * a.R + r) * a.H + h;
+      ((half_t*)a.part_o)[pi * 64 + d] = (half_t)(nkeys > 0 ? o / l : 0.f);
+      if (d == 0) {
+        a.part_ml[pi * 2 + 0] = nkeys > 0 ? m : WH_NEG_INF;
+        a.part_ml[pi * 2 + 1] = nkeys > 0 ? l : 0.f;
+      }
+    }
+  }
+}
+
+// =============================================================================================
 // cross QK capture
 // =============================================================================================
 template <typename T>
@@ -989,6 +1136,11 @@ static hipError_t launch_attn_decode_t(const DecAttnArgs& a, hipStream_t stream)
     if (a.vt && !no_mfma && a.kv_group > 1 && a.kv_group <= 8 && a.R % a.kv_group == 0 && chunk <= 512 &&
         (int64_t)a.splits * ((chunk + 127) / 128 * 128) <= a.vt_ld) {
       dim3 ggrid(a.splits, a.H, a.R / a.kv_group);
+      // round 6: whole cache lines per request (the diagonal tile); A/B against the kernels below: WH_GROUP_ATTN_HALF_LINES=1
+      if (!WH_DEV_FLAG("WH_GROUP_ATTN_HALF_LINES") && a.vt_ld >= 64) {
+        hipLaunchKernelGGL((attn_decode_group_diag_kernel<8>), ggrid, dim3(512), 0, stream, a);
+        return hipGetLastError();
+      }
       // 8 waves x 2 blocks and 4 waves x 4 blocks of 32 keys measured the same (232.8 vs 233.0 ms per 64-step beam pass)
       if ((chunk + 127) / 128 <= 1) hipLaunchKernelGGL((attn_decode_group_mfma_kernel<1, 8>), ggrid, dim3(512), 0, stream, a);
       else hipLaunchKernelGGL((attn_decode_group_mfma_kernel<2, 8>), ggrid, dim3(512), 0, stream, a);
