@@ -1171,3 +1171,51 @@ def test_beam_shared_history_permutation_model_is_exact():
                 for i in range(G):                                        # the next decode step appends position `length`
                     cache[i].append(tuple(hist[i]))
     assert moved < full                                                   # and it does save copies
+
+
+def test_coalesce_batches_and_job_seeds():
+    """round 6 host logic of decode_many / the lanes (CPU): batches are coalesced into chains of at most chain_rows rows in order, a batch
+    wider than the bound stays alone, None / 0 disables it; and the sampling seeds a job draws are a function of the base seed and the
+    job's INDEX only (not of the order in which lanes run jobs), repeatable under torch.manual_seed, distinct between jobs."""
+    from whisper_amd import decoding as D
+    assert D.coalesce_batches([8, 8, 8], 24) == [[0, 1, 2]]
+    assert D.coalesce_batches([8, 8, 8, 8, 8], 24) == [[0, 1, 2], [3, 4]]
+    assert D.coalesce_batches([8, 16, 8, 1, 1], 24) == [[0, 1], [2, 3, 4]]
+    assert D.coalesce_batches([40, 40, 8, 8], 24) == [[0], [1], [2, 3]]          # beam 5 x 8 clips: wider than a chain
+    assert D.coalesce_batches([8, 8], None) == [[0], [1]] and D.coalesce_batches([8, 8], 0) == [[0], [1]]
+    assert D.coalesce_batches([], 24) == []
+    flat = [i for c in D.coalesce_batches([3, 1, 2, 3, 2, 24, 5, 19, 1], 24) for i in c]
+    assert flat == list(range(9))
+
+    def draws(order):
+        torch.manual_seed(7)
+        base = D._draw_seed()
+        out = {}
+        for i in order:                                   # jobs picked up in any order by the lanes
+            with D._job_seeds(D._job_generator(base, i)):
+                out[i] = (D._draw_seed(), D._draw_seed())
+        return out
+    a, b = draws([0, 1, 2, 3]), draws([3, 1, 0, 2])
+    assert a == b
+    assert len({v for pair in a.values() for v in pair}) == 8
+    torch.manual_seed(8)
+    assert D._draw_seed() != draws([0])[0][0]
+    # outside a job the process-wide generator is used, as in the reference
+    torch.manual_seed(3); x = D._draw_seed(); torch.manual_seed(3); assert D._draw_seed() == x
+
+
+def test_greedy_decoder_update_returns_fresh_tensors_to_external_callers():
+    """ADVICE round 5: GreedyDecoder.update must not alias the tensor an earlier call returned (reference decoding.py:290 is a torch.cat);
+    the in-place append is reserved for DecodingTask's own host loop."""
+    from whisper_amd.decoding import GreedyDecoder
+    dec = GreedyDecoder(0.0, eot=9)
+    tokens = torch.tensor([[1, 2], [3, 4]])
+    logits = torch.zeros(2, 10); logits[0, 5] = 1.0; logits[1, 6] = 1.0
+    s0 = torch.zeros(2)
+    t1, _ = dec.update(tokens, logits.clone(), s0)
+    logits2 = torch.zeros(2, 10); logits2[0, 7] = 1.0; logits2[1, 8] = 1.0
+    t2a, _ = dec.update(t1, logits2.clone(), s0)
+    t2b, _ = dec.update(t1, logits.clone(), s0)           # branching from the same prefix again
+    assert t1.tolist() == [[1, 2, 5], [3, 4, 6]]
+    assert t2a.tolist() == [[1, 2, 5, 7], [3, 4, 6, 8]] and t2b.tolist() == [[1, 2, 5, 5], [3, 4, 6, 6]]
+    assert t2a.data_ptr() != t2b.data_ptr() and t1.shape[1] == 3

@@ -1028,6 +1028,22 @@ def run_interleaved(model: "Whisper", jobs: Sequence, in_flight: int = 3, dtype:
     return results
 
 
+def coalesce_batches(rows: Sequence[int], chain_rows: Optional[int]) -> List[List[int]]:
+    """Indices of consecutive batches grouped into decode chains: a batch joins the chain before it while the chain's rows
+    (clips x beams / samples) stay within `chain_rows`; a batch that is wider than `chain_rows` by itself is a chain of its own;
+    None / 0 = no coalescing.  Order is kept, every index appears exactly once."""
+    chains: List[List[int]] = []
+    total = 0
+    for i, r in enumerate(rows):
+        if chains and chain_rows and total + r <= chain_rows:
+            chains[-1].append(i)
+            total += r
+        else:
+            chains.append([i])
+            total = r
+    return chains
+
+
 def decode_many(model: "Whisper", mels: Sequence[Tensor], options: DecodingOptions = DecodingOptions(), in_flight: int = 3,
                 chain_rows: Optional[int] = 24, **kwargs) -> List[List[DecodingResult]]:
     """`decode(model, mel, options)` for every batch of `mels` — each a (B, n_mels, 3000) tensor, or raw (B, 480000) audio (its
@@ -1052,14 +1068,10 @@ def decode_many(model: "Whisper", mels: Sequence[Tensor], options: DecodingOptio
     def rows_of(m: Tensor) -> int:
         return (m.shape[0] if m.dim() >= 2 else 1) * group
 
-    chains: List[List[int]] = []
-    for i, m in enumerate(mels):
+    for m in mels:
         if m.dim() < 2:
             raise ValueError("decode_many takes batches: (B, n_mels, 3000) spectrograms or (B, 480000) audio")
-        if (chains and chain_rows and sum(rows_of(mels[j]) for j in chains[-1]) + rows_of(m) <= chain_rows):
-            chains[-1].append(i)
-        else:
-            chains.append([i])
+    chains = coalesce_batches([rows_of(m) for m in mels], chain_rows)
 
     def chain_steps(idx: List[int]):
         parts = []
