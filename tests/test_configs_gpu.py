@@ -178,3 +178,37 @@ def test_decode_many_coalesces_batches_into_one_chain(gpu_device):
         # chains) where decode() alone uses the fused launch: the fp32 partial sums meet in another order there
         assert same == 24 if not fp16 else same >= 22, same
         eng.drop_cached_tasks()
+
+
+def test_ragged_prompts_in_a_20_row_chain(gpu_device):
+    """Rows of ONE decode chain with previous-text prompts of different lengths (wh_task_set_lag) at the row counts of round 6's chains:
+    20 rows at large-v3 widths (2 + 2 layers) — the row-tiled projections' cache append at `*d_pos - lag[r]`, the per-row self-attention
+    lengths, the sampler's per-row sample_begin, with three row tiles per weight fragment.  tests/test_api_gpu.py covers this at 6 rows
+    (the <= 8-row kernels) only; transcribe_batch(batch_size = 16 .. 24, condition_on_previous_text=True) runs exactly this.
+    Every row against the same segment decoded ALONE with options.prompt: fp32 engine ids exact, avg_logprob to 1e-4; fp16 engine at
+    least 18 of 20 rows identical over 16 steps on these random-init weights (a batched and a single-row decode sum in different
+    orders), avg_logprob within 2e-2 where the ids agree."""
+    import whisper_amd
+    from whisper_amd.model import ModelDimensions, Whisper
+    from oracle.model import dims_dict
+    dims = oracle.dims_for("wide-v3")
+    sd = oracle.synthetic_state_dict(dims, seed=3)
+    model = Whisper(ModelDimensions(**dims_dict(dims)), sd, device=gpu_device)
+    R = 20
+    rng = np.random.default_rng(11)
+    lengths = [0, 1, 5, 17, 40, 3, 0, 9, 60, 2] * 2
+    prompts = [None if n == 0 else rng.integers(300, 40000, n).tolist() for n in lengths]
+    audio = torch.from_numpy(_clips(R, seed0=300)).to(gpu_device)
+    mel = whisper_amd.log_mel_spectrogram(audio, dims.n_mels)
+    for fp16 in (False, True):
+        opts = whisper_amd.DecodingOptions(language="en", fp16=fp16, sample_len=16)
+        got = whisper_amd.decode(model, mel, opts, prompts=prompts)
+        same = 0
+        for i, p in enumerate(prompts):
+            want = whisper_amd.decode(model, mel[i], opts, prompt=p)
+            if got[i].tokens == want.tokens:
+                same += 1
+                assert abs(got[i].avg_logprob - want.avg_logprob) < (2e-2 if fp16 else 1e-4), (fp16, i)
+            else:
+                assert fp16, (i, got[i].tokens, want.tokens)          # the fp32 engine is exact
+        assert same >= (18 if fp16 else R), (fp16, same)
