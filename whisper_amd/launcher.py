@@ -100,7 +100,7 @@ def _audio_cost(audio) -> float:
     return float(getattr(audio, "shape", [1])[-1])
 
 
-def transcribe_sharded(model, audios: Sequence[Any], dist=None, *, batch_size: int = 16, **kwargs) -> Optional[List[dict]]:
+def transcribe_sharded(model, audios: Sequence[Any], dist=None, *, batch_size: int = 24, **kwargs) -> Optional[List[dict]]:
     """Many files over many GPUs: every rank transcribes its cost-balanced share with `transcribe_batch` (windows of
     one file never leave their rank: seek and prompt depend on the previous window, transcribe.py:288-293,371-399);
     rank 0 returns the result dicts in input order, other ranks None.  All inputs must be of one kind (arrays or
