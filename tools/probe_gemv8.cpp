@@ -56,8 +56,42 @@ int main(int argc, char** argv) {
     {"LN->fc1 gelu (4D x D)", whk::PRO_LN, whk::EPI_GELU, 4 * D, D, (size_t)6 * D * D},
     {"plain->fc2 resid (Dx4D)", whk::PRO_PLAIN, whk::EPI_RESID, D, 4 * D, (size_t)10 * D * D},
   };
+  // PROBE_FRAG=1: the PRO_PLAIN x rows in fragment order (kernels.h); checked once against the row-major launch
+  // (the weights in fragment order were measured with an earlier form of this probe: profiles/r06_fragment_order.txt)
+  const bool frag = getenv("PROBE_FRAG") && atoi(getenv("PROBE_FRAG")), fragx = frag;
+  half_t* xh_frag = nullptr;
+  if (frag) {
+    const int Rp = (R + 7) / 8 * 8;
+    CK(hipMalloc(&xh_frag, (size_t)Rp * 4 * D * 2)); CK(hipMemset(xh_frag, 0, (size_t)Rp * 4 * D * 2));
+  }
   for (const Case& c : cases) for (int variant : {0, 99}) {
-    if (variant == 99 && getenv("PROBE_MFMA_ONLY")) continue;
+    if (variant == 99 && (getenv("PROBE_MFMA_ONLY") || frag)) continue;
+    if (frag) {
+      if (c.pro == whk::PRO_PLAIN) {
+        std::vector<half_t> h((size_t)R * c.K), hf((size_t)((R + 7) / 8 * 8) * c.K, (half_t)0.f);
+        CK(hipMemcpy(h.data(), xh, h.size() * 2, hipMemcpyDeviceToHost));
+        for (int r = 0; r < R; ++r) for (int k = 0; k < c.K; ++k) hf[whk::frag_index(r, k, c.K)] = h[(size_t)r * c.K + k];
+        CK(hipMemcpy(xh_frag, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
+      }
+      // one launch each way from the same inputs
+      std::vector<float> res0((size_t)R * D), o0, o1;
+      CK(hipMemcpy(res0.data(), resid, res0.size() * 4, hipMemcpyDeviceToHost));
+      for (int way = 0; way < 2; ++way) {
+        whk::GemvArgs a; memset(&a, 0, sizeof(a));
+        a.pro = c.pro; a.x = way && fragx && c.pro == whk::PRO_PLAIN ? xh_frag : xh; a.x_frag = way && fragx && c.pro == whk::PRO_PLAIN; a.x_ld = c.K; a.xf = xf; a.xf_ld = D; a.ln_w = lnw; a.ln_b = lnb; a.ln_folded = 1;
+        a.part_o = part_o; a.part_ml = part_ml; a.splits = 3; a.H = H;
+        a.W = W + c.woff; a.bias = bias; a.N = c.Nn; a.K = c.K; a.R = R;
+        a.epi = c.epi; a.y = y; a.y_ld = c.Nn; a.resid = resid; a.resid_ld = D;
+        CK(hipMemcpy(resid, res0.data(), res0.size() * 4, hipMemcpyHostToDevice));
+        CK(whk::launch_gemv(a, 1, st)); CK(hipStreamSynchronize(st));
+        std::vector<float>& o = way ? o1 : o0;
+        if (c.epi == whk::EPI_RESID) { o.resize((size_t)R * D); CK(hipMemcpy(o.data(), resid, o.size() * 4, hipMemcpyDeviceToHost)); }
+        else { std::vector<half_t> hy((size_t)R * c.Nn); CK(hipMemcpy(hy.data(), y, hy.size() * 2, hipMemcpyDeviceToHost)); o.assign(hy.begin(), hy.end()); }
+      }
+      size_t nd = 0; for (size_t i = 0; i < o0.size(); ++i) nd += !(o0[i] == o1[i]);
+      printf("%-26s fragment order vs row-major: %zu of %zu outputs differ\n", c.name, nd, o0.size());
+      CK(hipMemcpy(resid, res0.data(), res0.size() * 4, hipMemcpyHostToDevice));
+    }
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     bool ok = true;
@@ -66,6 +100,7 @@ int main(int argc, char** argv) {
       a.pro = c.pro; a.x = xh; a.x_ld = c.K; a.xf = xf; a.xf_ld = D; a.ln_w = lnw; a.ln_b = lnb; a.ln_folded = 1;
       a.part_o = part_o; a.part_ml = part_ml; a.splits = 3; a.H = H;
       a.W = W + wl * (i % L) + c.woff; a.bias = bias; a.N = c.Nn; a.K = c.K; a.R = R;
+      if (fragx && c.pro == whk::PRO_PLAIN) { a.x = xh_frag; a.x_frag = 1; }
       a.epi = c.epi; a.y = y; a.y_ld = c.Nn; a.resid = resid; a.resid_ld = D;
       a.probe = i == N - 1 ? d_probe : nullptr;
       a.variant = variant == 99 ? -1 : variant;      // -1: the v_dot2 kernels

@@ -393,8 +393,10 @@ static void task_carve(wh_task* t, void* base) {
   t->x = (float*)c.take(Mx * D * 4);
   t->xn = c.take(Mx * D * es);
   t->qkv = c.take(Mx * 3 * D * es);
-  t->att = c.take(Mx * D * es);
-  t->h = c.take(Mx * 4 * D * es);
+  // (att, h may be written in fragment order — kernels.h — whose units span 8 rows: whole row tiles must exist)
+  const size_t Mx8 = std::max(Mx, (R + 7) / 8 * 8);
+  t->att = c.take(Mx8 * D * es);
+  t->h = c.take(Mx8 * 4 * D * es);
   t->qbuf = c.take(R * D * es);
   // the few-row prefill (<= SKINNY_ROWS rows x tokens) runs its cross attention through the decode kernel: one partial per (row, token)
   size_t Rp = Mx < (size_t)SKINNY_ROWS ? Mx : (size_t)SKINNY_ROWS;
@@ -842,6 +844,14 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
   // applies attn.out writes the OTHER buffer (its LayerNorm input is still being read), so the pointer alternates
   float* xc = t->x;
   float* xo = t->x2;
+  // Fragment-order hand-offs (kernels.h): an activation that goes from one launch of the step straight into a PRO_PLAIN projection
+  // is written by its producer in the order that projection's lanes read it — only where BOTH ends are launches that know the
+  // order (fp16, <= 24 rows: gemv8_kernel).  A/B: WH_NO_FRAGMENT_ORDER=1.
+  const bool frag_on = m->dtype == WH_F16 && !WH_DEV_FLAG("WH_NO_FRAGMENT_ORDER");
+  const bool frag_att = frag_on && gemv8_will_run(R, D, D, PRO_PLAIN);                     // attention output -> D x D projection
+  const bool frag_self = frag_att && !t->fused_sattn && !t->fused_xout && t->self_splits <= 1;
+  const bool frag_mlp = frag_on && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) && gemv8_will_run(R, 4 * D, D, PRO_LN) &&
+                        gemv8_will_run(R, D, 4 * D, PRO_PLAIN);                           // FC1 -> FC2
   for (int l = 0; l < d.n_text_layer; ++l) {
     const wh_layer_weights& L = m->dec[l];
     GemvArgs g;
@@ -866,7 +876,7 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
       a.v = self_v_layer(t, l); a.v_ld = D; a.v_bs = (int64_t)C * D;
       a.H = H; a.R = R; a.kv_group = 1; a.d_len = t->d_pos; a.len_plus = 1; a.splits = t->self_splits;
       a.lag = t->d_lag;
-      a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
+      a.out = t->att; a.o_ld = D; a.o_frag = frag_self; a.part_o = t->part_o; a.part_ml = t->part_ml;
       HIPCHK(launch_attn_decode(a, m->dtype, s));
     }
     }
@@ -876,7 +886,7 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
     if (t->self_splits > 1) {
       g.pro = PRO_COMBINE; g.part_o = t->part_o; g.part_ml = t->part_ml; g.splits = t->self_splits; g.H = H;
     } else {
-      g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D;
+      g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D; g.x_frag = frag_self;
     }
     g.W = L.out_w; g.bias = L.out_b; g.N = D; g.K = D; g.R = R;
     g.epi = EPI_RESID; g.resid = xc; g.resid_ld = D;
@@ -911,8 +921,8 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
     // again, so the merge is a launch of its own there (A/B: WH_NO_MERGE_KERNEL=1)
     const bool merge_kernel = !WH_DEV_FLAG("WH_NO_MERGE_KERNEL");   // developer A/B switch
     if (t->cross_splits > 1 && R > 16 && m->dtype == WH_F16 && merge_kernel) {   // the fp32 engine keeps one code path
-      HIPCHK(launch_merge_partials(t->part_o, t->part_ml, t->cross_splits, R, H, t->att, D, m->dtype, s));
-      g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D;
+      HIPCHK(launch_merge_partials(t->part_o, t->part_ml, t->cross_splits, R, H, t->att, D, m->dtype, s, frag_att));
+      g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D; g.x_frag = frag_att;
     } else if (t->cross_splits > 1) {
       g.pro = PRO_COMBINE; g.part_o = t->part_o; g.part_ml = t->part_ml; g.splits = t->cross_splits; g.H = H;
     } else {
@@ -925,10 +935,10 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
     memset(&g, 0, sizeof(g));
     g.pro = PRO_LN; g.xf = xc; g.xf_ld = D; g.ln_w = L.mlp_ln_w; g.ln_b = L.mlp_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
     g.W = L.fc1_w; g.bias = L.fc1_b; g.N = 4 * D; g.K = D; g.R = R;
-    g.epi = EPI_GELU; g.y = t->h; g.y_ld = 4 * D;
+    g.epi = EPI_GELU; g.y = t->h; g.y_ld = 4 * D; g.y_frag = frag_mlp;
     HIPCHK(launch_gemv(g, m->dtype, s));
     memset(&g, 0, sizeof(g));
-    g.pro = PRO_PLAIN; g.x = t->h; g.x_ld = 4 * D;
+    g.pro = PRO_PLAIN; g.x = t->h; g.x_ld = 4 * D; g.x_frag = frag_mlp;
     g.W = L.fc2_w; g.bias = L.fc2_b; g.N = D; g.K = 4 * D; g.R = R;
     g.epi = EPI_RESID; g.resid = xc; g.resid_ld = D;
     HIPCHK(launch_gemv(g, m->dtype, s));

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArg
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) { o += red[w][tid]; l += reds[w]; }
     if (S == 1) {
-      ((T*)a.out)[(int64_t)r * a.o_ld + h * 64 + tid] = from_f32<T>(o / l);
+      ((T*)a.out)[a.o_frag ? frag_elem(r, h * 64 + tid, a.H * 64) : (int64_t)r * a.o_ld + h * 64 + tid] = from_f32<T>(o / l);
     } else {
       // split-major partials [split][row][head]: the consumer projection reads, per split, one contiguous
       // [row][head][64] block with the same lane map; o is stored NORMALISED (o / l) in the element type
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_group_kernel(whk::DecA
     for (int w = 1; w < WAVES; ++w) { o += red[w][g][d]; l += reds[w][g]; }
     const int r = b * G + g;
     if (S == 1) {
-      ((T*)a.out)[(int64_t)r * a.o_ld + h * 64 + d] = from_f32<T>(o / l);
+      ((T*)a.out)[a.o_frag ? frag_elem(r, h * 64 + d, a.H * 64) : (int64_t)r * a.o_ld + h * 64 + d] = from_f32<T>(o / l);
     } else {
       const int64_t pi = ((int64_t)s * a.R + r) * a.H + h;
       ((T*)a.part_o)[pi * 64 + d] = from_f32<T>(nkeys > 0 ? o / l : 0.f);
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_group_mfma_kernel(whk:
     for (int w = 1; w < WAVES; ++w) { o += red_o[w][g][d]; l += red_l[w][g]; m = fmaxf(m, red_m[w][g]); }
     const int r = b * G + g;
     if (S == 1) {
-      ((half_t*)a.out)[(int64_t)r * a.o_ld + h * 64 + d] = (half_t)(o / l);
+      ((half_t*)a.out)[a.o_frag ? frag_elem(r, h * 64 + d, a.H * 64) : (int64_t)r * a.o_ld + h * 64 + d] = (half_t)(o / l);
     } else {
       const int64_t pi = ((int64_t)s * a.R + r) * a.H + h;
       ((half_t*)a.part_o)[pi * 64 + d] = (half_t)(nkeys > 0 ? o / l : 0.f);
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_group_diag_kernel(whk:
     for (int w = 1; w < WAVES; ++w) { o += red_o[w][g][d]; l += red_l[w][g]; m = fmaxf(m, red_m[w][g]); }
     const int r = b * G + g;
     if (S == 1) {
-      ((half_t*)a.out)[(int64_t)r * a.o_ld + h * 64 + d] = (half_t)(o / l);
+      ((half_t*)a.out)[a.o_frag ? frag_elem(r, h * 64 + d, a.H * 64) : (int64_t)r * a.o_ld + h * 64 + d] = (half_t)(o / l);
     } else {
       const int64_t pi = ((int64_t)s * a.R + r) * a.H + h;
       ((half_t*)a.part_o)[pi * 64 + d] = (half_t)(nkeys > 0 ? o / l : 0.f);

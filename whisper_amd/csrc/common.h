@@ -76,6 +76,11 @@ __device__ __forceinline__ float gelu_erf_f16out(float x) {
   const float half_erfc = 0.5f * t * q * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);   // erfc(|x|/sqrt2) / 2
   return x * (x >= 0.f ? 1.0f - half_erfc : half_erfc);
 }
+// element index of x[r][k] in a FRAGMENT-ORDER activation of K columns (kernels.h, GemvArgs::x_frag): unit (row tile, K block) = 1 KB,
+// lane 16 ((k & 31) >> 3) + 8 ((k >> 5) & 1) + r % 8 holds the 8 elements [k & ~7, +8)
+__device__ __forceinline__ int64_t frag_elem(int64_t r, int k, int K) {
+  return ((((r >> 3) * (K >> 6) + (k >> 6)) * 64 + 16 * ((k & 31) >> 3) + 8 * ((k >> 5) & 1) + (r & 7)) << 3) + (k & 7);
+}
 template <typename T> __device__ __forceinline__ float gelu_for(float x);
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
 template <> __device__ __forceinline__ float gelu_for<half_t>(float x) { return gelu_erf_f16out(x); }

@@ -823,14 +823,28 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
       wa[u] = WH_WEIGHT_LOAD((const half8v*)((const char*)a.W + (size_t)blk * 128 + lane_off));
     }
     if (PRO == whk::PRO_PLAIN) {
+      if (a.x_frag) {
+        // fragment-order rows: unit (row tile, K block) = 1 KB, lane-linear (rows beyond R hold whatever the producer left:
+        // they only reach output columns that are dropped)
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) {
-        int rr = rt * 8 + idx; if (rr > R - 1) rr = R - 1;  // padded rows re-read a valid row; their outputs are dropped
-        const uint32_t xoff = ((uint32_t)(r0 + rr) * (uint32_t)a.x_ld + (uint32_t)koff) * 2u;
+        for (int rt = 0; rt < NRT; ++rt) {
+          const char* tile = (const char*)a.x + (size_t)((r0 >> 3) + rt) * nblk * 1024 + (uint32_t)lane * 16u;
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-          int blk = kw + KS * u; if (blk > nblk - 1) blk = nblk - 1;
-          xb[rt][u] = *(const half8v*)((const char*)a.x + (size_t)blk * 128 + xoff);
+          for (int u = 0; u < NU; ++u) {
+            int blk = kw + KS * u; if (blk > nblk - 1) blk = nblk - 1;
+            xb[rt][u] = *(const half8v*)(tile + (size_t)blk * 1024);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+          int rr = rt * 8 + idx; if (rr > R - 1) rr = R - 1;  // padded rows re-read a valid row; their outputs are dropped
+          const uint32_t xoff = ((uint32_t)(r0 + rr) * (uint32_t)a.x_ld + (uint32_t)koff) * 2u;
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            int blk = kw + KS * u; if (blk > nblk - 1) blk = nblk - 1;
+            xb[rt][u] = *(const half8v*)((const char*)a.x + (size_t)blk * 128 + xoff);
+          }
         }
       }
     }
@@ -1041,8 +1055,8 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
       const int64_t rr = r0 + ert * 8 + er;
       const int n = en;
       switch (a.epi) {
-        case whk::EPI_STORE: ((half_t*)a.y)[rr * a.y_ld + n] = (half_t)v; break;
-        case whk::EPI_GELU: ((half_t*)a.y)[rr * a.y_ld + n] = (half_t)gelu_erf(v); break;
+        case whk::EPI_STORE: ((half_t*)a.y)[a.y_frag ? frag_elem(rr, n, a.N) : rr * a.y_ld + n] = (half_t)v; break;
+        case whk::EPI_GELU: ((half_t*)a.y)[a.y_frag ? frag_elem(rr, n, a.N) : rr * a.y_ld + n] = (half_t)gelu_erf(v); break;
         case whk::EPI_F32: ((float*)a.y)[rr * a.y_ld + n] = v; break;
         case whk::EPI_RESID: a.resid[rr * a.resid_ld + n] = e_res[j] + v; break;
         case whk::EPI_QKV: {
@@ -1102,22 +1116,37 @@ static int gemv8_fw(int N, int gs) {
 //   D x D [160 workgroups] and 3D x D [2 feature-group slots, 240 workgroups]: 8 prologue waves, one row each;
 //   4D x D: 3 slots [214 workgroups of 4 + 12 waves] — a launch costs about
 //   1.5 us + (12.6 cycles x HBM lines + 3.7 cycles x L2 lines requested by the busiest CU) / clock.
+// feature-group slots per workgroup for (N, prologue) — the one place the launcher and the fragment-order packer take it from
+static int gemv8_slots(int N, int pro) {
+  const int ngroups = (N + 7) / 8;
+  if (pro == whk::PRO_LN) return ngroups >= 600 ? 3 : ngroups >= 400 ? 2 : 1;
+  return 1;
+}
+
 template <int PRO, int CSm>
 hipError_t launch_gemv8_pro(const whk::GemvArgs& a, hipStream_t stream) {
-  const int nblk = a.K / 64, ngroups = (a.N + 7) / 8;
+  const int nblk = a.K / 64, gs = gemv8_slots(a.N, PRO), fw = gemv8_fw(a.N, gs);
   if constexpr (PRO == whk::PRO_PLAIN) {
-    if (nblk > 20) return launch_gemv8_cfg<PRO, 1, 16, CSm, 0>(a, gemv8_fw(a.N, 1), stream);
-    return launch_gemv8_cfg<PRO, 1, 4, CSm, 0>(a, gemv8_fw(a.N, 1), stream);
+    if (nblk > 20) return launch_gemv8_cfg<PRO, 1, 16, CSm, 0>(a, fw, stream);
+    return launch_gemv8_cfg<PRO, 1, 4, CSm, 0>(a, fw, stream);
   } else {
     if (nblk > 20) return hipErrorNotSupported;              // the prologue waves cover K <= 1280
     if constexpr (PRO == whk::PRO_LN) {
-      if (ngroups >= 600) return launch_gemv8_cfg<PRO, 3, 4, CSm, 4>(a, gemv8_fw(a.N, 3), stream);
-      if (ngroups >= 400) return launch_gemv8_cfg<PRO, 2, 4, CSm, 8>(a, gemv8_fw(a.N, 2), stream);
+      if (gs == 3) return launch_gemv8_cfg<PRO, 3, 4, CSm, 4>(a, fw, stream);
+      if (gs == 2) return launch_gemv8_cfg<PRO, 2, 4, CSm, 8>(a, fw, stream);
     }
-    return launch_gemv8_cfg<PRO, 1, 4, CSm, 8>(a, gemv8_fw(a.N, 1), stream);
+    return launch_gemv8_cfg<PRO, 1, 4, CSm, 8>(a, fw, stream);
   }
 }
 
+static bool gemv8_covers(int N, int K, int pro) {
+  if (K % 64 != 0) return false;
+  const int nblk = K / 64;
+  if (nblk > 20 ? (nblk + 15) / 16 > 5 : (nblk + 3) / 4 > 5) return false;
+  if (pro != whk::PRO_PLAIN && nblk > 20) return false;
+  if ((int64_t)N * K >= (1ll << 31)) return false;
+  return true;
+}
 bool gemv8_enabled() {
   return !WH_DEV_FLAG("WH_GEMV_DOT2");      // developer switch: the round-1 v_dot2 kernels instead
 }
@@ -1452,7 +1481,7 @@ hipError_t launch_rows48_stream(const whk::GemvArgs& a, hipStream_t stream) {
 // Same operations in the same order as the fused fast path above (S <= 4): the fp16 values are identical.
 template <typename T, int MS>      // MS: splits held in registers (>= S)
 __global__ __launch_bounds__(256) void merge_partials_kernel(const T* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                             int S, int R, int H, T* __restrict__ out, int64_t o_ld) {
+                                                             int S, int R, int H, T* __restrict__ out, int64_t o_ld, int o_frag) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= R * H * 16) return;
   const int r = i / (H * 16), rem = i - r * (H * 16);
@@ -1483,7 +1512,8 @@ __global__ __launch_bounds__(256) void merge_partials_kernel(const T* __restrict
     num[0] = __builtin_fmaf(f, o[s][0], num[0]); num[1] = __builtin_fmaf(f, o[s][1], num[1]);
     num[2] = __builtin_fmaf(f, o[s][2], num[2]); num[3] = __builtin_fmaf(f, o[s][3], num[3]);
   }
-  Pack4<T>::store(out + (int64_t)r * o_ld + h * 64 + d4 * 4, num[0], num[1], num[2], num[3]);
+  // o_frag: fragment order for the projection that follows (kernels.h); the 4 values stay inside one 16-byte piece
+  Pack4<T>::store(out + (o_frag ? frag_elem(r, h * 64 + d4 * 4, H * 64) : (int64_t)r * o_ld + h * 64 + d4 * 4), num[0], num[1], num[2], num[3]);
 }
 
 }  // namespace
@@ -1527,21 +1557,26 @@ hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream) {
   return launch_rt<float, 8>(a, stream);
 }
 
+// true when launch_gemv hands (R rows, fp16) x (N, K, pro) to gemv8_kernel — the only kernel that reads x_frag and writes y_frag
+bool gemv8_will_run(int R, int N, int K, int pro) {
+  return gemv8_enabled() && R >= 1 && R <= WH_GEMV8_MAX_ROWS && gemv8_covers(N, K, pro);
+}
+
 hipError_t launch_merge_partials(const void* part_o, const float* part_ml, int splits, int R, int H, void* out,
-                                 int64_t o_ld, int dtype, hipStream_t stream) {
+                                 int64_t o_ld, int dtype, hipStream_t stream, int o_frag) {
   if (splits < 1 || splits > DEC_ATTN_MAX_SPLITS || R <= 0 || H <= 0) return hipErrorInvalidValue;
   const int n = R * H * 16;
   const dim3 grid((n + 255) / 256), block(256);
   if (dtype == 1) {
     if (splits <= 4)
-      hipLaunchKernelGGL((merge_partials_kernel<half_t, 4>), grid, block, 0, stream, (const half_t*)part_o, part_ml, splits, R, H, (half_t*)out, o_ld);
+      hipLaunchKernelGGL((merge_partials_kernel<half_t, 4>), grid, block, 0, stream, (const half_t*)part_o, part_ml, splits, R, H, (half_t*)out, o_ld, o_frag);
     else
-      hipLaunchKernelGGL((merge_partials_kernel<half_t, DEC_ATTN_MAX_SPLITS>), grid, block, 0, stream, (const half_t*)part_o, part_ml, splits, R, H, (half_t*)out, o_ld);
+      hipLaunchKernelGGL((merge_partials_kernel<half_t, DEC_ATTN_MAX_SPLITS>), grid, block, 0, stream, (const half_t*)part_o, part_ml, splits, R, H, (half_t*)out, o_ld, o_frag);
   } else {
     if (splits <= 4)
-      hipLaunchKernelGGL((merge_partials_kernel<float, 4>), grid, block, 0, stream, (const float*)part_o, part_ml, splits, R, H, (float*)out, o_ld);
+      hipLaunchKernelGGL((merge_partials_kernel<float, 4>), grid, block, 0, stream, (const float*)part_o, part_ml, splits, R, H, (float*)out, o_ld, o_frag);
     else
-      hipLaunchKernelGGL((merge_partials_kernel<float, DEC_ATTN_MAX_SPLITS>), grid, block, 0, stream, (const float*)part_o, part_ml, splits, R, H, (float*)out, o_ld);
+      hipLaunchKernelGGL((merge_partials_kernel<float, DEC_ATTN_MAX_SPLITS>), grid, block, 0, stream, (const float*)part_o, part_ml, splits, R, H, (float*)out, o_ld, o_frag);
   }
   return hipGetLastError();
 }

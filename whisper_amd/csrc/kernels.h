@@ -130,6 +130,7 @@ struct DecAttnArgs {
   const int* lag;                                 // with d_len: row r holds lag[r] fewer keys (ragged prompts); may be null
   int splits;                                     // key-range splits
   void* out; int64_t o_ld;                        // splits==1: normalized output, element type
+  int o_frag;                                     // splits==1, fp16: write `out` in fragment order (GemvArgs::x_frag below); o_ld ignored
   void* part_o; float* part_ml;                   // splits>1: [S][R][H][64] element type, normalised (o / l); (m, l) fp32 [S][R][H][2]
   // beam groups, fp16: V transposed per audio, row h*64+d holds the keys of head dim d (row stride vt_ld >= the
   // padded key count, pad columns finite).  With it the group kernel runs on the matrix cores; null: vector ALU form
@@ -209,6 +210,9 @@ struct GemvArgs {
   const void* part_o; const float* part_ml; int splits; int H;  // PRO_COMBINE: [S][R][H][64] element type, [S][R][H][2]
   // weights
   const void* W; const float* bias; int N; int K; int R;
+  // gemv8_kernel only (fp16, R <= 24; every other kernel ignores them — set them only where gemv8_will_run says so):
+  int x_frag;                                     // PRO_PLAIN: x holds FRAGMENT-ORDER rows (below), K columns; x_ld ignored
+  int y_frag;                                     // EPI_STORE / EPI_GELU: write y in fragment order (N % 64 == 0); y_ld ignored
   // epilogue
   int epi;
   void* y; int64_t y_ld;                          // EPI_STORE / EPI_GELU (element type), EPI_F32 (float)
@@ -221,9 +225,25 @@ struct GemvArgs {
   WH_PROBE_FIELD
 };
 hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream);
+// Fragment order (fp16 activations that only travel from one launch of a decode step to the next: self-attention output ->
+// attn.out, merged cross-attention output -> cross_attn.out, FC1 -> FC2).  A wave-load is 64 lanes x 16 bytes, and the memory
+// pipeline of a CU takes ~58 cycles for one whose CONSECUTIVE lanes sit in different cache lines — the MFMA operand map read
+// straight from row-major rows: lane 16 c + 8 half + i = row i, bytes 64 half + 16 c of a 128-byte block — against ~19.5 when
+// lane l reads bytes [16 l, +16) of one contiguous KB (tools/ubench_ta.cpp, profiles/r06_fragment_order.txt: same 8 lines, same
+// bytes).  With 2 - 3 row tiles a weight wave of a PRO_PLAIN launch issues 10 - 15 such x loads behind its 5 weight loads, so
+// the PRODUCER writes the rows in the order the consumer's lanes want them: unit (row tile r / 8, K block k / 64) = 1 KB,
+// lane 16 ((k & 31) >> 3) + 8 ((k >> 5) & 1) + r % 8 holds elements [k & ~7, +8).  Rows up to the next multiple of 8 must exist
+// in the buffer (never written, read into output columns that are dropped).  FC2 of a 24-row step 11.0 -> 7.7 us, the D x D
+// projections 4.9 -> 3.9; the same order for the WEIGHTS was measured too and is not used (D x D 4.9 -> 5.6 us: the 640-byte
+// pieces of a 5-feature workgroup come off fewer HBM channels than five 128-byte lines 2.5 KB apart).
+// element offset of x[r][k] in a fragment-order activation of K columns (K % 64 == 0)
+static inline int64_t frag_index(int r, int k, int K) {
+  return ((((int64_t)(r >> 3) * (K >> 6) + (k >> 6)) * 64 + 16 * ((k & 31) >> 3) + 8 * ((k >> 5) & 1) + (r & 7)) << 3) + (k & 7);
+}
+bool gemv8_will_run(int R, int N, int K, int pro);      // launch_gemv(R rows of fp16) goes to gemv8_kernel for this shape
 // PRO_COMBINE's merge of the decode-attention partials as a launch of its own ([rows][H*64] in the element type)
 hipError_t launch_merge_partials(const void* part_o, const float* part_ml, int splits, int R, int H, void* out,
-                                 int64_t o_ld, int dtype, hipStream_t stream);
+                                 int64_t o_ld, int dtype, hipStream_t stream, int o_frag = 0);
 
 // ---- sampling.hip --------------------------------------------------------------------------
 struct SampleArgs {
