@@ -310,6 +310,7 @@ struct wh_task {
   unsigned long long* xq_gran; int* d_tick; int* d_err;
   unsigned long long* sq_gran;   // the same for self attention + QKV projection (q, new k, new v)
   unsigned long long* so_gran;   // ... and for the attention outputs handed to attn.out inside the same launch
+  int* merge_cnt;                // [R][H] tickets of the cross attention's in-launch merge (attention.hip), 0 between launches
   float* x2;                     // second residual-stream buffer: the fused self-attention launch reads x and writes x2 (or back)
   bool fused_xattn, fused_sattn, fused_out;   // fused_out: attn.out + residual inside the self-attention launch (dev builds)
   bool fused_xout;               // attn.out + residual as phase 0 of the fused cross-attention launch (xattn.hip, OUT0)
@@ -425,6 +426,7 @@ static void task_carve(wh_task* t, void* base) {
   t->x2 = (float*)c.take(R * D * 4);
   t->d_tick = (int*)c.take(256);
   t->d_err = t->d_tick + 16;
+  t->merge_cnt = (int*)c.take(R * H * 4);
   t->total = align_up(c.off, 256);
 }
 
@@ -534,6 +536,7 @@ static int task_reset_impl(wh_task* t, void* stream_) {
     HIPCHK(hipMemsetAsync(t->sq_gran, 0, (size_t)t->R * (3 * t->m->d.n_text_state / 2) * 8, s));
     HIPCHK(hipMemsetAsync(t->so_gran, 0, (size_t)t->R * (t->m->d.n_text_state / 2) * 8, s));
     HIPCHK(hipMemsetAsync(t->d_tick, 0, 256, s));
+    HIPCHK(hipMemsetAsync(t->merge_cnt, 0, (size_t)t->R * t->m->d.n_text_head * 4, s));
     if (t->cross_vt)        // pad columns of the transposed cross-attention V: finite forever after (wh_task_set_audio)
       HIPCHK(hipMemsetAsync(t->cross_vt, 0, (size_t)t->m->d.n_text_layer * t->B * t->m->d.n_text_state * t->vt_ld * t->m->esize, s));
   }
@@ -852,6 +855,12 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
   const bool frag_self = frag_att && !t->fused_sattn && !t->fused_xout && t->self_splits <= 1;
   const bool frag_mlp = frag_on && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) && gemv8_will_run(R, 4 * D, D, PRO_LN) &&
                         gemv8_will_run(R, D, 4 * D, PRO_PLAIN);                           // FC1 -> FC2
+  // Up to 16 rows the per-row cross attention (no beam groups) with 2 - 4 key splits merges its partials in the launch
+  // (attention.hip: the last workgroup of a (row, head) to finish), so cross_attn.out is a plain projection without a merge
+  // prologue: 9 / 12 / 16 rows 1753 / 1816 / 1999 -> 1701 / 1770 / 1973 us per step.  At 17 - 24 rows the tickets of 1440
+  // workgroups cost more than the merge launch they replace (24 rows 2448 -> 2471): that launch stays.  A/B: WH_NO_TAIL_MERGE=1.
+  const bool tail_merge = m->dtype == WH_F16 && !t->fused_xattn && t->G == 1 && R <= 16 && t->cross_splits >= 2 &&
+                          t->cross_splits <= 4 && !WH_DEV_FLAG("WH_NO_TAIL_MERGE");
   for (int l = 0; l < d.n_text_layer; ++l) {
     const wh_layer_weights& L = m->dec[l];
     GemvArgs g;
@@ -910,6 +919,7 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
       a.v = (char*)cross_layer(t, l) + (size_t)D * es; a.v_ld = 2 * D; a.v_bs = a.k_bs;
       a.H = H; a.R = R; a.kv_group = t->G; a.Tk = Ta; a.splits = t->cross_splits;
       a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
+      if (tail_merge) { a.merge_cnt = t->merge_cnt; a.o_frag = frag_att; }
       if (t->cross_vt) {
         a.vt = (char*)t->cross_vt + (size_t)l * t->B * D * t->vt_ld * es; a.vt_ld = t->vt_ld; a.vt_bs = (int64_t)D * t->vt_ld;
       }
@@ -920,7 +930,9 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
     // 17+ rows (beam search): the projection runs as 16-row workgroups that would each merge their rows' partials
     // again, so the merge is a launch of its own there (A/B: WH_NO_MERGE_KERNEL=1)
     const bool merge_kernel = !WH_DEV_FLAG("WH_NO_MERGE_KERNEL");   // developer A/B switch
-    if (t->cross_splits > 1 && R > 16 && m->dtype == WH_F16 && merge_kernel) {   // the fp32 engine keeps one code path
+    if (tail_merge) {                 // merged inside the attention launch by the last workgroup of each (row, head)
+      g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D; g.x_frag = frag_att;
+    } else if (t->cross_splits > 1 && R > 16 && m->dtype == WH_F16 && merge_kernel) {   // the fp32 engine keeps one code path
       HIPCHK(launch_merge_partials(t->part_o, t->part_ml, t->cross_splits, R, H, t->att, D, m->dtype, s, frag_att));
       g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D; g.x_frag = frag_att;
     } else if (t->cross_splits > 1) {

@@ -549,6 +549,81 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(whk::DecAttnArg
   if (lane == 0) reds[wave] = sum;
   __syncthreads();
   WH_PROBE_AT(a, wgid, 3);
+  if constexpr (sizeof(T) == 2) {
+    if (S > 1 && a.merge_cnt) {
+      // ---- the LAST of the S workgroups of (row, head) to get here merges the S partials itself — no merge launch (4.8 us
+      // per layer at 24 rows) and no PRO_COMBINE prologue in the projection that follows.  No workgroup waits for another:
+      // each publishes its partial with write-through (agent-scope) stores, drains them, and takes a ticket; the one that
+      // draws S - 1 knows all S partials are in memory, reads them with agent-scope loads and does merge_partials_kernel's
+      // arithmetic on the same fp16 partials (16 lanes x 4 head dims, same order of operations: bit-identical output).
+      // MI355X_MICROARCH.md "handoff": sc1 payload -> vmcnt(0) -> ticket; sc1 loads after the ticket.  The ticket counter is
+      // back at 0 when the launch ends.
+      typedef unsigned long long u64;
+      if (wave == 0) {
+        const int64_t pi = ((int64_t)s * a.R + r) * a.H + h;
+        if (lane < 16) {
+          float l = reds[0];
+#pragma unroll
+          for (int w = 1; w < WAVES; ++w) l += reds[w];
+          half4v hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float o = red[0][4 * lane + e];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) o += red[w][4 * lane + e];
+            hv[e] = (half_t)(nkeys > 0 ? o / l : 0.f);
+          }
+          __hip_atomic_store((u64*)((half_t*)a.part_o + pi * 64 + 4 * lane), __builtin_bit_cast(u64, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) {
+            const float2v ml = {nkeys > 0 ? mx : WH_NEG_INF, nkeys > 0 ? l : 0.f};
+            __hip_atomic_store((u64*)(a.part_ml + pi * 2), __builtin_bit_cast(u64, ml), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the partial is in memory, THEN the ticket
+        int* cnt = a.merge_cnt + r * a.H + h;
+        int ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket == S - 1) {
+          if (lane == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane < 16) {
+            constexpr int MS = 4;                                     // callers pass merge_cnt only with splits <= 4
+            float2v ml[MS];
+            float4v o[MS];
+#pragma unroll
+            for (int j = 0; j < MS; ++j) {
+              const int sc = j < S ? j : S - 1;                       // branch-free loads, clamped (as merge_partials_kernel)
+              const int64_t pb = ((int64_t)sc * a.R + r) * a.H + h;
+              ml[j] = __builtin_bit_cast(float2v, __hip_atomic_load((u64*)(a.part_ml + pb * 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+              const half4v hp = __builtin_bit_cast(half4v, __hip_atomic_load((u64*)((half_t*)a.part_o + pb * 64 + 4 * lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+              o[j] = float4v{(float)hp[0], (float)hp[1], (float)hp[2], (float)hp[3]};
+            }
+            float M = WH_NEG_INF;
+#pragma unroll
+            for (int j = 0; j < MS; ++j) { if (j >= S) ml[j] = float2v{WH_NEG_INF, 0.f}; M = fmaxf(M, ml[j][0]); }
+            float wgt[MS], den = 0.f;
+#pragma unroll
+            for (int j = 0; j < MS; ++j) {
+              wgt[j] = (ml[j][0] == WH_NEG_INF) ? 0.f : __expf(ml[j][0] - M);
+              den = __builtin_fmaf(wgt[j], ml[j][1], den);
+            }
+            const float inv = 1.0f / den;
+            float4v num = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < MS; ++j) {
+              const float f = wgt[j] * ml[j][1] * inv;
+              num[0] = __builtin_fmaf(f, o[j][0], num[0]); num[1] = __builtin_fmaf(f, o[j][1], num[1]);
+              num[2] = __builtin_fmaf(f, o[j][2], num[2]); num[3] = __builtin_fmaf(f, o[j][3], num[3]);
+            }
+            const half4v res = {(half_t)num[0], (half_t)num[1], (half_t)num[2], (half_t)num[3]};
+            *(half4v*)((half_t*)a.out + (a.o_frag ? frag_elem(r, h * 64 + 4 * lane, a.H * 64) : (int64_t)r * a.o_ld + h * 64 + 4 * lane)) = res;
+          }
+        }
+      }
+      WH_PROBE_AT(a, wgid, 4);
+      return;
+    }
+  }
   if (tid < 64) {
     float o = red[0][tid], l = reds[0];
 #pragma unroll

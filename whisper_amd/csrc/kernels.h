@@ -132,6 +132,9 @@ struct DecAttnArgs {
   void* out; int64_t o_ld;                        // splits==1: normalized output, element type
   int o_frag;                                     // splits==1, fp16: write `out` in fragment order (GemvArgs::x_frag below); o_ld ignored
   void* part_o; float* part_ml;                   // splits>1: [S][R][H][64] element type, normalised (o / l); (m, l) fp32 [S][R][H][2]
+  // fp16, kv_group == 1, 2 <= splits <= 4: [R][H] tickets, all 0 between launches.  With it the last workgroup of a (row, head)
+  // to finish merges the partials and writes `out` (o_ld / o_frag as for splits == 1): no merge launch, no PRO_COMBINE after it
+  int* merge_cnt;
   // beam groups, fp16: V transposed per audio, row h*64+d holds the keys of head dim d (row stride vt_ld >= the
   // padded key count, pad columns finite).  With it the group kernel runs on the matrix cores; null: vector ALU form
   const void* vt; int64_t vt_ld; int64_t vt_bs;
