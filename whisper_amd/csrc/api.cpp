@@ -835,6 +835,30 @@ static SAttnArgs sattn_args(const wh_task* t, int l, int epoch, const float* x_i
 }
 
 // ---- one decode step (all kernels read the position from *d_pos: graph-replayable) ---------------
+// How the launches of one decode step hand their activations on (decided once per task shape; step_launch and the per-kernel
+// bench below read the same plan).
+//  * Fragment-order hand-offs (kernels.h): an activation that goes from one launch straight into a PRO_PLAIN projection is written
+//    by its producer in the order that projection's lanes read it — only where BOTH ends are launches that know the order (fp16,
+//    <= 24 rows: gemv8_kernel).  A/B: WH_NO_FRAGMENT_ORDER=1.
+//  * Up to 16 rows the per-row cross attention (no beam groups) with 2 - 4 key splits merges its partials in the launch
+//    (attention.hip: the last workgroup of a (row, head) to finish), so cross_attn.out is a plain projection without a merge
+//    prologue: 9 / 12 / 16 rows 1753 / 1816 / 1999 -> 1701 / 1770 / 1973 us per step.  At 17 - 24 rows the tickets of 1440
+//    workgroups cost more than the merge launch they replace (24 rows 2448 -> 2471): that launch stays.  A/B: WH_NO_TAIL_MERGE=1.
+struct StepPlan { bool frag_att, frag_self, frag_mlp, tail_merge; };
+static StepPlan step_plan(const wh_task* t) {
+  const wh_model* m = t->m;
+  const int D = m->d.n_text_state, R = t->R;
+  StepPlan p;
+  const bool frag_on = m->dtype == WH_F16 && !WH_DEV_FLAG("WH_NO_FRAGMENT_ORDER");
+  p.frag_att = frag_on && gemv8_will_run(R, D, D, PRO_PLAIN);                              // attention output -> D x D projection
+  p.frag_self = p.frag_att && !t->fused_sattn && !t->fused_xout && t->self_splits <= 1;
+  p.frag_mlp = frag_on && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) && gemv8_will_run(R, 4 * D, D, PRO_LN) &&
+               gemv8_will_run(R, D, 4 * D, PRO_PLAIN);                                    // FC1 -> FC2
+  p.tail_merge = m->dtype == WH_F16 && !t->fused_xattn && t->G == 1 && R <= 16 && t->cross_splits >= 2 &&
+                 t->cross_splits <= 4 && !WH_DEV_FLAG("WH_NO_TAIL_MERGE");
+  return p;
+}
+
 static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
   const wh_model* m = t->m;
   const wh_dims& d = m->d;
@@ -847,20 +871,8 @@ static int step_launch(wh_task* t, hipStream_t s, bool embedded = false) {
   // applies attn.out writes the OTHER buffer (its LayerNorm input is still being read), so the pointer alternates
   float* xc = t->x;
   float* xo = t->x2;
-  // Fragment-order hand-offs (kernels.h): an activation that goes from one launch of the step straight into a PRO_PLAIN projection
-  // is written by its producer in the order that projection's lanes read it — only where BOTH ends are launches that know the
-  // order (fp16, <= 24 rows: gemv8_kernel).  A/B: WH_NO_FRAGMENT_ORDER=1.
-  const bool frag_on = m->dtype == WH_F16 && !WH_DEV_FLAG("WH_NO_FRAGMENT_ORDER");
-  const bool frag_att = frag_on && gemv8_will_run(R, D, D, PRO_PLAIN);                     // attention output -> D x D projection
-  const bool frag_self = frag_att && !t->fused_sattn && !t->fused_xout && t->self_splits <= 1;
-  const bool frag_mlp = frag_on && (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) && gemv8_will_run(R, 4 * D, D, PRO_LN) &&
-                        gemv8_will_run(R, D, 4 * D, PRO_PLAIN);                           // FC1 -> FC2
-  // Up to 16 rows the per-row cross attention (no beam groups) with 2 - 4 key splits merges its partials in the launch
-  // (attention.hip: the last workgroup of a (row, head) to finish), so cross_attn.out is a plain projection without a merge
-  // prologue: 9 / 12 / 16 rows 1753 / 1816 / 1999 -> 1701 / 1770 / 1973 us per step.  At 17 - 24 rows the tickets of 1440
-  // workgroups cost more than the merge launch they replace (24 rows 2448 -> 2471): that launch stays.  A/B: WH_NO_TAIL_MERGE=1.
-  const bool tail_merge = m->dtype == WH_F16 && !t->fused_xattn && t->G == 1 && R <= 16 && t->cross_splits >= 2 &&
-                          t->cross_splits <= 4 && !WH_DEV_FLAG("WH_NO_TAIL_MERGE");
+  const StepPlan plan = step_plan(t);
+  const bool frag_att = plan.frag_att, frag_self = plan.frag_self, frag_mlp = plan.frag_mlp, tail_merge = plan.tail_merge;
   for (int l = 0; l < d.n_text_layer; ++l) {
     const wh_layer_weights& L = m->dec[l];
     GemvArgs g;
@@ -1439,6 +1451,7 @@ static int bench_issue(wh_task* t, int kind, int iters, double* bytes_per_launch
   const int D = d.n_text_state, H = d.n_text_head, C = d.n_text_ctx, Ta = d.n_audio_ctx, V = d.n_vocab;
   const int R = t->R, Ln = d.n_text_layer;
   const double es = m->esize;
+  const StepPlan plan = step_plan(t);            // the kernels are timed in the form the step launches them in
   double bytes = 0;
   for (int i = 0; i < iters; ++i) {
     const int l = i % Ln;
@@ -1467,6 +1480,7 @@ static int bench_issue(wh_task* t, int kind, int iters, double* bytes_per_launch
         a.v = (char*)cross_layer(t, l) + (size_t)D * m->esize; a.v_ld = 2 * D; a.v_bs = a.k_bs;
         a.H = H; a.R = R; a.kv_group = t->G; a.Tk = Ta; a.splits = t->cross_splits;
         a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
+        if (plan.tail_merge) { a.merge_cnt = t->merge_cnt; a.o_frag = plan.frag_att; }
         HIPCHK(launch_attn_decode(a, m->dtype, s));
         bytes = (double)t->B * 2.0 * Ta * D * es;
       } break;
@@ -1480,7 +1494,7 @@ static int bench_issue(wh_task* t, int kind, int iters, double* bytes_per_launch
         a.k = self_k_layer(t, l); a.k_ld = D; a.k_bs = (int64_t)C * D;
         a.v = self_v_layer(t, l); a.v_ld = D; a.v_bs = (int64_t)C * D;
         a.H = H; a.R = R; a.kv_group = 1; a.d_len = t->d_pos; a.len_plus = 0; a.splits = t->self_splits;
-        a.out = t->att; a.o_ld = D; a.part_o = t->part_o; a.part_ml = t->part_ml;
+        a.out = t->att; a.o_ld = D; a.o_frag = plan.frag_self; a.part_o = t->part_o; a.part_ml = t->part_ml;
         HIPCHK(launch_attn_decode(a, m->dtype, s));
         bytes = (double)R * t->pos * 2.0 * D * es;
       } break;
@@ -1494,12 +1508,12 @@ static int bench_issue(wh_task* t, int kind, int iters, double* bytes_per_launch
       case 4:
         g.pro = PRO_LN; g.xf = t->x; g.xf_ld = D; g.ln_w = L.mlp_ln_w; g.ln_b = L.mlp_ln_b; g.ln_folded = (m->w.flags & WH_WEIGHTS_DEC_LN_FOLDED) ? 1 : 0;
         g.W = L.fc1_w; g.bias = L.fc1_b; g.N = 4 * D; g.K = D; g.R = R;
-        g.epi = EPI_GELU; g.y = t->h; g.y_ld = 4 * D;
+        g.epi = EPI_GELU; g.y = t->h; g.y_ld = 4 * D; g.y_frag = plan.frag_mlp;
         HIPCHK(launch_gemv(g, m->dtype, s));
         bytes = 4.0 * D * D * es;
         break;
       case 5:
-        g.pro = PRO_PLAIN; g.x = t->h; g.x_ld = 4 * D;
+        g.pro = PRO_PLAIN; g.x = t->h; g.x_ld = 4 * D; g.x_frag = plan.frag_mlp;
         g.W = L.fc2_w; g.bias = L.fc2_b; g.N = D; g.K = 4 * D; g.R = R;
         g.epi = EPI_STORE; g.y = t->att; g.y_ld = D;
         HIPCHK(launch_gemv(g, m->dtype, s));
@@ -1513,7 +1527,7 @@ static int bench_issue(wh_task* t, int kind, int iters, double* bytes_per_launch
         bytes = (double)V * D * es + (double)R * V * 4.0;
         break;
       case 7:
-        g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D;
+        g.pro = PRO_PLAIN; g.x = t->att; g.x_ld = D; g.x_frag = plan.frag_self;
         g.W = L.out_w; g.bias = L.out_b; g.N = D; g.K = D; g.R = R;
         g.epi = EPI_STORE; g.y = t->qbuf; g.y_ld = D;
         HIPCHK(launch_gemv(g, m->dtype, s));

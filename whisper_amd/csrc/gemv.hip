@@ -788,7 +788,7 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
   pin_kernargs(a);
   asm volatile("" ::"s"(fw));
   static_assert((PRO == whk::PRO_PLAIN) == (XW == 0), "prologue waves exist exactly when there is a prologue");
-  static_assert(PRO != whk::PRO_LN || KS == 4, "LayerNorm prologue: one wave-load of fp32 = 256 elements = 4 K blocks");
+  static_assert(PRO != whk::PRO_LN || KS == 4 || KS == 2, "LayerNorm prologue: one wave-load of fp32 = 256 elements = 4 K blocks");
   constexpr int MW = GS * KS;                              // weight (MFMA) waves; XW prologue waves in front of them
   constexpr int NT = (MW + XW) * 64;
   constexpr int RW = 8 * NRT;                              // rows per workgroup
@@ -805,7 +805,9 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
   (void)wgid;
   WH_PROBE_AT(a, wgid, 0);
 
-  half8v wa[NU], xb[NRT][NU];
+  // x fragments of a weight wave: all row tiles at once when they come from global memory (PRO_PLAIN: requested up front); with
+  // prologue waves they are read from LDS one row tile at a time, right before that tile's MFMAs (registers: NU, not NRT x NU)
+  half8v wa[NU], xb[XW ? 1 : NRT][XW ? 1 : NU];
   const int mw = wave - XW;
   const int kw = mw % KS;                                  // weight waves: split of K
 
@@ -856,17 +858,22 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
     constexpr int NR = XW ? (RW + XW - 1) / XW : 1;
     const float invK = 1.0f / (float)K;
     // LDS byte address of this lane's 4 elements of wave-load j, row r: + j * 1024 + (r / 8) * FRAG * 16 + (r % 8) * 16
-    const uint32_t fbase = (uint32_t)((lane >> 4) * NU * 64 + 16 * ((lane >> 1) & 3) + 8 * ((lane >> 3) & 1)) * 16u + (uint32_t)(lane & 1) * 8u;
-    constexpr int RB = NR > 3 ? 3 : NR;                    // rows in flight per wave (register budget: 3 x NU float4 = 60 VGPRs)
+    // (a wave-load of fp32 covers 4 K blocks: block 4 j + q, q = lane >> 4, is unit ((4 j + q) % KS, (4 j + q) / KS) — for KS = 4
+    // unit (q, j), for KS = 2 unit (q & 1, 2 j + (q >> 1)): a per-lane base plus j * JSTRIDE bytes)
+    constexpr int NJ = NU * KS / 4;                        // wave-loads of fp32 per row
+    constexpr int JSTRIDE = (4 / KS) * 1024;
+    const int q4 = lane >> 4;
+    const uint32_t fbase = (uint32_t)(((q4 % KS) * NU + q4 / KS) * 64 + 16 * ((lane >> 1) & 3) + 8 * ((lane >> 3) & 1)) * 16u + (uint32_t)(lane & 1) * 8u;
+    constexpr int RB = NR > 3 ? 3 : NR;                    // rows in flight per wave (register budget: 3 x NJ float4 = 60 VGPRs)
 #pragma unroll
     for (int i0 = 0; i0 < NR; i0 += RB) {
-      float4v v[RB][NU];
+      float4v v[RB][NJ];
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         const int r = wave + XW * (i0 + i);
         const char* src = (const char*)a.xf + (size_t)(r0 + (r < R ? r : R - 1)) * (size_t)a.xf_ld * 4;   // wave-uniform
 #pragma unroll
-        for (int j = 0; j < NU; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           int k = (j * 64 + lane) * 4; if (k > K - 4) k = K - 4;          // branch-free, masked at use
           v[i][j] = *(const float4v*)(src + (uint32_t)k * 4u);
         }
@@ -878,14 +885,14 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
         if (i0 + i < NR && r < RW) {
           float sum = 0.f;
 #pragma unroll
-          for (int j = 0; j < NU; ++j) {
+          for (int j = 0; j < NJ; ++j) {
             const float t = (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
             sum += ((j * 64 + lane) * 4 < K) ? t : 0.f;
           }
           const float mean = wave_sum(sum) * invK;
           float ss = 0.f;
 #pragma unroll
-          for (int j = 0; j < NU; ++j) {
+          for (int j = 0; j < NJ; ++j) {
             if ((j * 64 + lane) * 4 < K) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) { const float d = v[i][j][e] - mean; ss = __builtin_fmaf(d, d, ss); }
@@ -894,12 +901,12 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
           const float rstd = rsqrtf(wave_sum(ss) * invK + 1e-5f);
           const uint32_t rbase = fbase + (uint32_t)((r >> 3) * FRAG * 16 + (r & 7) * 16);
 #pragma unroll
-          for (int j = 0; j < NU; ++j) {
+          for (int j = 0; j < NJ; ++j) {
             const bool on = (j * 64 + lane) * 4 < K;
             half4v o4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o4[e] = on ? (half_t)((v[i][j][e] - mean) * rstd) : (half_t)0.f;
-            *(half4v*)((char*)xfrag + rbase + (uint32_t)(j * 1024)) = o4;
+            *(half4v*)((char*)xfrag + rbase + (uint32_t)(j * JSTRIDE)) = o4;
           }
         }
       }
@@ -996,14 +1003,8 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
   }
   if (!XW) WH_PROBE_AT(a, wgid, 1);
 
-  if (XW) {
+  if constexpr (XW != 0) {
     __syncthreads();
-    if (!is_x) {
-#pragma unroll
-      for (int rt = 0; rt < NRT; ++rt)
-#pragma unroll
-        for (int u = 0; u < NU; ++u) xb[rt][u] = xfrag[rt * FRAG + (kw * NU + u) * 64 + lane];
-    }
   } else {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -1023,8 +1024,16 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) {
       float4v acc = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (XW != 0) {
+        half8v xt[NU];
 #pragma unroll
-      for (int u = 0; u < NU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u], xb[rt][u], acc, 0, 0, 0);
+        for (int u = 0; u < NU; ++u) xt[u] = xfrag[rt * FRAG + (kw * NU + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u], xt[u], acc, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u], xb[rt][u], acc, 0, 0, 0);
+      }
       // lane holds C[m = 4 (lane >> 4) + e][n = lane & 15]; valid where (m >> 3) == (n >> 3)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -1084,9 +1093,14 @@ hipError_t launch_gemv8_nrt(const whk::GemvArgs& a, int fw, hipStream_t stream) 
   const int nblk = a.K / 64;
   const int nu = (nblk + KS - 1) / KS;
   dim3 grid((a.N + fw - 1) / fw, (a.R + 8 * NRT - 1) / (8 * NRT)), block(WAVES * 64);
-  if (nu <= 3) hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 3, CSm, XW, NRT>), grid, block, 0, stream, a, fw);
-  else if (nu <= 5) hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 5, CSm, XW, NRT>), grid, block, 0, stream, a, fw);
-  else return hipErrorInvalidValue;
+  if constexpr (KS == 2) {         // the 3-slot LayerNorm projection of 9+ rows: K <= 1280 as 2 splits x 10 wave-loads
+    if (nu > 10) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 10, CSm, XW, NRT>), grid, block, 0, stream, a, fw);
+  } else {
+    if (nu <= 3) hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 3, CSm, XW, NRT>), grid, block, 0, stream, a, fw);
+    else if (nu <= 5) hipLaunchKernelGGL((gemv8_kernel<PRO, GS, KS, 5, CSm, XW, NRT>), grid, block, 0, stream, a, fw);
+    else return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 
@@ -1132,6 +1146,13 @@ hipError_t launch_gemv8_pro(const whk::GemvArgs& a, hipStream_t stream) {
   } else {
     if (nblk > 20) return hipErrorNotSupported;              // the prologue waves cover K <= 1280
     if constexpr (PRO == whk::PRO_LN) {
+      // 3 slots (4D x D of large-v3: 256 workgroups x 20 features).  Up to 8 rows: 12 weight waves + 4 LayerNorm waves of 2 rows.
+      // From 9 rows on the 4 LayerNorm waves (6 rows each at 24 rows, two round trips) were the launch's long pole (9280 of its
+      // 13 984 cycles, tools/probe_gemv8 24): 6 weight waves of 10 wave-loads + 8 LayerNorm waves of 3 rows, one round trip.
+      if (gs == 3 && a.R > 8 && !WH_DEV_FLAG("WH_GEMV8_LN3_KS4")) {
+        if (a.R <= 16) return launch_gemv8_nrt<PRO, 3, 2, CSm, 8, 2>(a, fw, stream);
+        return launch_gemv8_nrt<PRO, 3, 2, CSm, 8, 3>(a, fw, stream);
+      }
       if (gs == 3) return launch_gemv8_cfg<PRO, 3, 4, CSm, 4>(a, fw, stream);
       if (gs == 2) return launch_gemv8_cfg<PRO, 2, 4, CSm, 8>(a, fw, stream);
     }
