@@ -17,7 +17,7 @@ PATTERNS = {
     "attn_decode_self": rf"(sattn8_kernel|attn_decode_kernelIDF16_Li8ELi8ELb1E.*grid=\(512,20,{ROWS}\))",
     # gemv8_kernel<PRO, GS, KS, NU, CSm, XW, NRT>: LN = 1, PLAIN = 0, COMBINE = 2
     "gemv_qkv": rf"gemv8_kernel<1, 2, 4, 5, 1, 8, {NRT}>",
-    "gemv_fc1": rf"gemv8_kernel<1, 3, 4, 5, 1, 4, {NRT}>",
+    "gemv_fc1": rf"gemv8_kernel<1, 3, 4, 5, 1, 4, {NRT}>" if ROWS <= 8 else rf"gemv8_kernel<1, 3, 2, 10, 1, 8, {NRT}>",   # 9+ rows: 8 LayerNorm waves
     "gemv_fc2": rf"gemv8_kernel<0, 1, 16, 5, 1, 0, {NRT}>",
     "gemv_out": rf"gemv8_kernel<0, 1, 4, 5, 1, 0, {NRT}>",
     "gemv_cq": rf"gemv8_kernel<1, 1, 4, 5, 1, 8, {NRT}>",
