@@ -1240,6 +1240,9 @@ static hipError_t launch_attn_decode_t(const DecAttnArgs& a, hipStream_t stream)
 hipError_t launch_attn_decode(const DecAttnArgs& a, int dtype, hipStream_t stream) {
   // a split must fit the register-resident K/V tile: callers size `splits` with attn_decode_capacity()
   if (a.splits < 1 || a.splits > DEC_ATTN_MAX_SPLITS) return hipErrorInvalidValue;
+  // the in-launch merge exists in attn_decode_kernel<half> only, for up to 4 splits: anything else must not be asked for silently
+  if (a.merge_cnt && (dtype != 1 || a.kv_group != 1 || a.splits < 2 || a.splits > 4 || !a.out)) return hipErrorInvalidValue;
+  if (a.o_frag && dtype != 1) return hipErrorInvalidValue;
   if ((int64_t)a.k_ld * 2048 > 0x7fffffff || (int64_t)a.v_ld * 2048 > 0x7fffffff) return hipErrorInvalidValue;
   return dtype == 1 ? launch_attn_decode_t<half_t>(a, stream) : launch_attn_decode_t<float>(a, stream);
 }

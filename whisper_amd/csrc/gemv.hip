@@ -1543,6 +1543,13 @@ namespace whk {
 
 hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream) {
   if (a.R <= 0) return hipErrorInvalidValue;
+  if (a.x_frag || a.y_frag) {
+    // only gemv8_kernel knows the fragment order (kernels.h): a caller that asks for it where that kernel does not run must hear
+    // about it (api.cpp::step_plan asks gemv8_will_run first) — never row-major arithmetic on fragment-order bytes
+    if (dtype != 1 || a.R > WH_GEMV8_MAX_ROWS) return hipErrorInvalidValue;
+    const hipError_t e = launch_gemv8(a, stream);
+    return e == hipErrorNotSupported ? hipErrorInvalidValue : e;
+  }
   if (dtype == 1) {
     // the decode step (and the few-row prefill, and beam-search rows): MFMA diagonal form
     // More rows (beam search: 8 clips x 5 beams = 40): every workgroup reads ALL x rows, so beyond 8 rows the x
@@ -1566,6 +1573,7 @@ hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream) {
       const hipError_t e = launch_gemv8(a, stream);
       if (e != hipErrorNotSupported) return e;
     }
+
     if (a.R <= 4) return launch_rt<half_t, 4>(a, stream);
     // beam-search row counts: row tiles of 16 through the matrix cores while x (16 rows) fits in LDS
     if (a.R > 8 && a.variant <= 0 && a.K % 128 == 0 && a.K <= 5120 && (a.K / 32 <= 40 || a.pro == whk::PRO_PLAIN))
