@@ -80,6 +80,7 @@ int main(int argc, char** argv) {
         whk::GemvArgs a; memset(&a, 0, sizeof(a));
         a.pro = c.pro; a.x = way && fragx && c.pro == whk::PRO_PLAIN ? xh_frag : xh; a.x_frag = way && fragx && c.pro == whk::PRO_PLAIN; a.x_ld = c.K; a.xf = xf; a.xf_ld = D; a.ln_w = lnw; a.ln_b = lnb; a.ln_folded = 1;
         a.part_o = part_o; a.part_ml = part_ml; a.splits = 3; a.H = H;
+        a.w_ordered = way && getenv("PROBE_WORD") ? atoi(getenv("PROBE_WORD")) : 0;
         a.W = W + c.woff; a.bias = bias; a.N = c.Nn; a.K = c.K; a.R = R;
         a.epi = c.epi; a.y = y; a.y_ld = c.Nn; a.resid = resid; a.resid_ld = D;
         CK(hipMemcpy(resid, res0.data(), res0.size() * 4, hipMemcpyHostToDevice));
@@ -101,6 +102,7 @@ int main(int argc, char** argv) {
       a.part_o = part_o; a.part_ml = part_ml; a.splits = 3; a.H = H;
       a.W = W + wl * (i % L) + c.woff; a.bias = bias; a.N = c.Nn; a.K = c.K; a.R = R;
       if (fragx && c.pro == whk::PRO_PLAIN) { a.x = xh_frag; a.x_frag = 1; }
+      a.w_ordered = getenv("PROBE_WORD") ? atoi(getenv("PROBE_WORD")) : 0;
       a.epi = c.epi; a.y = y; a.y_ld = c.Nn; a.resid = resid; a.resid_ld = D;
       a.probe = i == N - 1 ? d_probe : nullptr;
       a.variant = variant == 99 ? -1 : variant;      // -1: the v_dot2 kernels

@@ -795,6 +795,10 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
   constexpr int FRAG = KS * NU * 64;                       // x fragment units of one row tile
   __shared__ float red[MW][NRT][8][8];                     // [weight wave][row tile][feature][row] partial sums
   __shared__ __attribute__((aligned(16))) half8v xfrag[XW ? NRT * FRAG : 1];   // [row tile][kw][u][lane]
+  // memory-order weight loads pay only where a workgroup issues MANY of them next to as many x loads: the 16-wave K = 5120 shape
+  // (FC2: 7.65 -> 7.30 us at 24 rows, 5.80 -> 5.44 at 8; the 4-wave and LayerNorm shapes lose 0.1 - 0.3 us, tools/probe_gemv8)
+  constexpr bool W_ORDERED_OK = PRO == whk::PRO_PLAIN && KS == 16;
+  __shared__ __attribute__((aligned(16))) half8v turn[W_ORDERED_OK ? MW : 1][64];   // one wave-load per weight wave
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_x = wave < XW;                             // wave-uniform role
@@ -817,8 +821,14 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
     const int idx = lane & 7, koff = ((lane >> 3) & 1) * 32 + (lane >> 4) * 8;
     // rows beyond the workgroup's range re-read its last row (same cache lines: no extra requests); their outputs are dropped
     int n_last = (blockIdx.x + 1) * fw - 1; if (n_last > a.N - 1) n_last = a.N - 1;
-    int n = blockIdx.x * fw + (mw / KS) * 8 + idx; if (n > n_last) n = n_last;
-    const uint32_t lane_off = ((uint32_t)n * (uint32_t)K + (uint32_t)koff) * 2u;
+    // W_ORDERED: the lanes in MEMORY order — lane 8 r + s requests piece s ^ r (16 bytes) of row r's 128-byte block — and the
+    // operand order restored through 1 KB of wave-private LDS before the MFMAs (turn[]): the same 8 lines, a third of the
+    // memory pipeline's cycles per wave-load (kernels.h "fragment order")
+    const bool w_ordered = W_ORDERED_OK && a.w_ordered;
+    const int wrow = w_ordered ? (lane >> 3) : idx;
+    const int wpiece = w_ordered ? ((lane & 7) ^ (lane >> 3)) : (4 * ((lane >> 3) & 1) + (lane >> 4));
+    int n = blockIdx.x * fw + (mw / KS) * 8 + wrow; if (n > n_last) n = n_last;
+    const uint32_t lane_off = ((uint32_t)n * (uint32_t)K + (uint32_t)wpiece * 8u) * 2u;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       int blk = kw + KS * u; if (blk > nblk - 1) blk = nblk - 1;          // wave-uniform; clamped, masked through x == 0
@@ -1020,6 +1030,16 @@ __global__ __launch_bounds__((GS * KS + XW) * 64) void gemv8_kernel(whk::GemvArg
 
   // ---- weight waves: NU MFMAs per row tile, C[m][n] with m = weight row (+8: second half), n = batch row (+8: second half)
   if (!is_x) {
+    if (W_ORDERED_OK && a.w_ordered) {
+      const int i8 = lane & 7, rd = 8 * i8 + ((4 * ((lane >> 3) & 1) + (lane >> 4)) ^ i8);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        turn[mw][lane] = wa[u];
+        __builtin_amdgcn_wave_barrier();
+        wa[u] = turn[mw][rd];
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
     const bool diag = (lane >> 5) == ((lane >> 3) & 1);
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) {
@@ -1130,7 +1150,7 @@ static int gemv8_fw(int N, int gs) {
 //   D x D [160 workgroups] and 3D x D [2 feature-group slots, 240 workgroups]: 8 prologue waves, one row each;
 //   4D x D: 3 slots [214 workgroups of 4 + 12 waves] — a launch costs about
 //   1.5 us + (12.6 cycles x HBM lines + 3.7 cycles x L2 lines requested by the busiest CU) / clock.
-// feature-group slots per workgroup for (N, prologue) — the one place the launcher and the fragment-order packer take it from
+// feature-group slots per workgroup for (N, prologue)
 static int gemv8_slots(int N, int pro) {
   const int ngroups = (N + 7) / 8;
   if (pro == whk::PRO_LN) return ngroups >= 600 ? 3 : ngroups >= 400 ? 2 : 1;
@@ -1141,7 +1161,11 @@ template <int PRO, int CSm>
 hipError_t launch_gemv8_pro(const whk::GemvArgs& a, hipStream_t stream) {
   const int nblk = a.K / 64, gs = gemv8_slots(a.N, PRO), fw = gemv8_fw(a.N, gs);
   if constexpr (PRO == whk::PRO_PLAIN) {
-    if (nblk > 20) return launch_gemv8_cfg<PRO, 1, 16, CSm, 0>(a, fw, stream);
+    if (nblk > 20) {
+      whk::GemvArgs b = a;
+      b.w_ordered = !WH_DEV_FLAG("WH_GEMV8_W_OPERAND_ORDER");      // developer A/B: 1 = operand-order weight loads as everywhere else
+      return launch_gemv8_cfg<PRO, 1, 16, CSm, 0>(b, fw, stream);
+    }
     return launch_gemv8_cfg<PRO, 1, 4, CSm, 0>(a, fw, stream);
   } else {
     if (nblk > 20) return hipErrorNotSupported;              // the prologue waves cover K <= 1280
@@ -1573,7 +1597,6 @@ hipError_t launch_gemv(const GemvArgs& a, int dtype, hipStream_t stream) {
       const hipError_t e = launch_gemv8(a, stream);
       if (e != hipErrorNotSupported) return e;
     }
-
     if (a.R <= 4) return launch_rt<half_t, 4>(a, stream);
     // beam-search row counts: row tiles of 16 through the matrix cores while x (16 rows) fits in LDS
     if (a.R > 8 && a.variant <= 0 && a.K % 128 == 0 && a.K <= 5120 && (a.K / 32 <= 40 || a.pro == whk::PRO_PLAIN))

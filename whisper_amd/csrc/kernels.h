@@ -216,6 +216,7 @@ struct GemvArgs {
   // gemv8_kernel only (fp16, R <= 24; every other kernel ignores them — set them only where gemv8_will_run says so):
   int x_frag;                                     // PRO_PLAIN: x holds FRAGMENT-ORDER rows (below), K columns; x_ld ignored
   int y_frag;                                     // EPI_STORE / EPI_GELU: write y in fragment order (N % 64 == 0); y_ld ignored
+  int w_ordered;                                  // set by the launcher (gemv.hip): weight wave-loads in memory order + a turn through LDS
   // epilogue
   int epi;
   void* y; int64_t y_ld;                          // EPI_STORE / EPI_GELU (element type), EPI_F32 (float)
