@@ -119,6 +119,63 @@ def test_fused_step_kernels_equal_two_launch_form(gpu_device, name, B, T0):
         assert (out.argmax(-1) == plain.argmax(-1)).float().mean().item() > 0.98
 
 
+def test_in_launch_merge_is_deterministic_alone_and_beside_other_chains(gpu_device):
+    """csrc/attention.hip, DecAttnArgs::merge_cnt (<= 16 rows, 2 - 4 key splits, fp16): the last workgroup of a (row, head) to finish
+    merges the key splits of the cross attention inside the launch — write-through partials, a ticket per (row, head), nobody
+    waits.  Whichever workgroup draws the last ticket does the same arithmetic on the same fp16 partials, so a decode must give
+    the same tokens and log-probabilities every time it is run: alone, and with two other chains (their own tasks, streams and
+    ticket counters) on the chip.  Closeness to the oracle at these row counts is test_wide_prefill_and_steps' job (9, 12, 13,
+    16 rows); the tickets being back at zero after every launch is what lets the repetitions agree."""
+    import threading
+    from whisper_amd.tokenizer import get_tokenizer
+    dims = oracle.dims_for("wide-v3")
+    sd = oracle.synthetic_state_dict(dims, seed=11)
+    model = hip.HipModel(dims, hip.WH_F16, hip.pack_weights(sd, dims, hip.WH_F16, gpu_device))
+    tok = get_tokenizer(True, num_languages=dims.n_vocab - 51765 - 1, language="en", task="transcribe")
+    init = list(tok.sot_sequence)
+    T0, N = len(init), 40
+    feats = _feats(dims, 16, seed=78).to(gpu_device).half().contiguous()
+    mask = torch.zeros(dims.n_vocab, dtype=torch.uint8, device=gpu_device)
+    mask[tok.eot] = 1
+    params = hip.GreedyParams(sample_begin=T0, max_steps=N, n_ctx=dims.n_text_ctx, eot=tok.eot, timestamp_begin=tok.timestamp_begin,
+                              no_timestamps=tok.no_timestamps, max_initial_timestamp_index=50, suppress_blank=1,
+                              blank_token=tok.encode(" ")[0], suppress_mask=mask.data_ptr())
+
+    def run(B, stream, reps, out):
+        try:
+            torch.cuda.set_device(gpu_device)
+            task = hip.HipTask(model, B, 1, 8, stream=stream, two_launch_cross=True)
+            res = []
+            try:
+                for _ in range(reps):
+                    task.reset()
+                    task.set_audio(feats[:B].contiguous())
+                    tokens = torch.zeros(B, T0 + N + 1, dtype=torch.int64, device=gpu_device)
+                    tokens[:, :T0] = torch.tensor(init, device=gpu_device)
+                    n, lp, _ = task.greedy(tokens, params, 0, tok.no_speech)
+                    res.append((n, tokens.cpu(), lp.cpu()))
+            finally:
+                task.close()
+            out[B] = res
+        except Exception as e:                               # noqa: BLE001 — reported by the asserting thread
+            out[B] = e
+
+    alone = {}
+    for B in (8, 12, 16):                                    # 3 key splits at each of these row counts (20 heads)
+        run(B, torch.cuda.Stream(device=gpu_device), 3, alone)
+        assert not isinstance(alone[B], Exception), alone[B]
+        for n, t, lp in alone[B][1:]:
+            assert n == alone[B][0][0] and torch.equal(t, alone[B][0][1]) and torch.equal(lp, alone[B][0][2])
+    beside = {}
+    th = [threading.Thread(target=run, args=(B, torch.cuda.Stream(device=gpu_device), 3, beside)) for B in (8, 12, 16)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for B in (8, 12, 16):
+        assert not isinstance(beside[B], Exception), beside[B]
+        for n, t, lp in beside[B]:
+            assert n == alone[B][0][0] and torch.equal(t, alone[B][0][1]) and torch.equal(lp, alone[B][0][2])
+
+
 def test_handoff_timeout_falls_back_to_two_launch_kernels(gpu_device):
     """A hand-off spin that runs out (forced here: the fault-injection flag WH_TASK_EXPIRE_HANDOFFS lets every consumer give
     up after its first poll) must not cost the result: wh_task_greedy counts the time-outs, moves the task to the two-launch kernels, re-runs
